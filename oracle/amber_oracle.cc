@@ -1,0 +1,1016 @@
+/*
+ * amber_oracle.cc -- CPU ORACLE (test infrastructure, NOT product code; see amber_oracle.h).
+ *
+ * A from-scratch restatement of the reference's unidirectional path tracer and everything it
+ * calls.  All arithmetic is IEEE binary32 with the reference's operation order, no FMA
+ * contraction (build: -ffp-contract=off, no -mfma), double / long double only where the
+ * reference's own expressions promote (noted per function).  File:line citations are relative
+ * to /root/reference.
+ *
+ * Two knobs that the reference does not have, both needed to compare against a GPU:
+ *   math  = LIBM      glibc sinf/cosf/powf/pow exactly as the reference calls them
+ *         = PORTABLE  sin/cos/pow built from + - * / sqrt and integer ops only, so that the
+ *                     same sequence is bit-identical on x86 and gfx950
+ *   accel = BVH       the reference's SAH BVH (build + recursive ordered traversal + SSE slab)
+ *         = LIST      the reference's brute-force List acceleration (acceleration_list.h:51-68)
+ */
+#include "amber_oracle.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// constants  (include/amber/constants.h:25-28 -- all long double in the reference)
+// ------------------------------------------------------------------------------------------
+const long double kPI = 3.141592653589793238462643383279503L;
+const long double kEPS = 1e-6L;
+const long double kRussianRoulette = 0.9375L;
+const float kPIf = static_cast<float>(kPI);
+
+// ------------------------------------------------------------------------------------------
+// Vector3 (include/amber/prelude/vector3.h:36-342).  boost::field_operators generates
+// component-wise + - * / from the compound forms; scalars convert through Vector3(const T&).
+// ------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 splat(float s) { return V3{s, s, s}; }                        // vector3.h:163-168
+inline V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }   // :198-203
+inline V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }   // :205-210
+inline V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }   // :212-217
+inline V3 operator/(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }   // :219-224
+inline V3 operator*(float s, V3 v) { return splat(s) * v; }
+inline V3 operator*(V3 v, float s) { return v * splat(s); }
+inline V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }              // :191-196
+inline float Dot(V3 u, V3 v) { return u.x * v.x + u.y * v.y + u.z * v.z; }        // :290-295
+inline float SquaredLength(V3 v) { return Dot(v, v); }
+inline float Length(V3 v) { return std::sqrt(SquaredLength(v)); }
+inline V3 Normalize(V3 v) { const float l = Length(v); return V3{v.x / l, v.y / l, v.z / l}; }  // :311-317
+inline V3 Cross(V3 u, V3 v) {                                           // :319-328
+  return V3{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+}
+inline float Max3(V3 v) { return std::max({v.x, v.y, v.z}); }           // :276-281
+inline void OrthonormalBasis(V3 w, V3& u, V3& v) {                      // :330-342
+  u = Normalize(Cross(w, std::abs(w.x) < std::abs(w.y) ? v3(1, 0, 0) : v3(0, 1, 0)));
+  v = Normalize(Cross(w, u));
+}
+
+struct Ray { V3 o, d; };
+struct Hit {                                                            // hit.h:61-94
+  V3 pos{0, 0, 0}, n{0, 0, 0};
+  float t = std::numeric_limits<float>::quiet_NaN();
+  explicit operator bool() const { return std::isfinite(t); }
+};
+inline Hit MakeHitN(V3 p, V3 n_raw, float t) { Hit h; h.pos = p; h.n = Normalize(n_raw); h.t = t; return h; }  // hit.h:68-77
+inline Hit MakeHitU(V3 p, V3 n_unit, float t) { Hit h; h.pos = p; h.n = n_unit; h.t = t; return h; }          // hit.h:79-88
+
+// ------------------------------------------------------------------------------------------
+// math modes
+// ------------------------------------------------------------------------------------------
+// PORTABLE sin/cos: Cody-Waite 3-term reduction by multiples of pi/4 and the Cephes
+// single-precision minimax polynomials (published algorithm: S. Moshier, Cephes sinf.c/cosf.c),
+// written with separate mul/add only.  Valid for 0 <= phi <= ~8 (the path only needs [0, 2pi]).
+void PortableSinCos(float x, float* s_out, float* c_out) {
+  const float FOPI = 1.27323954473516f;         // 4/pi
+  const float DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
+  int j = static_cast<int>(FOPI * x);           // x >= 0
+  j += (j & 1);                                 // map to even octant boundary
+  const float y = static_cast<float>(j);
+  const float r = ((x - y * DP1) - y * DP2) - y * DP3;
+  const float z = r * r;
+  // sin polynomial on [-pi/4, pi/4]
+  float ps = ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * r + r;
+  // cos polynomial on [-pi/4, pi/4]
+  float pc = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z + 4.166664568298827E-002f) * z * z
+             - 0.5f * z + 1.0f;
+  const int q = (j >> 1) & 3;                   // quadrant: angle = r + q*pi/2
+  float s, c;
+  switch (q) {
+    case 0: s = ps; c = pc; break;
+    case 1: s = pc; c = -ps; break;
+    case 2: s = -ps; c = -pc; break;
+    default: s = -pc; c = ps; break;
+  }
+  *s_out = s; *c_out = c;
+}
+
+inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+// PORTABLE pow(x, y) for x >= 0: exp2(y * log2(x)) from + - * / and integer ops only.
+// log: atanh series on m in [sqrt(1/2), sqrt(2)); exp: Taylor in t = g*ln2, |g| <= 1/2.
+float PortablePow(float x, float y) {
+  if (y == 0.0f) return 1.0f;
+  if (x == 0.0f) return y > 0.0f ? 0.0f : std::numeric_limits<float>::infinity();
+  if (x == 1.0f) return 1.0f;
+  uint32_t bits = f2u(x);
+  int e = static_cast<int>((bits >> 23) & 0xff);
+  if (e == 0) {  // subnormal: scale up by 2^24 exactly
+    x = x * 16777216.0f; bits = f2u(x); e = static_cast<int>((bits >> 23) & 0xff) - 24;
+  }
+  e -= 127;
+  float m = u2f((bits & 0x007fffffu) | 0x3f800000u);    // [1, 2)
+  if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+  const float f = m - 1.0f;
+  const float s = f / (2.0f + f);
+  const float z = s * s;
+  // ln(m) = 2s (1 + z/3 + z^2/5 + z^3/7 + z^4/9 + z^5/11)
+  float p = 0.0909090909f;
+  p = p * z + 0.111111111f;
+  p = p * z + 0.142857143f;
+  p = p * z + 0.2f;
+  p = p * z + 0.333333333f;
+  p = p * z + 1.0f;
+  const float ln_m = 2.0f * s * p;
+  const float log2x = static_cast<float>(e) + ln_m * 1.44269504f;
+  const float w = y * log2x;
+  if (w >= 128.0f) return std::numeric_limits<float>::infinity();
+  if (w < -149.0f) return 0.0f;
+  const float nf = std::floor(w + 0.5f);
+  const float g = w - nf;
+  const float t = g * 0.693147181f;
+  float q = 1.98412698e-4f;               // 1/5040
+  q = q * t + 1.38888889e-3f;             // 1/720
+  q = q * t + 8.33333333e-3f;             // 1/120
+  q = q * t + 4.16666667e-2f;             // 1/24
+  q = q * t + 1.66666667e-1f;             // 1/6
+  q = q * t + 0.5f;
+  q = q * t + 1.0f;
+  q = q * t + 1.0f;
+  int n = static_cast<int>(nf);
+  // scale by 2^n in two exact steps (keeps subnormal results correctly rounded once)
+  if (n < -126) { q = q * u2f(static_cast<uint32_t>(n + 126 + 127) << 23); n = -126; }
+  return q * u2f(static_cast<uint32_t>(n + 127) << 23);
+}
+
+struct Math {
+  int mode;
+  void sincos(float phi, float& s, float& c) const {
+    if (mode == ORACLE_MATH_LIBM) { c = std::cos(phi); s = std::sin(phi); }   // sampling.h:248-249 (cosf/sinf)
+    else PortableSinCos(phi, &s, &c);
+  }
+  float powf_(float x, float y) const {                                       // sampling.h:279 (powf)
+    return mode == ORACLE_MATH_LIBM ? std::pow(x, y) : PortablePow(x, y);
+  }
+  // std::pow(float, int) promotes to double pow (C++11 [c.math]); used with exponents 2, 4, 5.
+  double pow_i(float x, int n) const {
+    if (mode == ORACLE_MATH_LIBM) return std::pow(x, n);
+    const double d = x, d2 = d * d;            // exact (24+24 bits)
+    if (n == 2) return d2;
+    const double d4 = d2 * d2;                 // one rounding
+    if (n == 4) return d4;
+    return d4 * d;                             // n == 5
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Samplers (include/amber/prelude/sampling.h:35-57, 148-175)
+// ------------------------------------------------------------------------------------------
+struct Sampler { virtual double operator()() = 0; virtual ~Sampler() {} };
+
+// GenericSampler<std::mt19937_64>: uniform_real_distribution<double>(0,1)(engine) in libstdc++
+// is generate_canonical<double,53> = double(x) / 2^64, clamped below 1 (verified in
+// tests/test_oracle_pin.py against std::uniform_real_distribution on this toolchain).
+struct MTSampler : Sampler {
+  std::mt19937_64 engine;
+  explicit MTSampler(uint64_t seed) : engine(seed) {}
+  double operator()() override {
+    double r = static_cast<double>(engine()) * 0x1p-64;
+    if (r >= 1.0) r = std::nextafter(1.0, 0.0);
+    return r;
+  }
+};
+
+// per-(pixel,sample) XorShift sampler (the north-star's "XorShift sampler"; the reference has
+// none -- SURVEY.md section 0).  Spec shared with the product: splitmix64-hashed seed, Marsaglia
+// xorshift64 (13,7,17), uniform = top 24 bits * 2^-24 (exact in float, never 1.0).
+inline uint64_t SplitMix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+inline uint64_t XorShiftSeed(uint64_t global_seed, uint32_t pixel, uint32_t sample) {
+  const uint64_t key = (static_cast<uint64_t>(pixel) << 32) | sample;
+  uint64_t s = SplitMix64(SplitMix64(global_seed) ^ key);
+  return s ? s : 0x9E3779B97F4A7C15ull;
+}
+struct XorShiftSampler : Sampler {
+  uint64_t s;
+  explicit XorShiftSampler(uint64_t state) : s(state) {}
+  double operator()() override {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    return static_cast<double>(s >> 40) * 0x1p-24;
+  }
+};
+struct ArraySampler : Sampler {   // feeds fixed uniforms (known-answer tests)
+  const double* u; uint32_t n, i = 0;
+  ArraySampler(const double* u_, uint32_t n_) : u(u_), n(n_) {}
+  double operator()() override { return i < n ? u[i++] : (i++, 0.5); }
+};
+
+inline float UniformF(Sampler& s) { return static_cast<float>(s()); }          // sampling.h:156-161
+inline float UniformF(float max, Sampler& s) { return static_cast<float>(s()) * max; }  // :163-168
+
+// sampling.h:234-265 (HemispherePSA), 267-300 (CosinePower); results are casts, not renormalised.
+V3 HemispherePSA(V3 w, Sampler& smp, const Math& M) {
+  V3 u, v; OrthonormalBasis(w, u, v);
+  const float r0 = UniformF(smp);
+  const float r1 = UniformF(smp);
+  const float cos_theta = std::sqrt(r0);
+  const float sin_theta = std::sqrt(1 - r0);
+  const float phi = 2 * kPIf * r1;
+  float sp, cp; M.sincos(phi, sp, cp);
+  return u * sin_theta * cp + v * sin_theta * sp + w * cos_theta;
+}
+V3 CosinePower(V3 w, float exponent, Sampler& smp, const Math& M) {
+  V3 u, v; OrthonormalBasis(w, u, v);
+  const float r0 = UniformF(smp);
+  const float r1 = UniformF(smp);
+  const float cos_theta = M.powf_(r0, 1 / (exponent + 1));
+  const float sin_theta = std::sqrt(1 - cos_theta * cos_theta);
+  const float phi = 2 * kPIf * r1;
+  float sp, cp; M.sincos(phi, sp, cp);
+  return u * sin_theta * cp + v * sin_theta * sp + w * cos_theta;
+}
+inline V3 PerfectReflection(V3 incident, V3 normal, float signed_cos) {   // geometry.h:38-47
+  return 2 * signed_cos * normal - incident;
+}
+
+// ------------------------------------------------------------------------------------------
+// AABB (include/amber/prelude/aabb.h:35-171, src/amber/prelude/aabb.cc:28-62)
+// ------------------------------------------------------------------------------------------
+struct AABB { V3 mn, mx; };
+inline AABB EmptyBox() { return AABB{splat(FLT_MAX), splat(-FLT_MAX)}; }
+inline AABB Union(const AABB& a, const AABB& b) {                        // aabb.h:117-132
+  return AABB{v3(std::min(a.mn.x, b.mn.x), std::min(a.mn.y, b.mn.y), std::min(a.mn.z, b.mn.z)),
+              v3(std::max(a.mx.x, b.mx.x), std::max(a.mx.y, b.mx.y), std::max(a.mx.z, b.mx.z))};
+}
+inline float SurfaceArea(const AABB& bb) {                              // aabb.h:164-171
+  const V3 s = v3(bb.mx.x - bb.mn.x, bb.mx.y - bb.mn.y, bb.mx.z - bb.mn.z);
+  return 2 * (s.x * s.y + s.y * s.z + s.z * s.x);
+}
+// SSE semantics: _mm_min_ps(a,b) = a < b ? a : b ; _mm_max_ps(a,b) = a > b ? a : b (b on NaN)
+inline float sse_min(float a, float b) { return a < b ? a : b; }
+inline float sse_max(float a, float b) { return a > b ? a : b; }
+bool SlabTest(const AABB& bb, const Ray& ray, float t_max, float& t_in, float& t_out) {  // aabb.cc:28-62
+  float t_min = 0;
+  const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;
+  const float t0x = (bb.mn.x - ray.o.x) * ix, t0y = (bb.mn.y - ray.o.y) * iy, t0z = (bb.mn.z - ray.o.z) * iz;
+  const float t1x = (bb.mx.x - ray.o.x) * ix, t1y = (bb.mx.y - ray.o.y) * iy, t1z = (bb.mx.z - ray.o.z) * iz;
+  t_min = std::max({t_min, sse_min(t0x, t1x), sse_min(t0y, t1y), sse_min(t0z, t1z)});
+  t_max = std::min({t_max, sse_max(t0x, t1x), sse_max(t0y, t1y), sse_max(t0z, t1z)});
+  t_in = t_min; t_out = t_max;
+  return t_min <= t_max;
+}
+
+// ------------------------------------------------------------------------------------------
+// Primitives (src/amber/scene/primitive_*.cc)
+// ------------------------------------------------------------------------------------------
+struct Object {
+  uint32_t kind = 0, material = 0;
+  V3 a{0, 0, 0}, b{0, 0, 0}, c{0, 0, 0};   // triangle: v0 v1 v2 ; sphere: a=center ; disk/cyl: a=center b=normal
+  float radius = 0, height = 0;
+  V3 normal{0, 0, 0};                       // triangle: Normalize(Cross(v1-v0, v2-v0)), primitive_triangle.cc:59-68
+  AABB cyl_bb = EmptyBox();
+  uint32_t index = 0;                       // insertion index
+};
+
+// algebra.h:31-52
+bool SolveQuadratic(float a, float b, float c, float& alpha, float& beta) {
+  const float d = b * b - 4 * a * c;
+  if (d < 0) return false;
+  const float sqrt_d = std::sqrt(d);
+  alpha = -b - sqrt_d;
+  beta = -b + sqrt_d;
+  if (std::abs(alpha) < std::abs(beta)) { alpha = c / beta * 2; beta /= 2 * a; }
+  else { beta = c / alpha * 2; alpha /= 2 * a; }
+  return true;
+}
+
+Hit IntersectTriangle(const Object& o, const Ray& ray) {               // primitive_triangle.cc:97-128
+  const V3 E1 = o.b - o.a;
+  const V3 E2 = o.c - o.a;
+  const V3 P = Cross(ray.d, E2);
+  const float det = Dot(P, E1);
+  const V3 T = ray.o - o.a;
+  const float u = Dot(P, T) / det;
+  if (u > 1 || u < 0) return Hit();
+  const V3 Q = Cross(T, E1);
+  const float v = Dot(Q, ray.d) / det;
+  if (v > 1 || v < 0) return Hit();
+  if (u + v > 1) return Hit();
+  const float t = Dot(Q, E2) / det;
+  if (t < kEPS) return Hit();                                           // float vs long double 1e-6L
+  return MakeHitU(o.a + u * E1 + v * E2, o.normal, t);
+}
+Hit IntersectSphere(const Object& o, const Ray& ray) {                 // primitive_sphere.cc:75-107
+  const float a = 1.0f;
+  const float b = -2 * Dot(o.a - ray.o, ray.d);
+  const float c = SquaredLength(o.a - ray.o) - o.radius * o.radius;
+  float alpha, beta;
+  if (!SolveQuadratic(a, b, c, alpha, beta)) return Hit();
+  if (alpha > kEPS) return MakeHitN(ray.o + alpha * ray.d, ray.o + alpha * ray.d - o.a, alpha);
+  if (beta > kEPS) return MakeHitN(ray.o + beta * ray.d, ray.o + beta * ray.d - o.a, beta);
+  return Hit();
+}
+Hit IntersectDisk(const Object& o, const Ray& ray) {                   // primitive_disk.cc:94-114
+  const float cos_theta = Dot(ray.d, o.b);
+  if (cos_theta == 0) return Hit();
+  const float t = Dot(o.a - ray.o, o.b) / cos_theta;
+  if (t < kEPS) return Hit();
+  const float sq = SquaredLength(ray.o + t * ray.d - o.a);
+  if (sq > o.radius * o.radius) return Hit();
+  return MakeHitU(ray.o + t * ray.d, o.b, t);
+}
+Hit IntersectCylinder(const Object& o, const Ray& ray) {               // primitive_cylinder.cc:100-142
+  const V3 OC = o.a - ray.o;
+  const V3 u = ray.d - Dot(ray.d, o.b) * o.b;
+  const V3 v = OC - Dot(OC, o.b) * o.b;
+  const float a = SquaredLength(u);
+  const float b = -2 * Dot(u, v);
+  const float c = SquaredLength(v) - o.radius * o.radius;
+  float alpha, beta;
+  if (!SolveQuadratic(a, b, c, alpha, beta)) return Hit();
+  if (alpha > kEPS) {
+    const float h = Dot(alpha * ray.d - OC, o.b);
+    if (h >= 0 && h <= o.height)
+      return MakeHitN(ray.o + alpha * ray.d, ray.o + alpha * ray.d - o.a - h * o.b, alpha);
+  }
+  if (beta > kEPS) {
+    const float h = Dot(beta * ray.d - OC, o.b);
+    if (h >= 0 && h <= o.height)
+      return MakeHitN(ray.o + beta * ray.d, ray.o + beta * ray.d - o.a - h * o.b, beta);
+  }
+  return Hit();
+}
+Hit Intersect(const Object& o, const Ray& ray) {                       // scene/object.h:136-141
+  switch (o.kind) {
+    case ORACLE_PRIM_TRIANGLE: return IntersectTriangle(o, ray);
+    case ORACLE_PRIM_SPHERE: return IntersectSphere(o, ray);
+    case ORACLE_PRIM_DISK: return IntersectDisk(o, ray);
+    default: return IntersectCylinder(o, ray);
+  }
+}
+AABB DiskBox(V3 center, V3 normal, float radius) {                     // primitive_disk.cc:81-92
+  const V3 f = v3(std::sqrt(1 - normal.x * normal.x), std::sqrt(1 - normal.y * normal.y),
+                  std::sqrt(1 - normal.z * normal.z));
+  return AABB{center - radius * f, center + radius * f};
+}
+AABB BoundingBox(const Object& o) {
+  switch (o.kind) {
+    case ORACLE_PRIM_TRIANGLE:                                          // primitive_triangle.cc:80-95
+      return AABB{v3(std::min({o.a.x, o.b.x, o.c.x}), std::min({o.a.y, o.b.y, o.c.y}), std::min({o.a.z, o.b.z, o.c.z})),
+                  v3(std::max({o.a.x, o.b.x, o.c.x}), std::max({o.a.y, o.b.y, o.c.y}), std::max({o.a.z, o.b.z, o.c.z}))};
+    case ORACLE_PRIM_SPHERE:                                            // primitive_sphere.cc:69-73
+      return AABB{o.a - splat(o.radius), o.a + splat(o.radius)};
+    case ORACLE_PRIM_DISK: return DiskBox(o.a, o.b, o.radius);
+    default: return o.cyl_bb;                                           // primitive_cylinder.cc:73-84
+  }
+}
+V3 Center(const Object& o) {
+  switch (o.kind) {
+    case ORACLE_PRIM_TRIANGLE:                                          // primitive_triangle.cc:70-78
+      return v3((o.a.x + o.b.x + o.c.x) / 3, (o.a.y + o.b.y + o.c.y) / 3, (o.a.z + o.b.z + o.c.z) / 3);
+    case ORACLE_PRIM_CYLINDER: return o.a + o.height / 2 * o.b;         // primitive_cylinder.cc:86-90
+    default: return o.a;
+  }
+}
+float TriangleArea(const Object& o) { return Length(Cross(o.b - o.a, o.c - o.a)) / 2; }   // primitive_triangle.cc:130-134
+Object MakeTriangle(V3 v0, V3 v1, V3 v2, uint32_t material) {
+  Object o; o.kind = ORACLE_PRIM_TRIANGLE; o.material = material; o.a = v0; o.b = v1; o.c = v2;
+  o.normal = Normalize(Cross(v1 - v0, v2 - v0));
+  return o;
+}
+void FinishObject(Object& o) {
+  if (o.kind == ORACLE_PRIM_TRIANGLE) o.normal = Normalize(Cross(o.b - o.a, o.c - o.a));
+  if (o.kind == ORACLE_PRIM_CYLINDER) {
+    o.cyl_bb = Union(Union(EmptyBox(), DiskBox(o.a, o.b, o.radius)), DiskBox(o.a + o.height * o.b, o.b, o.radius));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// BVH (include/amber/raytracer/acceleration_bvh.h:134-403) and List (acceleration_list.h:51-68)
+// ------------------------------------------------------------------------------------------
+struct BVH {
+  using It = std::vector<Object>::iterator;
+  struct Node {
+    std::unique_ptr<Node> left, right;
+    It first, last;
+    AABB bb;
+  };
+  struct Split { float cost = FLT_MAX; It middle; AABB bl = EmptyBox(), br = EmptyBox(); };
+
+  std::vector<Object> objects;
+  std::unique_ptr<Node> root;
+  uint32_t n_nodes = 0, n_leaves = 0, max_depth = 0;
+
+  static AABB Box(It first, It last) {                                  // :182-194
+    AABB bb = EmptyBox();
+    for (It i = first; i != last; ++i) bb = Union(bb, BoundingBox(*i));
+    return bb;
+  }
+  static float SAH(const AABB& p, const AABB& l, const AABB& r, std::size_t nl, std::size_t nr) {  // :298-312
+    return 2 * 2.0f + (nl * SurfaceArea(l) + nr * SurfaceArea(r)) / SurfaceArea(p) * 1.0f;
+  }
+  static Split FindSplitAxis(It first, It last, const AABB& bb, std::function<float(V3)> axis) {   // :243-296
+    std::sort(first, last, [&](const Object& a, const Object& b) { return axis(Center(a)) < axis(Center(b)); });
+    const std::size_t n_splits =
+        std::min<std::size_t>(15.0f, std::log2(std::distance(first, last)));
+    Split split;
+    for (std::size_t i = 0; i < n_splits; i++) {
+      const float split_point = axis(bb.mn) + (axis(bb.mx) - axis(bb.mn)) * (i + 1) / (n_splits + 1);
+      const It middle = std::lower_bound(first, last, split_point,
+          [&](const Object& object, const float sp) { return axis(Center(object)) < sp; });
+      const AABB bl = Box(first, middle), br = Box(middle, last);
+      const std::size_t nl = std::distance(first, middle), nr = std::distance(middle, last);
+      const float cost = SAH(bb, bl, br, nl, nr);
+      if (cost < split.cost) { split.cost = cost; split.middle = middle; split.bl = bl; split.br = br; }
+    }
+    return split;
+  }
+  static Split FindSplit(It first, It last, const AABB& bb) {           // :197-241
+    const Split sx = FindSplitAxis(first, last, bb, [](V3 v) { return v.x; });
+    const Split sy = FindSplitAxis(first, last, bb, [](V3 v) { return v.y; });
+    const Split sz = FindSplitAxis(first, last, bb, [](V3 v) { return v.z; });
+    if (sx.cost < sy.cost && sx.cost < sz.cost) {
+      std::sort(first, last, [](const Object& a, const Object& b) { return Center(a).x < Center(b).x; });
+      return sx;
+    } else if (sy.cost < sx.cost) {
+      std::sort(first, last, [](const Object& a, const Object& b) { return Center(a).y < Center(b).y; });
+      return sy;
+    } else {
+      std::sort(first, last, [](const Object& a, const Object& b) { return Center(a).z < Center(b).z; });
+      return sz;
+    }
+  }
+  std::unique_ptr<Node> Create(It first, It last, const AABB& bb, uint32_t depth) {   // :158-180
+    n_nodes++; max_depth = std::max(max_depth, depth);
+    const Split split = FindSplit(first, last, bb);
+    auto node = std::make_unique<Node>();
+    node->bb = bb;
+    if (split.cost > std::distance(first, last) * 1.0f) {
+      n_leaves++;
+      node->first = first; node->last = last;
+    } else {
+      node->first = node->last = It();
+      node->left = Create(first, split.middle, split.bl, depth + 1);
+      node->right = Create(split.middle, last, split.br, depth + 1);
+    }
+    return node;
+  }
+  explicit BVH(std::vector<Object>&& objs) : objects(std::move(objs)) {  // :134-138
+    root = Create(objects.begin(), objects.end(), Box(objects.begin(), objects.end()), 0);
+  }
+  static void CastNode(const Node* n, const Ray& ray, float distance, Hit& out_hit, const Object*& out_obj) {  // :340-403
+    if (n->first != n->last) {
+      Hit closest; const Object* closest_obj = nullptr;
+      for (It i = n->first; i != n->last; ++i) {
+        const Hit hit = Intersect(*i, ray);
+        if (hit && hit.t < distance) { distance = hit.t; closest = hit; closest_obj = &*i; }
+      }
+      out_hit = closest; out_obj = closest_obj; return;
+    }
+    bool lh = false, rh = false; float lin = FLT_MAX, rin = FLT_MAX, dummy;
+    if (n->left) lh = SlabTest(n->left->bb, ray, distance, lin, dummy);
+    if (n->right) rh = SlabTest(n->right->bb, ray, distance, rin, dummy);
+    if (!lh && !rh) { out_hit = Hit(); out_obj = nullptr; return; }
+    if (lh && !rh) { CastNode(n->left.get(), ray, distance, out_hit, out_obj); return; }
+    if (!lh && rh) { CastNode(n->right.get(), ray, distance, out_hit, out_obj); return; }
+    const Node* near_ = lin < rin ? n->left.get() : n->right.get();
+    const Node* far_ = lin < rin ? n->right.get() : n->left.get();
+    Hit nh; const Object* no = nullptr;
+    CastNode(near_, ray, distance, nh, no);
+    if (!nh) { CastNode(far_, ray, distance, out_hit, out_obj); return; }
+    if (nh.t < std::max(lin, rin)) { out_hit = nh; out_obj = no; return; }
+    Hit fh; const Object* fo = nullptr;
+    CastNode(far_, ray, nh.t, fh, fo);
+    if (!fh) { out_hit = nh; out_obj = no; } else { out_hit = fh; out_obj = fo; }
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Materials (src/amber/scene/material_*.cc, include/amber/scene/material_*.h)
+// ------------------------------------------------------------------------------------------
+struct Material {
+  uint32_t kind = 0;
+  V3 rho{0, 0, 0};
+  float param = 0;   // exponent / ior
+  float r0 = 0;      // refraction: Fresnel(ior), material_refraction.cc:265-269
+};
+float Fresnel(float ior, const Math& M) { return static_cast<float>(M.pow_i((ior - 1) / (ior + 1), 2)); }
+float Schlick(float r0, float cos_theta, const Math& M) {              // material_refraction.cc:271-275 (double pow)
+  return static_cast<float>(r0 + (1 - r0) * M.pow_i(1 - cos_theta, 5));
+}
+struct Scatter { V3 dir{0, 0, 0}; V3 weight{0, 0, 0}; };               // rendering/scatter.h:32-48
+
+V3 Radiance(const Material& m, V3 normal, V3 dir_out) {                // material_diffuse_light.h:127-139, material.h:101-109
+  if (m.kind != ORACLE_MAT_DIFFUSE_LIGHT) return splat(0);
+  if (Dot(dir_out, normal) <= 0) return splat(0);
+  return m.rho;
+}
+Scatter SampleLight(const Material& m, V3 normal, V3 dir_out, Sampler& smp, const Math& M) {
+  Scatter sc;
+  switch (m.kind) {
+    case ORACLE_MAT_LAMBERTIAN: {                                       // material_lambertian.cc:61-70
+      const V3 w = Dot(dir_out, normal) > 0 ? normal : -normal;
+      sc.dir = HemispherePSA(w, smp, M);
+      sc.weight = 1.0f * m.rho;                                         // material_basic.h:327-338
+      return sc;
+    }
+    case ORACLE_MAT_PHONG: {                                            // material_phong.cc:81-106
+      const V3 refl = PerfectReflection(dir_out, normal, Dot(dir_out, normal));
+      const float signed_cos_o = Dot(dir_out, normal);
+      for (;;) {
+        const V3 dir_in = CosinePower(refl, m.param, smp, M);
+        const float signed_cos_i = Dot(dir_in, normal);
+        if (signed_cos_o * signed_cos_i <= 0) continue;
+        sc.dir = dir_in;
+        sc.weight = ((m.param + 2) / (m.param + 1) * std::abs(signed_cos_i)) * m.rho;
+        return sc;
+      }
+    }
+    case ORACLE_MAT_SPECULAR: {                                         // material_specular.cc:62-70
+      sc.dir = PerfectReflection(dir_out, normal, Dot(dir_out, normal));
+      sc.weight = 1.0f * m.rho;
+      return sc;
+    }
+    case ORACLE_MAT_REFRACTION: {                                       // material_refraction.cc:177-220
+      const float signed_cos_alpha = Dot(dir_out, normal);
+      const float ior = signed_cos_alpha > 0 ? 1 / m.param : m.param;
+      const float squared_cos_beta = 1 - (1 - signed_cos_alpha * signed_cos_alpha) * (ior * ior);
+      const V3 dir_r = PerfectReflection(dir_out, normal, signed_cos_alpha);
+      if (squared_cos_beta < 0) { sc.dir = dir_r; sc.weight = 1.0f * m.rho; return sc; }
+      const float cos_alpha = std::abs(signed_cos_alpha);
+      const float cos_beta = std::sqrt(squared_cos_beta);
+      const V3 dir_t = -ior * dir_out + ((signed_cos_alpha < 0 ? 1 : -1) * cos_beta + ior * signed_cos_alpha) * normal;
+      const float rho_r = Schlick(m.r0, cos_alpha, M);
+      const float rho_t = (1 - rho_r) * (ior * ior);
+      const float rho = rho_r + rho_t;
+      const float p_r = (rho_r / rho + 0.5f) / 2;
+      const float p_t = (rho_t / rho + 0.5f) / 2;
+      if (UniformF(smp) < p_r) { sc.dir = dir_r; sc.weight = (rho_r / p_r) * m.rho; }
+      else { sc.dir = dir_t; sc.weight = (rho_t / p_t) * m.rho; }
+      return sc;
+    }
+    case ORACLE_MAT_EYE:                                                // material_eye.h:146-155
+      sc.dir = -dir_out; sc.weight = splat(1); return sc;
+    default:                                                            // DiffuseLight, material_diffuse_light.h:185-194
+      return sc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Thin lens + sensor (src/amber/scene/lens_thin.cc:32-148, src/amber/rendering/sensor.cc:94-120)
+// ------------------------------------------------------------------------------------------
+struct M3 {
+  float e[9];
+  V3 operator()(V3 v) const {                                           // matrix3.h:101-109
+    return v3(e[0] * v.x + e[1] * v.y + e[2] * v.z, e[3] * v.x + e[4] * v.y + e[5] * v.z,
+              e[6] * v.x + e[7] * v.y + e[8] * v.z);
+  }
+  M3 Inverse() const {                                                  // matrix3.h:111-143
+    const float e11 = e[0], e12 = e[1], e13 = e[2], e21 = e[3], e22 = e[4], e23 = e[5], e31 = e[6], e32 = e[7], e33 = e[8];
+    const float d = +e11 * (e22 * e33 - e23 * e32) - e21 * (e12 * e33 - e13 * e32) + e31 * (e12 * e23 - e13 * e22);
+    M3 r;
+    if (d == 0) { for (float& x : r.e) x = std::numeric_limits<float>::quiet_NaN(); return r; }
+    const float dinv = 1 / d;
+    r.e[0] = +dinv * (e22 * e33 - e23 * e32); r.e[1] = -dinv * (e12 * e33 - e13 * e32); r.e[2] = +dinv * (e12 * e23 - e13 * e22);
+    r.e[3] = -dinv * (e21 * e33 - e23 * e31); r.e[4] = +dinv * (e11 * e33 - e13 * e31); r.e[5] = -dinv * (e11 * e23 - e13 * e21);
+    r.e[6] = +dinv * (e21 * e32 - e22 * e31); r.e[7] = -dinv * (e11 * e32 - e12 * e31); r.e[8] = +dinv * (e11 * e22 - e12 * e21);
+    return r;
+  }
+};
+struct ThinLens {
+  V3 origin; M3 global_, local_;
+  std::vector<Object> blades;       // lens-owned aperture triangles (lens_thin.cc:46-55)
+  float focus_distance, sensor_distance, p_area;
+};
+ThinLens MakeThinLens(const float t[16], float focal_length, float focus_distance, float radius,
+                      uint32_t n_blades, uint32_t eye_material, const Math& M) {   // lens_thin.cc:32-57
+  ThinLens L;
+  // origin_ = transform(Vector3()) : matrix4.h:98-107
+  L.origin = v3(t[0] * 0.0f + t[1] * 0.0f + t[2] * 0.0f + t[3], t[4] * 0.0f + t[5] * 0.0f + t[6] * 0.0f + t[7],
+                t[8] * 0.0f + t[9] * 0.0f + t[10] * 0.0f + t[11]);
+  const float g[9] = {t[0], t[1], t[2], t[4], t[5], t[6], t[8], t[9], t[10]};
+  std::memcpy(L.global_.e, g, sizeof g);
+  L.local_ = L.global_.Inverse();
+  L.focus_distance = focus_distance;
+  L.sensor_distance = 1 / (1 / focal_length - 1 / focus_distance);
+  L.p_area = 1;
+  const std::size_t n = n_blades;
+  for (std::size_t i = 0; i < n; i++) {
+    const float alpha = 2 * kPIf / n * i;
+    const float beta = 2 * kPIf / n * (i + 1);
+    float sa, ca, sb, cb;
+    if (M.mode == ORACLE_MATH_LIBM) { ca = std::cos(alpha); sa = std::sin(alpha); cb = std::cos(beta); sb = std::sin(beta); }
+    else { PortableSinCos(alpha, &sa, &ca); PortableSinCos(beta, &sb, &cb); }
+    L.blades.push_back(MakeTriangle(L.origin + L.global_(radius * v3(ca, sa, 0)),
+                                    L.origin + L.global_(radius * v3(cb, sb, 0)), L.origin, eye_material));
+  }
+  L.p_area /= TriangleArea(L.blades.front()) * n;
+  return L;
+}
+
+struct Sensor { uint64_t w, h; float sw, sh; };
+
+struct EyeRay { V3 origin, normal, dir; float weight; uint32_t blade; };
+// BasicThin::GenerateRay lens_thin.cc:70-107 ; Sensor::PixelBound::Uniform sensor.cc:111-120.
+// The two jitter draws are constructor arguments of Vector2 (sensor.cc:114-117): their order is
+// unspecified by C++; the reference's recorded outputs come from g++ 11.4 which evaluates the
+// SECOND argument (Y) first.  The oracle fixes that order: draw#4 -> Y, draw#5 -> X.
+EyeRay GenerateEyeRay(const ThinLens& L, const Sensor& S, uint64_t px, uint64_t py, Sampler& smp, const Math& M) {
+  const std::size_t nb = L.blades.size();
+  const std::size_t pos = std::min<std::size_t>(nb - 1, std::floor(UniformF(static_cast<float>(nb), smp)));
+  const Object& tri = L.blades[pos];
+  // Triangle::SampleSurfacePoint primitive_triangle.cc:136-150
+  float u = UniformF(smp);
+  float v = UniformF(smp);
+  if (u + v >= 1) { u = 1 - u; v = 1 - v; }
+  const V3 ap_origin = (1 - u - v) * tri.a + u * tri.b + v * tri.c;
+  const V3 aperture_point = L.local_(ap_origin - L.origin);
+  const float jy = UniformF(smp);
+  const float jx = UniformF(smp);
+  const float uvx = (px + jx) / S.w;
+  const float uvy = (py + jy) / S.h;
+  const float sx = (uvx - 0.5f) * S.sw;                                 // UVToPoint sensor.cc:94-101
+  const float sy = (uvy - 0.5f) * S.sh;
+  const V3 sensor_point = v3(sx, sy, L.sensor_distance);
+  const V3 direction = Normalize(-L.focus_distance / L.sensor_distance * sensor_point - aperture_point);
+  const double factor = M.pow_i(Normalize(sensor_point - aperture_point).z / direction.z, 4);
+  const V3 ray_dir = Normalize(L.global_(direction));                   // Ray(origin, Vector3) normalises, ray.h:52-56
+  // PDFDirection lens_thin.cc:138-148 : float * double / double -> double -> real_type
+  const V3 dloc = L.local_(ray_dir);
+  const float pdf_dir = static_cast<float>(
+      static_cast<float>(S.w * S.h) / (S.sw * S.sh) * M.pow_i(L.sensor_distance, 2) / M.pow_i(dloc.z, 4));
+  EyeRay e;
+  e.origin = ap_origin; e.normal = tri.normal; e.dir = ray_dir; e.blade = static_cast<uint32_t>(pos);
+  e.weight = static_cast<float>(factor / L.p_area / pdf_dir);          // double / float / float -> real_type
+  return e;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// Scene
+// ------------------------------------------------------------------------------------------
+struct oracle_scene {
+  int accel = ORACLE_ACCEL_BVH;
+  std::vector<Object> objects;        // insertion order
+  std::vector<Material> materials;
+  ThinLens lens;
+  std::unique_ptr<BVH> bvh;
+
+  void Finish() {
+    for (uint32_t i = 0; i < objects.size(); i++) objects[i].index = i;
+    if (accel == ORACLE_ACCEL_BVH) bvh = std::make_unique<BVH>(std::vector<Object>(objects));
+  }
+  // Scene::Cast scene/scene.h:236-244 -> Acceleration::Cast(ray, FLT_MAX) acceleration.h:46-51
+  bool Cast(const Ray& ray, Hit& hit, const Object*& obj) const {
+    if (accel == ORACLE_ACCEL_BVH) {
+      BVH::CastNode(bvh->root.get(), ray, FLT_MAX, hit, obj);
+    } else {                                                            // acceleration_list.h:51-68
+      float distance = FLT_MAX; hit = Hit(); obj = nullptr;
+      for (const Object& o : objects) {
+        const Hit h = Intersect(o, ray);
+        if (h && h.t < distance) { distance = h.t; hit = h; obj = &o; }
+      }
+    }
+    return static_cast<bool>(hit);
+  }
+};
+
+namespace {
+
+struct PathResult { V3 measurement; uint32_t casts, hits; };
+
+// PathTracing::Thread::Render algorithm_pt.cc:125-160.  max_depth == 0 means RR-only (reference).
+PathResult TracePath(const oracle_scene& sc, const Sensor& S, uint64_t px, uint64_t py, Sampler& smp,
+                     const Math& M, uint32_t max_depth, oracle_bounce* trace, uint32_t max_trace,
+                     float* eye_out) {
+  const EyeRay eye = GenerateEyeRay(sc.lens, S, px, py, smp, M);
+  if (eye_out) {
+    eye_out[0] = eye.origin.x; eye_out[1] = eye.origin.y; eye_out[2] = eye.origin.z;
+    eye_out[3] = eye.dir.x; eye_out[4] = eye.dir.y; eye_out[5] = eye.dir.z; eye_out[6] = eye.weight;
+  }
+  V3 measurement = splat(0);
+  Ray ray{eye.origin, eye.dir};
+  V3 weight = splat(eye.weight);                                        // Leading<Radiant>(.., Radiant(weight))
+  PathResult r{splat(0), 0, 0};
+  for (;;) {
+    Hit hit; const Object* obj = nullptr;
+    sc.Cast(ray, hit, obj);
+    r.casts++;
+    if (!hit) {
+      if (trace && r.casts <= max_trace) { oracle_bounce& b = trace[r.casts - 1]; std::memset(&b, 0, sizeof b); b.object = -1; b.t = hit.t; }
+      break;
+    }
+    r.hits++;
+    const Material& m = sc.materials[obj->material];
+    const V3 weight_before = weight;
+    measurement = measurement + weight * Radiance(m, hit.n, -ray.d);
+    const Scatter scat = SampleLight(m, hit.n, -ray.d, smp, M);
+    const float p_rr = std::min<float>(static_cast<float>(kRussianRoulette), Max3(scat.weight));
+    if (trace && r.casts <= max_trace) {
+      oracle_bounce& b = trace[r.casts - 1];
+      b.object = static_cast<int32_t>(obj->index); b.t = hit.t;
+      b.pos[0] = hit.pos.x; b.pos[1] = hit.pos.y; b.pos[2] = hit.pos.z;
+      b.weight[0] = weight_before.x; b.weight[1] = weight_before.y; b.weight[2] = weight_before.z;
+      b.measurement[0] = measurement.x; b.measurement[1] = measurement.y; b.measurement[2] = measurement.z;
+    }
+    if (UniformF(smp) >= p_rr) break;
+    if (max_depth && r.casts >= max_depth) break;                       // build-side extension (config 5)
+    ray = Ray{hit.pos, scat.dir};
+    weight = weight * (scat.weight / splat(p_rr));
+  }
+  r.measurement = measurement;
+  return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+oracle_scene* oracle_scene_create(const oracle_object* objects, uint32_t n_objects,
+                                  const oracle_material* materials, uint32_t n_materials,
+                                  const oracle_thin_lens* lens, int accel) {
+  auto* sc = new oracle_scene();
+  sc->accel = accel;
+  const Math M{ORACLE_MATH_LIBM};
+  for (uint32_t i = 0; i < n_materials; i++) {
+    Material m; m.kind = materials[i].kind; m.rho = v3(materials[i].rho[0], materials[i].rho[1], materials[i].rho[2]);
+    m.param = materials[i].param;
+    if (m.kind == ORACLE_MAT_REFRACTION) m.r0 = Fresnel(m.param, M);
+    sc->materials.push_back(m);
+  }
+  Material eye; eye.kind = ORACLE_MAT_EYE; eye.rho = splat(1);
+  sc->materials.push_back(eye);
+  const uint32_t eye_id = static_cast<uint32_t>(sc->materials.size() - 1);
+  sc->lens = MakeThinLens(lens->transform, lens->focal_length, lens->focus_distance, lens->radius, lens->n_blades, eye_id, M);
+  for (const Object& b : sc->lens.blades) sc->objects.push_back(b);     // cornel_box.cc:62-64
+  for (uint32_t i = 0; i < n_objects; i++) {
+    Object o; o.kind = objects[i].kind; o.material = objects[i].material;
+    const float* p = objects[i].p;
+    o.a = v3(p[0], p[1], p[2]);
+    if (o.kind == ORACLE_PRIM_TRIANGLE) { o.b = v3(p[3], p[4], p[5]); o.c = v3(p[6], p[7], p[8]); }
+    else if (o.kind == ORACLE_PRIM_SPHERE) { o.radius = p[3]; }
+    else { o.b = v3(p[3], p[4], p[5]); o.radius = p[6]; o.height = p[7]; }
+    FinishObject(o);
+    sc->objects.push_back(o);
+  }
+  sc->Finish();
+  return sc;
+}
+
+// etude::CornelBox src/amber/etude/cornel_box.cc:38-204 (literals are double in the reference and
+// narrow to real_type at the Vector3 / RGB constructors).
+oracle_scene* oracle_scene_cornell_box(float focal_length, float aperture_radius, uint32_t n_blades, int accel) {
+  std::vector<oracle_object> objs;
+  std::vector<oracle_material> mats;
+  auto mat = [&](uint32_t kind, double r, double g, double b, double param) {
+    oracle_material m; m.kind = kind; m.rho[0] = static_cast<float>(r); m.rho[1] = static_cast<float>(g);
+    m.rho[2] = static_cast<float>(b); m.param = static_cast<float>(param); mats.push_back(m);
+    return static_cast<uint32_t>(mats.size() - 1);
+  };
+  auto tri = [&](uint32_t m, double x0, double y0, double z0, double x1, double y1, double z1, double x2, double y2, double z2) {
+    oracle_object o; o.kind = ORACLE_PRIM_TRIANGLE; o.material = m;
+    const double v[9] = {x0, y0, z0, x1, y1, z1, x2, y2, z2};
+    for (int i = 0; i < 9; i++) o.p[i] = static_cast<float>(v[i]);
+    objs.push_back(o);
+  };
+  auto sph = [&](uint32_t m, double x, double y, double z, double r) {
+    oracle_object o; o.kind = ORACLE_PRIM_SPHERE; o.material = m; std::memset(o.p, 0, sizeof o.p);
+    o.p[0] = static_cast<float>(x); o.p[1] = static_cast<float>(y); o.p[2] = static_cast<float>(z); o.p[3] = static_cast<float>(r);
+    objs.push_back(o);
+  };
+  uint32_t m;
+  m = mat(ORACLE_MAT_DIFFUSE_LIGHT, 1e11, 1e11, 1e11, 0);              // :66-79 light source
+  tri(m, 0.01, 0.99, 0.01, -0.01, 0.99, 0.01, -0.01, 0.99, -0.01);
+  tri(m, -0.01, 0.99, -0.01, 0.01, 0.99, -0.01, 0.01, 0.99, 0.01);
+  m = mat(ORACLE_MAT_LAMBERTIAN, .5, 0, 0, 0);                          // :81-94 left wall
+  tri(m, -1, 1, 1, -1, -1, 1, -1, -1, -1);
+  tri(m, -1, -1, -1, -1, 1, -1, -1, 1, 1);
+  m = mat(ORACLE_MAT_LAMBERTIAN, 0, .5, 0, 0);                          // :96-109 right wall
+  tri(m, 1, 1, 1, 1, 1, -1, 1, -1, -1);
+  tri(m, 1, -1, -1, 1, -1, 1, 1, 1, 1);
+  m = mat(ORACLE_MAT_PHONG, .95, .95, .95, 256);                        // :111-124 back wall
+  tri(m, 1, 1, -1, -1, 1, -1, -1, -1, -1);
+  tri(m, -1, -1, -1, 1, -1, -1, 1, 1, -1);
+  m = mat(ORACLE_MAT_LAMBERTIAN, .5, .5, .5, 0);                        // :126-139 floor
+  tri(m, 1, -1, 1, 1, -1, -1, -1, -1, -1);
+  tri(m, -1, -1, -1, -1, -1, 1, 1, -1, 1);
+  m = mat(ORACLE_MAT_LAMBERTIAN, .5, .5, .5, 0);                        // :141-154 ceiling
+  tri(m, 1, 1, 1, -1, 1, 1, -1, 1, -1);
+  tri(m, -1, 1, -1, 1, 1, -1, 1, 1, 1);
+  m = mat(ORACLE_MAT_REFRACTION, 1, 1, 1, 1.333);                       // :156-181 water
+  tri(m, 1, -0.5, 1, 1, -0.5, -1, -1, -0.5, -1);
+  tri(m, -1, -0.5, -1, -1, -0.5, 1, 1, -0.5, 1);
+  tri(m, 1, -0.5, 1, -1, -0.5, 1, -1, -1, 1);
+  tri(m, -1, -1, 1, 1, -1, 1, 1, -0.5, 1);
+  m = mat(ORACLE_MAT_LAMBERTIAN, .5, .5, .5, 0);                        // :183-186 diffuse sphere
+  sph(m, 0.4, -0.6, -0.5, 0.4);
+  m = mat(ORACLE_MAT_SPECULAR, .95, .95, .95, 0);                       // :188-191 specular sphere
+  sph(m, -0.4, -0.7, 0.1, 0.3);
+  m = mat(ORACLE_MAT_REFRACTION, 1, 1, 1, 1.125);                       // :193-196 refraction sphere
+  sph(m, 0.1, -0.8, 0.6, 0.2);
+  oracle_thin_lens lens;
+  const float T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 4, 0, 0, 0, 1};  // :50-61
+  std::memcpy(lens.transform, T, sizeof T);
+  lens.focal_length = focal_length; lens.focus_distance = 4; lens.radius = aperture_radius; lens.n_blades = n_blades;
+  return oracle_scene_create(objs.data(), static_cast<uint32_t>(objs.size()), mats.data(),
+                             static_cast<uint32_t>(mats.size()), &lens, accel);
+}
+
+void oracle_scene_destroy(oracle_scene* s) { delete s; }
+
+uint32_t oracle_scene_object_count(const oracle_scene* s) { return static_cast<uint32_t>(s->objects.size()); }
+uint32_t oracle_scene_material_count(const oracle_scene* s) { return static_cast<uint32_t>(s->materials.size()); }
+void oracle_scene_get_object(const oracle_scene* s, uint32_t i, oracle_object* out, float normal_out[3]) {
+  const Object& o = s->objects[i];
+  std::memset(out, 0, sizeof *out);
+  out->kind = o.kind; out->material = o.material;
+  out->p[0] = o.a.x; out->p[1] = o.a.y; out->p[2] = o.a.z;
+  if (o.kind == ORACLE_PRIM_TRIANGLE) { out->p[3] = o.b.x; out->p[4] = o.b.y; out->p[5] = o.b.z; out->p[6] = o.c.x; out->p[7] = o.c.y; out->p[8] = o.c.z; }
+  else if (o.kind == ORACLE_PRIM_SPHERE) { out->p[3] = o.radius; }
+  else { out->p[3] = o.b.x; out->p[4] = o.b.y; out->p[5] = o.b.z; out->p[6] = o.radius; out->p[7] = o.height; }
+  normal_out[0] = o.normal.x; normal_out[1] = o.normal.y; normal_out[2] = o.normal.z;
+}
+void oracle_scene_get_material(const oracle_scene* s, uint32_t i, oracle_material* out, float* r0_out) {
+  const Material& m = s->materials[i];
+  out->kind = m.kind; out->rho[0] = m.rho.x; out->rho[1] = m.rho.y; out->rho[2] = m.rho.z; out->param = m.param;
+  *r0_out = m.r0;
+}
+void oracle_scene_get_lens(const oracle_scene* s, float origin[3], float global_[9], float local_[9],
+                           float* focus_distance, float* sensor_distance, float* p_area) {
+  origin[0] = s->lens.origin.x; origin[1] = s->lens.origin.y; origin[2] = s->lens.origin.z;
+  std::memcpy(global_, s->lens.global_.e, 36); std::memcpy(local_, s->lens.local_.e, 36);
+  *focus_distance = s->lens.focus_distance; *sensor_distance = s->lens.sensor_distance; *p_area = s->lens.p_area;
+}
+void oracle_scene_bvh_stats(const oracle_scene* s, uint32_t* n_nodes, uint32_t* n_leaves, uint32_t* max_depth) {
+  *n_nodes = s->bvh ? s->bvh->n_nodes : 0; *n_leaves = s->bvh ? s->bvh->n_leaves : 0; *max_depth = s->bvh ? s->bvh->max_depth : 0;
+}
+
+// PathTracing::Render (algorithm_pt.cc:82-95) through ParallelMean (rendering/parallel.h:57-68) with
+// ThreadCount()==1: passes are summed by the binary-counter Accumulator (accumulator.h:136-166) and
+// divided by the pass count (Mean, :88-95).  Pixel loop: y outer, x inner (algorithm_pt.cc:112-123).
+void oracle_render_mt(const oracle_scene* sc, const oracle_sensor* sensor, uint64_t seed, uint32_t spp,
+                      int math, float* out_rgb, oracle_counters* counters) {
+  const Sensor S{sensor->width, sensor->height, sensor->scene_width, sensor->scene_height};
+  const Math M{math};
+  MTSampler smp(seed);
+  const std::size_t n = static_cast<std::size_t>(S.w) * S.h * 3;
+  std::vector<std::vector<float>> buffer;   // Accumulator::buffer_
+  std::size_t size = 0;
+  oracle_counters cnt{0, 0, 0};
+  for (uint32_t pass = 0; pass < spp; pass++) {
+    std::vector<float> image(n, 0.0f);
+    for (uint64_t y = 0; y < S.h; y++)
+      for (uint64_t x = 0; x < S.w; x++) {
+        const PathResult r = TracePath(*sc, S, x, y, smp, M, 0, nullptr, 0, nullptr);
+        float* p = &image[(x + y * S.w) * 3];
+        p[0] = r.measurement.x; p[1] = r.measurement.y; p[2] = r.measurement.z;
+        cnt.casts += r.casts; cnt.hits += r.hits; cnt.paths++;
+      }
+    // Accumulator::Add(0, value)
+    size += 1;
+    for (std::size_t i = 0;; i++) {
+      const std::size_t mask = static_cast<std::size_t>(1) << i;
+      if (size & mask) {
+        if (i == buffer.size()) buffer.emplace_back(std::move(image)); else buffer[i] = std::move(image);
+        break;
+      }
+      for (std::size_t k = 0; k < n; k++) image[k] += buffer[i][k];     // value += buffer_[i]
+    }
+  }
+  std::vector<float> sum(n, 0.0f);                                       // Sum(): initial_ + set bits ascending
+  for (std::size_t i = 0; i < buffer.size(); i++)
+    if (size & (static_cast<std::size_t>(1) << i))
+      for (std::size_t k = 0; k < n; k++) sum[k] += buffer[i][k];
+  const float div = static_cast<float>(size);                            // Mean(): Sum() / size_
+  for (std::size_t k = 0; k < n; k++) out_rgb[k] = sum[k] / div;
+  if (counters) *counters = cnt;
+}
+
+void oracle_render_xorshift(const oracle_scene* sc, const oracle_sensor* sensor, uint64_t global_seed,
+                            uint32_t first_sample, uint32_t n_samples, uint32_t y0, uint32_t y1,
+                            int math, uint32_t max_depth, uint32_t n_threads,
+                            float* sum_rgb, oracle_counters* counters) {
+  const Sensor S{sensor->width, sensor->height, sensor->scene_width, sensor->scene_height};
+  const Math M{math};
+  if (n_threads == 0) n_threads = 1;
+  std::vector<oracle_counters> cnts(n_threads, oracle_counters{0, 0, 0});
+  auto work = [&](uint32_t tid) {
+    oracle_counters& cnt = cnts[tid];
+    for (uint64_t y = y0 + tid; y < y1; y += n_threads)
+      for (uint64_t x = 0; x < S.w; x++) {
+        const uint32_t pixel = static_cast<uint32_t>(x + y * S.w);
+        V3 sum = splat(0);
+        for (uint32_t s = first_sample; s < first_sample + n_samples; s++) {
+          XorShiftSampler smp(XorShiftSeed(global_seed, pixel, s));
+          const PathResult r = TracePath(*sc, S, x, y, smp, M, max_depth, nullptr, 0, nullptr);
+          sum = sum + r.measurement;
+          cnt.casts += r.casts; cnt.hits += r.hits; cnt.paths++;
+        }
+        float* p = &sum_rgb[static_cast<std::size_t>(pixel) * 3];
+        p[0] += sum.x; p[1] += sum.y; p[2] += sum.z;
+      }
+  };
+  std::vector<std::thread> threads;
+  for (uint32_t t = 1; t < n_threads; t++) threads.emplace_back(work, t);
+  work(0);
+  for (auto& t : threads) t.join();
+  if (counters) {
+    oracle_counters tot{0, 0, 0};
+    for (const auto& c : cnts) { tot.casts += c.casts; tot.hits += c.hits; tot.paths += c.paths; }
+    *counters = tot;
+  }
+}
+
+uint32_t oracle_trace_path(const oracle_scene* sc, const oracle_sensor* sensor, uint64_t global_seed,
+                           uint32_t px, uint32_t py, uint32_t sample, int math, uint32_t max_depth,
+                           oracle_bounce* out, uint32_t max_bounces, float eye_ray_out[7]) {
+  const Sensor S{sensor->width, sensor->height, sensor->scene_width, sensor->scene_height};
+  const Math M{math};
+  XorShiftSampler smp(XorShiftSeed(global_seed, static_cast<uint32_t>(px + py * S.w), sample));
+  return TracePath(*sc, S, px, py, smp, M, max_depth, out, max_bounces, eye_ray_out).casts;
+}
+
+int32_t oracle_cast(const oracle_scene* sc, const float origin[3], const float dir[3], float* t, float pos[3], float normal[3]) {
+  const Ray ray{v3(origin[0], origin[1], origin[2]), v3(dir[0], dir[1], dir[2])};
+  Hit hit; const Object* obj = nullptr;
+  sc->Cast(ray, hit, obj);
+  *t = hit.t; pos[0] = hit.pos.x; pos[1] = hit.pos.y; pos[2] = hit.pos.z; normal[0] = hit.n.x; normal[1] = hit.n.y; normal[2] = hit.n.z;
+  return hit ? static_cast<int32_t>(obj->index) : -1;
+}
+
+int oracle_intersect(const oracle_object* obj, const float origin[3], const float dir[3], float* t, float pos[3], float normal[3]) {
+  Object o; o.kind = obj->kind; o.material = obj->material; const float* p = obj->p;
+  o.a = v3(p[0], p[1], p[2]);
+  if (o.kind == ORACLE_PRIM_TRIANGLE) { o.b = v3(p[3], p[4], p[5]); o.c = v3(p[6], p[7], p[8]); }
+  else if (o.kind == ORACLE_PRIM_SPHERE) { o.radius = p[3]; }
+  else { o.b = v3(p[3], p[4], p[5]); o.radius = p[6]; o.height = p[7]; }
+  FinishObject(o);
+  const Hit hit = Intersect(o, Ray{v3(origin[0], origin[1], origin[2]), v3(dir[0], dir[1], dir[2])});
+  *t = hit.t; pos[0] = hit.pos.x; pos[1] = hit.pos.y; pos[2] = hit.pos.z; normal[0] = hit.n.x; normal[1] = hit.n.y; normal[2] = hit.n.z;
+  return hit ? 1 : 0;
+}
+
+int oracle_aabb_intersect(const float bmin[3], const float bmax[3], const float origin[3], const float dir[3],
+                          float t_max, float* t_in, float* t_out) {
+  const AABB bb{v3(bmin[0], bmin[1], bmin[2]), v3(bmax[0], bmax[1], bmax[2])};
+  return SlabTest(bb, Ray{v3(origin[0], origin[1], origin[2]), v3(dir[0], dir[1], dir[2])}, t_max, *t_in, *t_out) ? 1 : 0;
+}
+
+uint32_t oracle_sample_material(const oracle_material* m, const float normal[3], const float dir_out[3],
+                                const double* u, uint32_t n_u, int math, float dir_in[3], float weight[3]) {
+  const Math M{math};
+  Material mm; mm.kind = m->kind; mm.rho = v3(m->rho[0], m->rho[1], m->rho[2]); mm.param = m->param;
+  if (mm.kind == ORACLE_MAT_REFRACTION) mm.r0 = Fresnel(mm.param, Math{ORACLE_MATH_LIBM});
+  ArraySampler smp(u, n_u);
+  const Scatter s = SampleLight(mm, v3(normal[0], normal[1], normal[2]), v3(dir_out[0], dir_out[1], dir_out[2]), smp, M);
+  dir_in[0] = s.dir.x; dir_in[1] = s.dir.y; dir_in[2] = s.dir.z; weight[0] = s.weight.x; weight[1] = s.weight.y; weight[2] = s.weight.z;
+  return smp.i;
+}
+void oracle_radiance(const oracle_material* m, const float normal[3], const float dir_out[3], float out[3]) {
+  Material mm; mm.kind = m->kind; mm.rho = v3(m->rho[0], m->rho[1], m->rho[2]); mm.param = m->param;
+  const V3 r = Radiance(mm, v3(normal[0], normal[1], normal[2]), v3(dir_out[0], dir_out[1], dir_out[2]));
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void oracle_eye_ray(const oracle_scene* sc, const oracle_sensor* sensor, uint32_t px, uint32_t py, const double u[5],
+                    int math, float origin[3], float normal[3], float dir[3], float* weight, uint32_t* blade) {
+  const Sensor S{sensor->width, sensor->height, sensor->scene_width, sensor->scene_height};
+  ArraySampler smp(u, 5);
+  const EyeRay e = GenerateEyeRay(sc->lens, S, px, py, smp, Math{math});
+  origin[0] = e.origin.x; origin[1] = e.origin.y; origin[2] = e.origin.z;
+  normal[0] = e.normal.x; normal[1] = e.normal.y; normal[2] = e.normal.z;
+  dir[0] = e.dir.x; dir[1] = e.dir.y; dir[2] = e.dir.z; *weight = e.weight; *blade = e.blade;
+}
+
+void oracle_mt_uniforms(uint64_t seed, uint32_t n, uint64_t* raw, double* u, float* uf) {
+  std::mt19937_64 e(seed); MTSampler s(seed);
+  for (uint32_t i = 0; i < n; i++) { raw[i] = e(); u[i] = s(); uf[i] = static_cast<float>(u[i]); }
+}
+uint64_t oracle_xorshift_seed(uint64_t global_seed, uint32_t pixel, uint32_t sample) { return XorShiftSeed(global_seed, pixel, sample); }
+void oracle_xorshift_uniforms(uint64_t state, uint32_t n, double* u) { XorShiftSampler s(state); for (uint32_t i = 0; i < n; i++) u[i] = s(); }
+
+void oracle_sincos(float phi, int math, float* s, float* c) { Math{math}.sincos(phi, *s, *c); }
+float oracle_pow(float x, float y, int math) { return Math{math}.powf_(x, y); }
+
+uint64_t oracle_fnv1a64(const void* data, uint64_t n_bytes) {
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  uint64_t h = 14695981039346656037ull;
+  for (uint64_t i = 0; i < n_bytes; i++) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+}  // extern "C"

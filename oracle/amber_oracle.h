@@ -1,0 +1,154 @@
+/*
+ * amber_oracle.h -- C interface of the CPU ORACLE for the amber path-tracing hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as
+ * the checker / reported CPU baseline.  The product (amber_amd/) never links or calls it.
+ *
+ * The oracle is a CPU restatement (own code, C++17, g++) of the reference algorithm
+ *   src/amber/rendering/algorithm_pt.cc:112-160  and everything it calls
+ * (SURVEY.md section 8(a) rows a1..a20).  Every function in amber_oracle.cc cites the
+ * reference file:line it follows.
+ *
+ * PINNING STATUS (see DESIGN.md "Oracle"): the reference has no tests, golden vectors or
+ * fixtures for this path and cannot be built in this image (its hot path
+ * includes boost/operators.hpp and boost/optional.hpp; boost is not installed and writing
+ * stand-ins for missing headers is not allowed).  The only reference outputs available are the
+ * whole-image known answers recorded in SURVEY.md section 8(c) / BASELINE.md section 2 (unmodified
+ * reference, g++ 11.4, seed 12345, one thread).  The oracle's "MT-stream / BVH / libm" mode is
+ * checked bit-for-bit against those (tests/test_oracle_pin.py).  mt19937_64 itself is pinned by
+ * the C++ standard's 10000th-output known answer.
+ */
+#ifndef AMBER_ORACLE_H
+#define AMBER_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- flat scene description (plain data; same layout as include/amber_hip.h) ---------- */
+
+enum { ORACLE_PRIM_TRIANGLE = 0, ORACLE_PRIM_SPHERE = 1, ORACLE_PRIM_DISK = 2, ORACLE_PRIM_CYLINDER = 3 };
+enum {
+  ORACLE_MAT_LAMBERTIAN = 0, ORACLE_MAT_PHONG = 1, ORACLE_MAT_SPECULAR = 2,
+  ORACLE_MAT_REFRACTION = 3, ORACLE_MAT_DIFFUSE_LIGHT = 4, ORACLE_MAT_EYE = 5
+};
+
+typedef struct {
+  uint32_t kind;       /* ORACLE_PRIM_* */
+  uint32_t material;   /* index into materials */
+  float    p[9];       /* triangle: v0,v1,v2 ; sphere: center, radius ; disk: center,normal,radius ; cylinder: center,normal,radius,height */
+} oracle_object;
+
+typedef struct {
+  uint32_t kind;       /* ORACLE_MAT_* */
+  float    rho[3];     /* kd / ks / radiance ; (1,1,1) for refraction and eye */
+  float    param;      /* phong exponent / refraction ior */
+} oracle_material;
+
+typedef struct {
+  float    transform[16];   /* row-major Matrix4 */
+  float    focal_length, focus_distance, radius;
+  uint32_t n_blades;
+} oracle_thin_lens;
+
+typedef struct {
+  uint32_t width, height;
+  float    scene_width, scene_height;
+} oracle_sensor;
+
+/* modes */
+enum { ORACLE_ACCEL_BVH = 0, ORACLE_ACCEL_LIST = 1 };
+enum { ORACLE_MATH_LIBM = 0, ORACLE_MATH_PORTABLE = 1 };
+
+typedef struct oracle_scene oracle_scene;
+
+/* The reference's etude::CornelBox (src/amber/etude/cornel_box.cc:38-204). */
+oracle_scene* oracle_scene_cornell_box(float focal_length, float aperture_radius, uint32_t n_blades, int accel);
+/* Arbitrary scene: the lens' aperture triangles are PREPENDED as objects 0..n_blades-1 with an
+ * Eye material appended to the material table (mirrors cornel_box.cc:62-64). */
+oracle_scene* oracle_scene_create(const oracle_object* objects, uint32_t n_objects,
+                                  const oracle_material* materials, uint32_t n_materials,
+                                  const oracle_thin_lens* lens, int accel);
+void          oracle_scene_destroy(oracle_scene*);
+
+/* introspection (for cross-checking the product's own flattening) */
+uint32_t oracle_scene_object_count(const oracle_scene*);
+uint32_t oracle_scene_material_count(const oracle_scene*);
+void     oracle_scene_get_object(const oracle_scene*, uint32_t i, oracle_object* out, float normal_out[3]);
+void     oracle_scene_get_material(const oracle_scene*, uint32_t i, oracle_material* out, float* r0_out);
+void     oracle_scene_get_lens(const oracle_scene*, float origin[3], float global_[9], float local_[9],
+                               float* focus_distance, float* sensor_distance, float* p_area);
+/* BVH stats: nodes, leaves, max depth (reference BVH, acceleration_bvh.h:134-312) */
+void     oracle_scene_bvh_stats(const oracle_scene*, uint32_t* n_nodes, uint32_t* n_leaves, uint32_t* max_depth);
+
+typedef struct {
+  uint64_t casts;    /* Scene::Cast calls (= "rays", algorithm_pt.cc:139) */
+  uint64_t hits;     /* casts that hit something */
+  uint64_t paths;
+} oracle_counters;
+
+/* O1: MT-stream mode -- restates PathTracing::Render with ONE thread and the reference's
+ * sampler (mt19937_64 seeded with `seed`, stream running across pixels and passes), the
+ * binary-counter Accumulator and Mean.  out_rgb: W*H*3 floats, index (x + y*W)*3 + c. */
+void oracle_render_mt(const oracle_scene*, const oracle_sensor*, uint64_t seed, uint32_t spp,
+                      int math, float* out_rgb, oracle_counters* counters);
+
+/* XorShift mode -- per-(pixel,sample) sampler: seed = hash(global_seed, pixel, sample).
+ * Adds, for every pixel, the sequential f32 sum over samples [first_sample, first_sample+n)
+ * of the path measurements to sum_rgb (W*H*3, caller zero-initialises before the first pass).
+ * Rows [y0, y1) only.  n_threads > 1 splits rows across threads (results are identical). */
+void oracle_render_xorshift(const oracle_scene*, const oracle_sensor*, uint64_t global_seed,
+                            uint32_t first_sample, uint32_t n_samples, uint32_t y0, uint32_t y1,
+                            int math, uint32_t max_depth, uint32_t n_threads,
+                            float* sum_rgb, oracle_counters* counters);
+
+/* per-path trace in XorShift mode (for path-level parity tests) */
+typedef struct {
+  int32_t  object;       /* object index in oracle object order, -1 = miss */
+  float    t;
+  float    pos[3];
+  float    weight[3];    /* path weight BEFORE this hit's scatter is applied */
+  float    measurement[3]; /* running measurement after this hit */
+} oracle_bounce;
+/* returns number of casts performed; writes at most max_bounces records */
+uint32_t oracle_trace_path(const oracle_scene*, const oracle_sensor*, uint64_t global_seed,
+                           uint32_t px, uint32_t py, uint32_t sample, int math, uint32_t max_depth,
+                           oracle_bounce* out, uint32_t max_bounces, float eye_ray_out[7]);
+
+/* ---- known-answer entry points for unit parity tests --------------------------------- */
+/* closest hit of one ray against the scene; returns object index or -1 */
+int32_t oracle_cast(const oracle_scene*, const float origin[3], const float dir[3],
+                    float* t, float pos[3], float normal[3]);
+/* single-primitive intersection (Primitive::Intersect); returns 1 on finite hit */
+int oracle_intersect(const oracle_object* obj, const float origin[3], const float dir[3],
+                     float* t, float pos[3], float normal[3]);
+/* AABB slab test, prelude::Intersect (aabb.cc:28-62) */
+int oracle_aabb_intersect(const float bmin[3], const float bmax[3], const float origin[3],
+                          const float dir[3], float t_max, float* t_in, float* t_out);
+/* material sampling: uniforms consumed in order from u[]; returns number consumed */
+uint32_t oracle_sample_material(const oracle_material* m, const float normal[3], const float dir_out[3],
+                                const double* u, uint32_t n_u, int math, float dir_in[3], float weight[3]);
+void oracle_radiance(const oracle_material* m, const float normal[3], const float dir_out[3], float out[3]);
+/* eye ray: 5 uniforms in draw order (blade, tri-u, tri-v, jitter-Y, jitter-X -- g++ order) */
+void oracle_eye_ray(const oracle_scene*, const oracle_sensor*, uint32_t px, uint32_t py, const double u[5],
+                    int math, float origin[3], float normal[3], float dir[3], float* weight, uint32_t* blade);
+
+/* samplers */
+void     oracle_mt_uniforms(uint64_t seed, uint32_t n, uint64_t* raw, double* u, float* uf);
+uint64_t oracle_xorshift_seed(uint64_t global_seed, uint32_t pixel, uint32_t sample);
+void     oracle_xorshift_uniforms(uint64_t state, uint32_t n, double* u);
+
+/* portable math (bit-identical on CPU and gfx950) vs libm */
+void  oracle_sincos(float phi, int math, float* s, float* c);
+float oracle_pow(float x, float y, int math);
+
+/* image helpers */
+uint64_t oracle_fnv1a64(const void* data, uint64_t n_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
