@@ -1,0 +1,22 @@
+"""amber_amd -- MI355X-native path-tracing integrator for amber (etheriqa/amber's `pt` hot path).
+
+The product is the shared library ``amber_amd/lib/libamber_hip.so`` (gfx950 kernels, the C ABI of
+``include/amber_hip.h`` and the C++ host object model of ``amber_amd/csrc/amber``).  This Python
+package is a thin ctypes binding used by the tests, ``bench.py`` and the multi-GPU driver; it
+contains no rendering code of its own and has no CPU fallback.
+"""
+from .api import (  # noqa: F401
+    AmberError,
+    FlatMaterial,
+    FlatObject,
+    FlatThinLens,
+    HostScene,
+    PathTracer,
+    PtParams,
+    Sensor,
+    build_library,
+    device_count,
+    kat_math,
+    library_path,
+    load_library,
+)

@@ -1,0 +1,301 @@
+"""ctypes binding of include/amber_hip.h and include/amber_host.h (no compute in Python)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_ROOT = Path(__file__).resolve().parent
+_LIB_PATH = _ROOT / "lib" / "libamber_hip.so"
+_lib = None
+
+
+class AmberError(RuntimeError):
+    """Raised for every non-zero return code of the C ABI (message = amber_hip_last_error())."""
+
+
+# ---- plain-data structs (include/amber_hip.h) ---------------------------------------------------
+class FlatObject(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("material", C.c_uint32), ("p", C.c_float * 12)]
+
+
+class FlatMaterial(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("rho", C.c_float * 3), ("param", C.c_float), ("r0", C.c_float)]
+
+
+class FlatThinLens(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("global_", C.c_float * 9), ("local_", C.c_float * 9),
+                ("focus_distance", C.c_float), ("sensor_distance", C.c_float), ("p_area", C.c_float),
+                ("n_blades", C.c_uint32), ("first_blade_object", C.c_uint32)]
+
+
+class FlatSceneC(C.Structure):
+    _fields_ = [("objects", C.POINTER(FlatObject)), ("n_objects", C.c_uint32),
+                ("materials", C.POINTER(FlatMaterial)), ("n_materials", C.c_uint32), ("lens", FlatThinLens)]
+
+
+class Sensor(C.Structure):
+    """rendering::Sensor(width, height, scene_width, scene_height) -- application.cc:89-94."""
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("scene_width", C.c_float), ("scene_height", C.c_float)]
+
+    @classmethod
+    def default(cls, width: int, height: int) -> "Sensor":
+        # application.cc:89-94: Sensor(w, h, 0.036, 0.036 / w * h) -- doubles narrowed to real_type
+        return cls(width, height, np.float32(0.036), np.float32(0.036 / width * height))
+
+
+class PtParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("max_depth", C.c_uint32), ("device", C.c_int32), ("row_begin", C.c_uint32),
+                ("row_end", C.c_uint32), ("stream", C.c_void_p), ("engine", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class HostStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("passes", C.c_uint64), ("launches", C.c_uint32), ("pad", C.c_uint32), ("kernel_ms", C.c_double)]
+
+
+PRIM_TRIANGLE, PRIM_SPHERE, PRIM_DISK, PRIM_CYLINDER = 0, 1, 2, 3
+MAT_LAMBERTIAN, MAT_PHONG, MAT_SPECULAR, MAT_REFRACTION, MAT_DIFFUSE_LIGHT, MAT_EYE = 0, 1, 2, 3, 4, 5
+ENGINE_AUTO, ENGINE_MEGAKERNEL, ENGINE_WAVEFRONT = 0, 1, 2
+
+# every symbol include/amber_hip.h and include/amber_host.h declare
+ABI_SYMBOLS = [
+    "amber_hip_pt_create", "amber_hip_pt_render_pass", "amber_hip_pt_clear", "amber_hip_pt_sync",
+    "amber_hip_pt_download", "amber_hip_pt_device_framebuffer", "amber_hip_pt_kernel_time", "amber_hip_pt_destroy",
+    "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_device_count",
+    "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math",
+    "amber_host_cornell_box", "amber_host_scene_create", "amber_host_scene_destroy", "amber_host_scene_flatten",
+    "amber_host_pt_create", "amber_host_render", "amber_host_last_error",
+]
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def build_library(force: bool = False) -> Path:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force or not _LIB_PATH.exists():
+        subprocess.run(["make", "-C", str(_ROOT / "csrc")] + (["-B"] if force else []), check=True)
+    return _LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    """Load libamber_hip.so.  Fails loudly: there is no CPU implementation to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise AmberError(f"{_LIB_PATH} is missing: build it with `make -C amber_amd/csrc` "
+                         "(or __graft_entry__.build()); amber_amd has no CPU fallback")
+    lib = C.CDLL(str(_LIB_PATH))
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+    lib.amber_hip_last_error.restype = C.c_char_p
+    lib.amber_host_last_error.restype = C.c_char_p
+    lib.amber_hip_pt_create.argtypes = [C.POINTER(FlatSceneC), C.POINTER(Sensor), C.POINTER(PtParams), C.POINTER(vp)]
+    lib.amber_hip_pt_render_pass.argtypes = [vp, u32, u32]
+    lib.amber_hip_pt_clear.argtypes = [vp]
+    lib.amber_hip_pt_sync.argtypes = [vp]
+    lib.amber_hip_pt_download.argtypes = [vp, vp, C.POINTER(u64)]
+    lib.amber_hip_pt_device_framebuffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    lib.amber_hip_pt_kernel_time.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_double)]
+    lib.amber_hip_pt_destroy.argtypes = [vp]
+    lib.amber_hip_pt_destroy.restype = None
+    lib.amber_hip_kat_cast.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
+    lib.amber_hip_kat_sample.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
+    lib.amber_hip_kat_eye.argtypes = [vp, u32, vp, vp, vp]
+    lib.amber_hip_kat_trace.argtypes = [vp, u32, vp, vp, u32, vp, vp]
+    lib.amber_hip_kat_math.argtypes = [i32, i32, u32, vp, vp]
+    lib.amber_host_cornell_box.restype = vp
+    lib.amber_host_cornell_box.argtypes = [C.c_float, C.c_float, u32]
+    lib.amber_host_scene_create.restype = vp
+    lib.amber_host_scene_create.argtypes = [C.POINTER(FlatObject), u32, C.POINTER(FlatMaterial), u32, C.POINTER(C.c_float),
+                                            C.c_float, C.c_float, C.c_float, u32, C.c_int]
+    lib.amber_host_scene_destroy.argtypes = [vp]
+    lib.amber_host_scene_destroy.restype = None
+    lib.amber_host_scene_flatten.argtypes = [vp, C.POINTER(FlatObject), C.POINTER(u32), C.POINTER(FlatMaterial), C.POINTER(u32),
+                                             C.POINTER(FlatThinLens)]
+    lib.amber_host_pt_create.argtypes = [vp, C.POINTER(Sensor), C.POINTER(PtParams), C.POINTER(vp)]
+    lib.amber_host_render.argtypes = [vp, C.c_char_p, C.POINTER(Sensor), u32, u64, u32, C.c_int, u32, vp, C.POINTER(HostStats)]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, host: bool = False) -> None:
+    if rc != 0:
+        lib = load_library()
+        msg = (lib.amber_host_last_error() if host else lib.amber_hip_last_error()) or b""
+        if host and not msg:
+            msg = lib.amber_hip_last_error() or b""
+        raise AmberError(f"amber error {rc}: {msg.decode(errors='replace')}")
+
+
+def device_count() -> int:
+    return int(load_library().amber_hip_device_count())
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class HostScene:
+    """Handle of a scene built by the C++ host object model (amber::scene::Scene)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise AmberError("scene creation failed: " + (load_library().amber_host_last_error() or b"").decode())
+        self._h = C.c_void_p(handle)
+
+    @classmethod
+    def cornell_box(cls, focal_length: float = 0.050, aperture_radius: float = 0.050, n_blades: int = 6) -> "HostScene":
+        """etude::CornelBox(0.050, 0.050, 6) -- application.cc:68-73."""
+        return cls(load_library().amber_host_cornell_box(focal_length, aperture_radius, n_blades))
+
+    @classmethod
+    def create(cls, objects, materials, transform, focal_length, focus_distance, radius, n_blades, accel: int = 0) -> "HostScene":
+        """objects: list of (kind, material, params...) ; materials: list of (kind, (r,g,b), param)."""
+        objs = (FlatObject * max(1, len(objects)))()
+        for i, (kind, mat, params) in enumerate(objects):
+            objs[i].kind, objs[i].material = kind, mat
+            for j, v in enumerate(params):
+                objs[i].p[j] = v
+        mats = (FlatMaterial * max(1, len(materials)))()
+        for i, (kind, rho, param) in enumerate(materials):
+            mats[i].kind, mats[i].param = kind, param
+            for j in range(3):
+                mats[i].rho[j] = rho[j]
+        t = (C.c_float * 16)(*[float(x) for x in transform])
+        return cls(load_library().amber_host_scene_create(objs, len(objects), mats, len(materials), t, focal_length,
+                                                          focus_distance, radius, n_blades, accel))
+
+    def flatten(self):
+        lib = load_library()
+        no, nm = C.c_uint32(0), C.c_uint32(0)
+        _check(lib.amber_host_scene_flatten(self._h, None, C.byref(no), None, C.byref(nm), None), host=True)
+        objs, mats, lens = (FlatObject * no.value)(), (FlatMaterial * nm.value)(), FlatThinLens()
+        _check(lib.amber_host_scene_flatten(self._h, objs, C.byref(no), mats, C.byref(nm), C.byref(lens)), host=True)
+        return objs, mats, lens
+
+    def render(self, sensor: Sensor, spp: int, seed: int = 12345, max_depth: int = 0, device: int = 0,
+               samples_per_launch: int = 0, algorithm: str = "pt"):
+        """Algorithm<RGB>::Render through cli::MakeAlgorithm(algorithm) and cli::Context(1, spp)."""
+        out = np.empty((sensor.height, sensor.width, 3), np.float32)
+        st = HostStats()
+        _check(load_library().amber_host_render(self._h, algorithm.encode(), C.byref(sensor), spp, seed, max_depth, device,
+                                                samples_per_launch, out.ctypes.data, C.byref(st)), host=True)
+        return out, {"rays": st.rays, "passes": st.passes, "launches": st.launches, "kernel_ms": st.kernel_ms}
+
+    def close(self):
+        if self._h:
+            load_library().amber_host_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PathTracer:
+    """amber_hip_pt handle: the device-side engine for one band of the framebuffer on one GPU."""
+
+    def __init__(self, scene: HostScene, sensor: Sensor, seed: int = 12345, max_depth: int = 0, device: int = 0,
+                 rows=None, stream: int | None = None, engine: int = ENGINE_AUTO):
+        self.sensor = sensor
+        rb, re = rows if rows is not None else (0, 0)
+        self.rows = (rb, re) if rows is not None else (0, sensor.height)
+        p = PtParams(seed, max_depth, device, rb, re, stream, engine, 0)
+        h = C.c_void_p()
+        _check(load_library().amber_host_pt_create(scene._h, C.byref(sensor), C.byref(p), C.byref(h)), host=True)
+        self._h = h
+
+    @property
+    def band_shape(self):
+        return (self.rows[1] - self.rows[0], self.sensor.width, 3)
+
+    def render_pass(self, first_sample: int, n_samples: int) -> None:
+        _check(load_library().amber_hip_pt_render_pass(self._h, first_sample, n_samples))
+
+    def clear(self) -> None:
+        _check(load_library().amber_hip_pt_clear(self._h))
+
+    def sync(self) -> None:
+        _check(load_library().amber_hip_pt_sync(self._h))
+
+    def download(self):
+        out = np.empty(self.band_shape, np.float32)
+        rays = C.c_uint64()
+        _check(load_library().amber_hip_pt_download(self._h, out.ctypes.data, C.byref(rays)))
+        return out, rays.value
+
+    def ray_count(self) -> int:
+        rays = C.c_uint64()
+        _check(load_library().amber_hip_pt_download(self._h, None, C.byref(rays)))
+        return rays.value
+
+    def device_framebuffer(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        _check(load_library().amber_hip_pt_device_framebuffer(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def kernel_time(self):
+        n, ms = C.c_uint32(), C.c_double()
+        _check(load_library().amber_hip_pt_kernel_time(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    # ---- known-answer entry points -----------------------------------------------------------
+    def kat_cast(self, origins, dirs):
+        o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+        n = len(o)
+        obj, t = np.empty(n, np.int32), np.empty(n, np.float32)
+        pos, nrm = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+        _check(load_library().amber_hip_kat_cast(self._h, n, o.ctypes.data, d.ctypes.data, obj.ctypes.data, t.ctypes.data,
+                                                 pos.ctypes.data, nrm.ctypes.data))
+        return obj, t, pos, nrm
+
+    def kat_sample(self, material, normals, dirs_out, rng_state):
+        m = np.ascontiguousarray(material, np.uint32)
+        nn, dd = _f32(normals).reshape(-1, 3), _f32(dirs_out).reshape(-1, 3)
+        st = np.ascontiguousarray(rng_state, np.uint64).copy()
+        n = len(m)
+        di, w = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+        _check(load_library().amber_hip_kat_sample(self._h, n, m.ctypes.data, nn.ctypes.data, dd.ctypes.data, st.ctypes.data,
+                                                   di.ctypes.data, w.ctypes.data))
+        return di, w, st
+
+    def kat_eye(self, pixel, sample):
+        p, s = np.ascontiguousarray(pixel, np.uint32), np.ascontiguousarray(sample, np.uint32)
+        out = np.empty((len(p), 7), np.float32)
+        _check(load_library().amber_hip_kat_eye(self._h, len(p), p.ctypes.data, s.ctypes.data, out.ctypes.data))
+        return out
+
+    def kat_trace(self, pixel, sample, max_bounces: int = 16):
+        p, s = np.ascontiguousarray(pixel, np.uint32), np.ascontiguousarray(sample, np.uint32)
+        rec = np.zeros((len(p), max_bounces, 11), np.uint32)
+        casts = np.zeros(len(p), np.uint32)
+        _check(load_library().amber_hip_kat_trace(self._h, len(p), p.ctypes.data, s.ctypes.data, max_bounces, rec.ctypes.data,
+                                                  casts.ctypes.data))
+        return rec, casts
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().amber_hip_pt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def kat_math(mode: int, x, device: int = 0) -> np.ndarray:
+    """Portable device math: mode 0 sincos(x[i]) -> (n,2) ; mode 1 pow(x[i,0], x[i,1]) -> (n,)."""
+    x = _f32(x)
+    n = len(x)
+    out = np.empty((n, 2) if mode == 0 else (n,), np.float32)
+    _check(load_library().amber_hip_kat_math(device, mode, n, x.ctypes.data, out.ctypes.data))
+    return out

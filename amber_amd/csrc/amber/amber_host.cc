@@ -1,0 +1,380 @@
+// amber_host.cc -- implementation of the host object model (amber/scene.h, amber/rendering.h).
+//
+// Concrete primitives / materials / lens are private to this file, as in the reference
+// (primitive_*.cc, material_*.cc, lens_thin.cc); only the Make* factories are exported.
+// Everything computed here is scene DATA for the device; file:line citations are relative to
+// /root/reference.
+#include <cstring>
+#include <stdexcept>
+#include <type_traits>
+
+#include "rendering.h"
+#include "scene.h"
+
+namespace amber {
+namespace prelude {
+
+Matrix3 Matrix3::Inverse() const {   // matrix3.h:111-143
+  const real_type e11 = e[0], e12 = e[1], e13 = e[2], e21 = e[3], e22 = e[4], e23 = e[5], e31 = e[6], e32 = e[7], e33 = e[8];
+  const real_type d = +e11 * (e22 * e33 - e23 * e32) - e21 * (e12 * e33 - e13 * e32) + e31 * (e12 * e23 - e13 * e22);
+  Matrix3 r;
+  if (d == 0) {
+    for (real_type& x : r.e) x = std::numeric_limits<real_type>::quiet_NaN();
+    return r;
+  }
+  const real_type dinv = 1 / d;
+  r.e[0] = +dinv * (e22 * e33 - e23 * e32); r.e[1] = -dinv * (e12 * e33 - e13 * e32); r.e[2] = +dinv * (e12 * e23 - e13 * e22);
+  r.e[3] = -dinv * (e21 * e33 - e23 * e31); r.e[4] = +dinv * (e11 * e33 - e13 * e31); r.e[5] = -dinv * (e11 * e23 - e13 * e21);
+  r.e[6] = +dinv * (e21 * e32 - e22 * e31); r.e[7] = -dinv * (e11 * e32 - e12 * e31); r.e[8] = +dinv * (e11 * e22 - e12 * e21);
+  return r;
+}
+
+}  // namespace prelude
+
+namespace scene {
+namespace {
+
+void Put3(float* dst, const Vector3& v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
+
+// ---- primitives -------------------------------------------------------------------------------
+class Triangle : public Primitive {   // primitive_triangle.cc:33-150
+ public:
+  Triangle(const Vector3& v0, const Vector3& v1, const Vector3& v2) noexcept
+      : v0_(v0), v1_(v1), v2_(v2), normal_(Normalize(Cross(v1 - v0, v2 - v0))) {}
+  const Vector3 Center() const noexcept override {
+    return Vector3((v0_.x + v1_.x + v2_.x) / 3, (v0_.y + v1_.y + v2_.y) / 3, (v0_.z + v1_.z + v2_.z) / 3);
+  }
+  const AABB BoundingBox() const noexcept override {
+    return AABB{Vector3(std::min({v0_.x, v1_.x, v2_.x}), std::min({v0_.y, v1_.y, v2_.y}), std::min({v0_.z, v1_.z, v2_.z})),
+                Vector3(std::max({v0_.x, v1_.x, v2_.x}), std::max({v0_.y, v1_.y, v2_.y}), std::max({v0_.z, v1_.z, v2_.z}))};
+  }
+  real_type SurfaceArea() const noexcept override { return Length(Cross(v1_ - v0_, v2_ - v0_)) / 2; }
+  void Flatten(AmberFlatObject& o) const noexcept override {
+    o.kind = AMBER_PRIM_TRIANGLE;
+    Put3(o.p, v0_); Put3(o.p + 3, v1_); Put3(o.p + 6, v2_); Put3(o.p + 9, normal_);
+  }
+
+ private:
+  Vector3 v0_, v1_, v2_;
+  UnitVector3 normal_;
+};
+
+class Sphere : public Primitive {   // primitive_sphere.cc:32-125
+ public:
+  Sphere(const Vector3& center, real_type radius) noexcept : center_(center), radius_(radius) {}
+  const Vector3 Center() const noexcept override { return center_; }
+  const AABB BoundingBox() const noexcept override { return AABB{center_ - radius_, center_ + radius_}; }
+  real_type SurfaceArea() const noexcept override { return 4 * static_cast<real_type>(kPI) * radius_ * radius_; }
+  void Flatten(AmberFlatObject& o) const noexcept override {
+    o.kind = AMBER_PRIM_SPHERE;
+    Put3(o.p, center_); o.p[3] = radius_;
+  }
+
+ private:
+  Vector3 center_;
+  real_type radius_;
+};
+
+AABB DiskBox(const Vector3& c, const Vector3& n, real_type r) {   // primitive_disk.cc:81-92
+  const Vector3 f(std::sqrt(1 - n.x * n.x), std::sqrt(1 - n.y * n.y), std::sqrt(1 - n.z * n.z));
+  return AABB{c - r * f, c + r * f};
+}
+
+class Disk : public Primitive {   // primitive_disk.cc:33-139 (normal is stored as given, not normalised)
+ public:
+  Disk(const Vector3& center, const Vector3& normal, real_type radius) noexcept : center_(center), normal_(normal), radius_(radius) {}
+  const Vector3 Center() const noexcept override { return center_; }
+  const AABB BoundingBox() const noexcept override { return DiskBox(center_, normal_, radius_); }
+  real_type SurfaceArea() const noexcept override { return static_cast<real_type>(kPI) * radius_ * radius_; }
+  void Flatten(AmberFlatObject& o) const noexcept override {
+    o.kind = AMBER_PRIM_DISK;
+    Put3(o.p, center_); Put3(o.p + 3, normal_); o.p[6] = radius_;
+  }
+
+ private:
+  Vector3 center_;
+  UnitVector3 normal_;
+  real_type radius_;
+};
+
+class Cylinder : public Primitive {   // primitive_cylinder.cc:33-167
+ public:
+  Cylinder(const Vector3& center, const Vector3& normal, real_type radius, real_type height) noexcept
+      : center_(center), normal_(normal), radius_(radius), height_(height), bb_(AABB::Empty()) {
+    bb_ += DiskBox(center_, normal_, radius_);
+    bb_ += DiskBox(center_ + height_ * normal_, normal_, radius_);
+  }
+  const Vector3 Center() const noexcept override { return center_ + height_ / 2 * normal_; }
+  const AABB BoundingBox() const noexcept override { return bb_; }
+  real_type SurfaceArea() const noexcept override { return 2 * static_cast<real_type>(kPI) * radius_ * height_; }
+  void Flatten(AmberFlatObject& o) const noexcept override {
+    o.kind = AMBER_PRIM_CYLINDER;
+    Put3(o.p, center_); Put3(o.p + 3, normal_); o.p[6] = radius_; o.p[7] = height_;
+  }
+
+ private:
+  Vector3 center_;
+  UnitVector3 normal_;
+  real_type radius_, height_;
+  AABB bb_;
+};
+
+// ---- materials ----------------------------------------------------------------------------------
+class FlatMaterial : public Material {
+ public:
+  FlatMaterial(uint32_t kind, rendering::SurfaceType surface, const RGB& rho, real_type param, real_type r0)
+      : kind_(kind), surface_(surface), rho_(rho), param_(param), r0_(r0) {}
+  rendering::SurfaceType Surface() const noexcept override { return surface_; }
+  void Flatten(AmberFlatMaterial& m) const noexcept override {
+    m.kind = kind_; m.rho[0] = rho_.x; m.rho[1] = rho_.y; m.rho[2] = rho_.z; m.param = param_; m.r0 = r0_;
+  }
+
+ private:
+  uint32_t kind_;
+  rendering::SurfaceType surface_;
+  RGB rho_;
+  real_type param_, r0_;
+};
+
+// ---- thin lens (lens_thin.cc:32-57, lens_basic.h:100-125) ---------------------------------------------
+class ThinLens : public Lens {
+ public:
+  ThinLens(const Matrix4& transform, real_type focal_length, real_type focus_distance, real_type radius, std::size_t n_blades)
+      : origin_(transform(Vector3())), global_(static_cast<Matrix3>(transform)), local_(global_.Inverse()),
+        focus_distance_(focus_distance), sensor_distance_(1 / (1 / focal_length - 1 / focus_distance)), p_area_(1),
+        eye_(MakeEye()) {
+    for (std::size_t i = 0; i < n_blades; i++) {
+      const real_type alpha = 2 * static_cast<real_type>(kPI) / n_blades * i;
+      const real_type beta = 2 * static_cast<real_type>(kPI) / n_blades * (i + 1);
+      primitives_.emplace_back(MakeTriangle(origin_ + global_(radius * Vector3(std::cos(alpha), std::sin(alpha), 0)),
+                                            origin_ + global_(radius * Vector3(std::cos(beta), std::sin(beta), 0)), origin_));
+    }
+    p_area_ /= primitives_.front()->SurfaceArea() * n_blades;
+    objects_.reserve(primitives_.size());
+    for (const auto& p : primitives_) objects_.emplace_back(p.get(), eye_.get());
+  }
+  // The reference iterates an unordered_map keyed by primitive address (lens_basic.h:113-124), i.e. an
+  // arbitrary order; blade order is used here (object order only matters for exact distance ties).
+  std::vector<const Object*> ApertureObjects() const noexcept override {
+    std::vector<const Object*> v;
+    for (const auto& o : objects_) v.push_back(&o);
+    return v;
+  }
+  void Flatten(AmberFlatThinLens& L) const noexcept override {
+    Put3(L.origin, origin_);
+    std::memcpy(L.global_, global_.e, sizeof L.global_);
+    std::memcpy(L.local_, local_.e, sizeof L.local_);
+    L.focus_distance = focus_distance_; L.sensor_distance = sensor_distance_; L.p_area = p_area_;
+    L.n_blades = static_cast<uint32_t>(primitives_.size());
+  }
+
+ private:
+  Vector3 origin_;
+  Matrix3 global_, local_;
+  real_type focus_distance_, sensor_distance_, p_area_;
+  std::unique_ptr<Material> eye_;
+  std::vector<std::unique_ptr<Primitive>> primitives_;
+  std::vector<Object> objects_;
+};
+
+}  // namespace
+
+std::unique_ptr<Primitive> MakeSphere(const Vector3& c, real_type r) noexcept { return std::make_unique<Sphere>(c, r); }
+std::unique_ptr<Primitive> MakeTriangle(const Vector3& a, const Vector3& b, const Vector3& c) noexcept { return std::make_unique<Triangle>(a, b, c); }
+std::unique_ptr<Primitive> MakeDisk(const Vector3& c, const Vector3& n, real_type r) noexcept { return std::make_unique<Disk>(c, n, r); }
+std::unique_ptr<Primitive> MakeCylinder(const Vector3& c, const Vector3& n, real_type r, real_type h) noexcept { return std::make_unique<Cylinder>(c, n, r, h); }
+
+std::unique_ptr<Material> MakeLambertian(const RGB& kd) {
+  return std::make_unique<FlatMaterial>(AMBER_MAT_LAMBERTIAN, rendering::SurfaceType::Diffuse, kd, 0, 0);
+}
+std::unique_ptr<Material> MakePhong(const RGB& ks, real_type exponent) {
+  return std::make_unique<FlatMaterial>(AMBER_MAT_PHONG, rendering::SurfaceType::Diffuse, ks, exponent, 0);
+}
+std::unique_ptr<Material> MakeSpecular(const RGB& ks) {
+  return std::make_unique<FlatMaterial>(AMBER_MAT_SPECULAR, rendering::SurfaceType::Specular, ks, 0, 0);
+}
+std::unique_ptr<Material> MakeRefraction(real_type ior) {
+  // BasicRefraction::Fresnel material_refraction.cc:265-269: std::pow(float, int) is evaluated in double
+  const real_type r0 = static_cast<real_type>(std::pow(static_cast<double>((ior - 1) / (ior + 1)), 2.0));
+  return std::make_unique<FlatMaterial>(AMBER_MAT_REFRACTION, rendering::SurfaceType::Specular, RGB(1), ior, r0);
+}
+std::unique_ptr<Material> MakeDiffuseLight(const RGB& radiance) {
+  return std::make_unique<FlatMaterial>(AMBER_MAT_DIFFUSE_LIGHT, rendering::SurfaceType::Light, radiance, 0, 0);
+}
+std::unique_ptr<Material> MakeEye() {
+  return std::make_unique<FlatMaterial>(AMBER_MAT_EYE, rendering::SurfaceType::Eye, RGB(1), 0, 0);
+}
+
+std::unique_ptr<Lens> MakeThinLens(const Matrix4& transform, real_type focal_length, real_type focus_distance,
+                                   real_type radius, std::size_t n_blades) {
+  if (n_blades == 0) throw std::invalid_argument("MakeThinLens: n_blades must be positive");
+  return std::make_unique<ThinLens>(transform, focal_length, focus_distance, radius, n_blades);
+}
+
+FlatScene Scene::Flatten() const {
+  FlatScene fs;
+  std::vector<const Material*> mat_ids;
+  auto material_index = [&](const Material* m) {
+    for (std::size_t i = 0; i < mat_ids.size(); i++)
+      if (mat_ids[i] == m) return static_cast<uint32_t>(i);
+    mat_ids.push_back(m);
+    AmberFlatMaterial fm{};
+    m->Flatten(fm);
+    fs.materials.push_back(fm);
+    return static_cast<uint32_t>(mat_ids.size() - 1);
+  };
+  fs.objects.reserve(objects_.size());
+  for (const Object& o : objects_) {
+    AmberFlatObject fo{};
+    o.GetPrimitive()->Flatten(fo);
+    fo.material = material_index(o.GetMaterial());
+    fs.objects.push_back(fo);
+  }
+  AmberFlatThinLens L{};
+  lens_->Flatten(L);
+  const auto blades = lens_->ApertureObjects();
+  // locate blade 0 and require blade order
+  std::size_t first = objects_.size();
+  for (std::size_t i = 0; i < objects_.size(); i++)
+    if (objects_[i].GetPrimitive() == blades.front()->GetPrimitive()) { first = i; break; }
+  if (first + blades.size() > objects_.size()) throw std::runtime_error("Scene::Flatten: aperture objects are not part of the scene");
+  for (std::size_t b = 0; b < blades.size(); b++)
+    if (objects_[first + b].GetPrimitive() != blades[b]->GetPrimitive())
+      throw std::runtime_error("Scene::Flatten: aperture objects must be contiguous and in blade order");
+  L.first_blade_object = static_cast<uint32_t>(first);
+  fs.flat.objects = fs.objects.data(); fs.flat.n_objects = static_cast<uint32_t>(fs.objects.size());
+  fs.flat.materials = fs.materials.data(); fs.flat.n_materials = static_cast<uint32_t>(fs.materials.size());
+  fs.flat.lens = L;
+  return fs;
+}
+
+}  // namespace scene
+
+// ---- etude::CornelBox (src/amber/etude/cornel_box.cc:38-204) -------------------------------------------
+namespace etude {
+
+scene::RGBScene CornelBox(scene::real_type focal_length, scene::real_type aperture_radius, std::size_t aperture_n_blades) {
+  using namespace scene;
+  std::vector<std::unique_ptr<Primitive>> primitives;
+  std::vector<std::unique_ptr<RGBMaterial>> materials;
+  std::vector<RGBObject> objects;
+
+  auto lens = MakeThinLens(Matrix4(1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 4, 0, 0, 0, 1), focal_length, 4, aperture_radius, aperture_n_blades);
+  for (const auto& object : lens->ApertureObjects()) objects.emplace_back(*object);
+
+  auto quad = [&](const Material* m, const Vector3& a, const Vector3& b, const Vector3& c, const Vector3& d, const Vector3& e,
+                  const Vector3& f) {
+    primitives.emplace_back(MakeTriangle(a, b, c));
+    objects.emplace_back(primitives.back().get(), m);
+    primitives.emplace_back(MakeTriangle(d, e, f));
+    objects.emplace_back(primitives.back().get(), m);
+  };
+  // literals are double in the reference and narrow at the Vector3 / RGB / real_type parameters
+  auto F = [](double v) { return static_cast<float>(v); };
+  auto V = [&](double x, double y, double z) { return Vector3(F(x), F(y), F(z)); };
+
+  materials.emplace_back(MakeDiffuseLight(RGB(F(1e11), F(1e11), F(1e11))));   // light source
+  quad(materials.back().get(), V(0.01, 0.99, 0.01), V(-0.01, 0.99, 0.01), V(-0.01, 0.99, -0.01),
+       V(-0.01, 0.99, -0.01), V(0.01, 0.99, -0.01), V(0.01, 0.99, 0.01));
+  materials.emplace_back(MakeLambertian(RGB(F(.5), 0, 0)));              // left wall
+  quad(materials.back().get(), V(-1, 1, 1), V(-1, -1, 1), V(-1, -1, -1), V(-1, -1, -1), V(-1, 1, -1), V(-1, 1, 1));
+  materials.emplace_back(MakeLambertian(RGB(0, F(.5), 0)));              // right wall
+  quad(materials.back().get(), V(1, 1, 1), V(1, 1, -1), V(1, -1, -1), V(1, -1, -1), V(1, -1, 1), V(1, 1, 1));
+  materials.emplace_back(MakePhong(RGB(F(.95)), 256));                   // back wall
+  quad(materials.back().get(), V(1, 1, -1), V(-1, 1, -1), V(-1, -1, -1), V(-1, -1, -1), V(1, -1, -1), V(1, 1, -1));
+  materials.emplace_back(MakeLambertian(RGB(F(.5))));                    // floor
+  quad(materials.back().get(), V(1, -1, 1), V(1, -1, -1), V(-1, -1, -1), V(-1, -1, -1), V(-1, -1, 1), V(1, -1, 1));
+  materials.emplace_back(MakeLambertian(RGB(F(.5))));                    // ceiling
+  quad(materials.back().get(), V(1, 1, 1), V(-1, 1, 1), V(-1, 1, -1), V(-1, 1, -1), V(1, 1, -1), V(1, 1, 1));
+  materials.emplace_back(MakeRefraction(F(1.333)));                      // water surface + front strip
+  quad(materials.back().get(), V(1, -0.5, 1), V(1, -0.5, -1), V(-1, -0.5, -1), V(-1, -0.5, -1), V(-1, -0.5, 1), V(1, -0.5, 1));
+  quad(materials.back().get(), V(1, -0.5, 1), V(-1, -0.5, 1), V(-1, -1, 1), V(-1, -1, 1), V(1, -1, 1), V(1, -0.5, 1));
+
+  primitives.emplace_back(MakeSphere(V(0.4, -0.6, -0.5), F(0.4)));       // diffuse sphere
+  materials.emplace_back(MakeLambertian(RGB(F(.5))));
+  objects.emplace_back(primitives.back().get(), materials.back().get());
+  primitives.emplace_back(MakeSphere(V(-0.4, -0.7, 0.1), F(0.3)));       // specular sphere
+  materials.emplace_back(MakeSpecular(RGB(F(.95))));
+  objects.emplace_back(primitives.back().get(), materials.back().get());
+  primitives.emplace_back(MakeSphere(V(0.1, -0.8, 0.6), F(0.2)));        // refraction sphere
+  materials.emplace_back(MakeRefraction(F(1.125)));
+  objects.emplace_back(primitives.back().get(), materials.back().get());
+
+  return RGBScene::Create<raytracer::BVH<real_type, RGBObject>>(std::move(primitives), std::move(materials),
+                                                                std::move(objects), std::move(lens));
+}
+
+}  // namespace etude
+
+// ---- rendering::HipPathTracing --------------------------------------------------------------------------
+namespace rendering {
+
+namespace {
+struct Handle {
+  amber_hip_pt* h = nullptr;
+  ~Handle() { if (h) amber_hip_pt_destroy(h); }
+};
+void Check(int rc, const char* what) {
+  if (rc != AMBER_OK) throw std::runtime_error(std::string(what) + ": " + amber_hip_last_error());
+}
+}  // namespace
+
+const Image<RGB> HipPathTracing::Render(const Scene<RGB>& scene, const Sensor& sensor, Context& context) {
+  stats_ = HipPathTracingStats();
+  const scene::FlatScene fs = scene.Flatten();
+  AmberSensor s{static_cast<uint32_t>(sensor.Width()), static_cast<uint32_t>(sensor.Height()), sensor.SceneWidth(), sensor.SceneHeight()};
+  AmberPtParams p{};
+  p.seed = options_.seed; p.max_depth = options_.max_depth; p.device = options_.device;
+  p.row_begin = options_.row_begin; p.row_end = options_.row_end; p.engine = options_.engine;
+  Handle handle;
+  Check(amber_hip_pt_create(&fs.flat, &s, &p, &handle.h), "amber_hip_pt_create");
+
+  // Context contract (context.cc:48-60): each successful Iterate() is one whole-image sample.
+  // Claim up to samples_per_launch passes, render them in one launch, repeat until Iterate() fails.
+  const uint32_t batch = options_.samples_per_launch ? options_.samples_per_launch : 1;
+  uint32_t first = 0;
+  for (;;) {
+    uint32_t n = 0;
+    while (n < batch && context.Iterate()) n++;
+    if (n == 0) break;
+    Check(amber_hip_pt_render_pass(handle.h, first, n), "amber_hip_pt_render_pass");
+    Check(amber_hip_pt_sync(handle.h), "amber_hip_pt_sync");   // bounded run-ahead: progress polling stays truthful
+    first += n;
+    stats_.passes += n;
+    if (n < batch) break;
+  }
+
+  const uint32_t rb = options_.row_begin, re = (options_.row_begin == 0 && options_.row_end == 0) ? s.height : options_.row_end;
+  std::vector<float> band(static_cast<std::size_t>(re - rb) * s.width * 3);
+  uint64_t rays = 0;
+  Check(amber_hip_pt_download(handle.h, band.data(), &rays), "amber_hip_pt_download");
+  stats_.rays = rays;
+  Check(amber_hip_pt_kernel_time(handle.h, &stats_.launches, &stats_.kernel_ms), "amber_hip_pt_kernel_time");
+
+  auto image = sensor.CreateImage<RGB>();
+  for (uint32_t y = rb; y < re; y++)
+    for (uint32_t x = 0; x < s.width; x++) {
+      const float* v = &band[(static_cast<std::size_t>(y - rb) * s.width + x) * 3];
+      image[Pixel(x, y)] = RGB(v[0], v[1], v[2]);
+    }
+  // Accumulator::Mean (accumulator.h:88-95): Sum() / size_ -- component-wise binary32 division
+  if (stats_.passes) image /= RGB(static_cast<real_type>(stats_.passes));
+  return image;
+}
+
+std::unique_ptr<Algorithm<RGB>> MakeRGBHipPathTracing(const HipPathTracingOptions& options) {
+  return std::make_unique<HipPathTracing>(options);
+}
+
+}  // namespace rendering
+
+namespace cli {
+std::unique_ptr<rendering::Algorithm<rendering::RGB>> MakeAlgorithm(const std::string& name,
+                                                                   const rendering::HipPathTracingOptions& options) {
+  // algorithm_factory.cc:35-79 dispatches on --algorithm; this package provides the path tracer only.
+  if (name == "pt" || name == "pt-hip") return rendering::MakeRGBHipPathTracing(options);
+  throw UnknownAlgorithmError(name);
+}
+}  // namespace cli
+
+}  // namespace amber

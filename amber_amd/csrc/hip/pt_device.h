@@ -1,0 +1,439 @@
+// pt_device.h -- gfx950 device functions of the path-tracing engine.
+//
+// Arithmetic contract (DESIGN.md "Numerics"): every float operation below is a single IEEE
+// binary32 operation in the order the reference performs it; the translation unit is built with
+// -ffp-contract=off (the reference's x86 build has no FMA) and hipcc's default correctly rounded
+// f32 divide/sqrt and un-flushed subnormals.  No OCML math call is on the path: sin/cos/pow are
+// the "portable" forms specified in DESIGN.md (Cephes-style reduction + polynomials, atanh-series
+// log, Taylor exp), built from + - * / only, so the CPU oracle reproduces them bit-for-bit.
+//
+// Reference citations are relative to /root/reference.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace amber_dev {
+
+// ---------------------------------------------------------------------------------------------
+// device-side scene layout (HBM, read through the scalar cache when the index is wave-uniform)
+// ---------------------------------------------------------------------------------------------
+struct alignas(16) DevObject {   // 64 B
+  float a[3];   uint32_t kind;       // triangle v0 | sphere/disk/cylinder centre
+  float e1[3];  float radius;        // triangle E1 = v1 - v0 | disk/cylinder normal
+  float e2[3];  float height;        // triangle E2 = v2 - v0
+  float n[3];   uint32_t material;   // triangle normal
+};
+struct alignas(16) DevMaterial {  // 32 B
+  uint32_t kind; float rho[3];
+  float param; float r0; float pad[2];
+};
+struct alignas(16) DevBlade {     // 48 B: aperture triangle with explicit vertices (SampleSurfacePoint)
+  float v0[3], v1[3], v2[3], n[3];
+};
+struct DevLens {
+  float origin[3];
+  float global_[9];
+  float local_[9];
+  float focus_distance, sensor_distance, p_area;
+  float neg_fd_over_sd;       // -focus_distance / sensor_distance (lens_thin.cc:87)
+  float size_over_area;       // sensor.Size() / sensor.SceneArea() in float (lens_thin.cc:145)
+  double sd2;                 // std::pow(sensor_distance_, 2) in double (lens_thin.cc:146)
+  uint32_t n_blades;
+  float n_blades_f;
+};
+struct DevSensor {
+  uint32_t w, h;
+  float wf, hf, sw, sh;
+};
+struct DevScene {
+  const DevObject* __restrict__ objects;
+  const DevMaterial* __restrict__ materials;
+  const DevBlade* __restrict__ blades;
+  uint32_t n_objects;
+  uint32_t max_depth;
+  DevLens lens;
+  DevSensor sensor;
+};
+
+enum { PRIM_TRIANGLE = 0, PRIM_SPHERE = 1, PRIM_DISK = 2, PRIM_CYLINDER = 3 };
+enum { MAT_LAMBERTIAN = 0, MAT_PHONG = 1, MAT_SPECULAR = 2, MAT_REFRACTION = 3, MAT_DIFFUSE_LIGHT = 4, MAT_EYE = 5 };
+
+// ---------------------------------------------------------------------------------------------
+// Vector3 (include/amber/prelude/vector3.h:36-342): component-wise ops, scalar splat
+// ---------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ V3 operator/(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 v) { return V3{s * v.x, s * v.y, s * v.z}; }
+__device__ __forceinline__ V3 operator*(V3 v, float s) { return V3{v.x * s, v.y * s, v.z * s}; }
+__device__ __forceinline__ V3 operator/(V3 v, float s) { return V3{v.x / s, v.y / s, v.z / s}; }
+__device__ __forceinline__ V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ float Dot(V3 u, V3 v) { return u.x * v.x + u.y * v.y + u.z * v.z; }
+__device__ __forceinline__ float SquaredLength(V3 v) { return Dot(v, v); }
+__device__ __forceinline__ float Sqrt(float x) { return __fsqrt_rn(x); }
+__device__ __forceinline__ V3 Normalize(V3 v) { const float l = Sqrt(SquaredLength(v)); return V3{v.x / l, v.y / l, v.z / l}; }
+__device__ __forceinline__ V3 Cross(V3 u, V3 v) {
+  return V3{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+}
+// std::max({x,y,z}) (vector3.h:276-281): first element wins unless a later one is strictly greater
+__device__ __forceinline__ float Max3(V3 v) { float m = v.x; if (m < v.y) m = v.y; if (m < v.z) m = v.z; return m; }
+__device__ __forceinline__ float Abs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ void OrthonormalBasis(V3 w, V3& u, V3& v) {      // vector3.h:330-342
+  const bool xs = Abs(w.x) < Abs(w.y);
+  u = Normalize(Cross(w, xs ? v3(1.f, 0.f, 0.f) : v3(0.f, 1.f, 0.f)));
+  v = Normalize(Cross(w, u));
+}
+__device__ __forceinline__ V3 MatMul(const float* e, V3 v) {               // matrix3.h:101-109
+  return v3(e[0] * v.x + e[1] * v.y + e[2] * v.z, e[3] * v.x + e[4] * v.y + e[5] * v.z, e[6] * v.x + e[7] * v.y + e[8] * v.z);
+}
+__device__ __forceinline__ bool IsFinite(float x) { return Abs(x) < __builtin_inff(); }   // false for NaN and inf
+
+// ---------------------------------------------------------------------------------------------
+// per-(pixel,sample) XorShift sampler (DESIGN.md "Sampler"): splitmix64-hashed seed, Marsaglia
+// xorshift64 (13,7,17), uniform = top 24 bits * 2^-24 -- exact in binary32, never 1.0.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t SplitMix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t XorShiftSeed(uint64_t hashed_global_seed, uint32_t pixel, uint32_t sample) {
+  const uint64_t key = (static_cast<uint64_t>(pixel) << 32) | sample;
+  const uint64_t s = SplitMix64(hashed_global_seed ^ key);
+  return s ? s : 0x9E3779B97F4A7C15ull;
+}
+__device__ __forceinline__ float Uniform(uint64_t& s) {
+  s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+  return static_cast<float>(static_cast<uint32_t>(s >> 40)) * 0x1p-24f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// portable math (bit-identical to oracle/amber_oracle.cc PortableSinCos / PortablePow)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void SinCos(float x, float& s_out, float& c_out) {
+  const float FOPI = 1.27323954473516f;
+  const float DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
+  int j = static_cast<int>(FOPI * x);
+  j += (j & 1);
+  const float y = static_cast<float>(j);
+  const float r = ((x - y * DP1) - y * DP2) - y * DP3;
+  const float z = r * r;
+  const float ps = ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * r + r;
+  const float pc = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z + 4.166664568298827E-002f) * z * z
+                   - 0.5f * z + 1.0f;
+  const int q = (j >> 1) & 3;
+  const float s = (q & 1) ? pc : ps;
+  const float c = (q & 1) ? ps : pc;
+  s_out = (q & 2) ? -s : s;
+  c_out = (q == 1 || q == 2) ? -c : c;
+}
+__device__ __forceinline__ float Pow(float x, float y) {
+  if (y == 0.0f) return 1.0f;
+  if (x == 0.0f) return y > 0.0f ? 0.0f : __builtin_inff();
+  if (x == 1.0f) return 1.0f;
+  uint32_t bits = __float_as_uint(x);
+  int e = static_cast<int>((bits >> 23) & 0xff);
+  if (e == 0) { x = x * 16777216.0f; bits = __float_as_uint(x); e = static_cast<int>((bits >> 23) & 0xff) - 24; }
+  e -= 127;
+  float m = __uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
+  if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+  const float f = m - 1.0f;
+  const float s = f / (2.0f + f);
+  const float z = s * s;
+  float p = 0.0909090909f;
+  p = p * z + 0.111111111f;
+  p = p * z + 0.142857143f;
+  p = p * z + 0.2f;
+  p = p * z + 0.333333333f;
+  p = p * z + 1.0f;
+  const float ln_m = 2.0f * s * p;
+  const float log2x = static_cast<float>(e) + ln_m * 1.44269504f;
+  const float w = y * log2x;
+  if (w >= 128.0f) return __builtin_inff();
+  if (w < -149.0f) return 0.0f;
+  const float nf = __builtin_floorf(w + 0.5f);
+  const float g = w - nf;
+  const float t = g * 0.693147181f;
+  float q = 1.98412698e-4f;
+  q = q * t + 1.38888889e-3f;
+  q = q * t + 8.33333333e-3f;
+  q = q * t + 4.16666667e-2f;
+  q = q * t + 1.66666667e-1f;
+  q = q * t + 0.5f;
+  q = q * t + 1.0f;
+  q = q * t + 1.0f;
+  int n = static_cast<int>(nf);
+  if (n < -126) { q = q * __uint_as_float(static_cast<uint32_t>(n + 126 + 127) << 23); n = -126; }
+  return q * __uint_as_float(static_cast<uint32_t>(n + 127) << 23);
+}
+// std::pow(float, int) promotes to double (C++11); portable form: exact square, one or two roundings
+__device__ __forceinline__ double Pow4(float x) { const double d = x; const double d2 = d * d; return d2 * d2; }
+__device__ __forceinline__ double Pow5(float x) { const double d = x; const double d2 = d * d; return (d2 * d2) * d; }
+
+// ---------------------------------------------------------------------------------------------
+// closest hit -- List semantics (acceleration_list.h:51-68): scan objects in insertion order,
+// keep a hit iff it is finite and STRICTLY closer.  The object index is wave-uniform, so object
+// data arrives through scalar loads and sits in SGPRs.
+// ---------------------------------------------------------------------------------------------
+#define AMBER_KEPS 1e-6f   // (t < kEPS) <=> (t <= 1e-6f) ; (t > kEPS) <=> (t > 1e-6f): 1e-6f < 1e-6L < nextafterf(1e-6f)
+
+struct HitRec { float t, u, v; int idx; };
+
+// algebra.h:31-52
+__device__ __forceinline__ bool SolveQuadratic(float a, float b, float c, float& alpha, float& beta) {
+  const float d = b * b - 4.0f * a * c;
+  if (d < 0.0f) return false;
+  const float sqrt_d = Sqrt(d);
+  alpha = -b - sqrt_d;
+  beta = -b + sqrt_d;
+  if (Abs(alpha) < Abs(beta)) { alpha = c / beta * 2.0f; beta = beta / (2.0f * a); }
+  else { beta = c / alpha * 2.0f; alpha = alpha / (2.0f * a); }
+  return true;
+}
+
+__device__ __forceinline__ void IntersectObject(const DevObject& ob, int i, V3 o, V3 d, HitRec& best) {
+  const V3 A = ld3(ob.a);
+  if (ob.kind == PRIM_TRIANGLE) {                       // primitive_triangle.cc:97-128
+    const V3 E1 = ld3(ob.e1), E2 = ld3(ob.e2);
+    const V3 P = Cross(d, E2);
+    const float det = Dot(P, E1);
+    const V3 T = o - A;
+    const float u = Dot(P, T) / det;
+    if (!(u > 1.0f || u < 0.0f)) {
+      const V3 Q = Cross(T, E1);
+      const float v = Dot(Q, d) / det;
+      if (!(v > 1.0f || v < 0.0f) && !(u + v > 1.0f)) {
+        const float t = Dot(Q, E2) / det;
+        if (!(t <= AMBER_KEPS) && IsFinite(t) && t < best.t) { best.t = t; best.u = u; best.v = v; best.idx = i; }
+      }
+    }
+  } else if (ob.kind == PRIM_SPHERE) {                  // primitive_sphere.cc:75-107
+    const V3 co = A - o;
+    const float b = -2.0f * Dot(co, d);
+    const float c = SquaredLength(co) - ob.radius * ob.radius;
+    float alpha, beta;
+    if (SolveQuadratic(1.0f, b, c, alpha, beta)) {
+      float t;
+      bool ok = true;
+      if (alpha > AMBER_KEPS) t = alpha; else if (beta > AMBER_KEPS) t = beta; else { ok = false; t = 0.f; }
+      if (ok && IsFinite(t) && t < best.t) { best.t = t; best.idx = i; }
+    }
+  } else if (ob.kind == PRIM_DISK) {                    // primitive_disk.cc:94-114
+    const V3 N = ld3(ob.e1);
+    const float cos_theta = Dot(d, N);
+    if (!(cos_theta == 0.0f)) {
+      const float t = Dot(A - o, N) / cos_theta;
+      if (!(t <= AMBER_KEPS)) {
+        const float sq = SquaredLength(o + t * d - A);
+        if (!(sq > ob.radius * ob.radius) && IsFinite(t) && t < best.t) { best.t = t; best.idx = i; }
+      }
+    }
+  } else {                                              // primitive_cylinder.cc:100-142
+    const V3 N = ld3(ob.e1);
+    const V3 OC = A - o;
+    const V3 uu = d - Dot(d, N) * N;
+    const V3 vv = OC - Dot(OC, N) * N;
+    const float a = SquaredLength(uu);
+    const float b = -2.0f * Dot(uu, vv);
+    const float c = SquaredLength(vv) - ob.radius * ob.radius;
+    float alpha, beta;
+    if (SolveQuadratic(a, b, c, alpha, beta)) {
+      bool ok = false; float t = 0.f;
+      if (alpha > AMBER_KEPS) {
+        const float h = Dot(alpha * d - OC, N);
+        if (h >= 0.0f && h <= ob.height) { ok = true; t = alpha; }
+      }
+      if (!ok && beta > AMBER_KEPS) {
+        const float h = Dot(beta * d - OC, N);
+        if (h >= 0.0f && h <= ob.height) { ok = true; t = beta; }
+      }
+      if (ok && IsFinite(t) && t < best.t) { best.t = t; best.idx = i; }
+    }
+  }
+}
+
+__device__ __forceinline__ void ClosestHitList(const DevScene& sc, V3 o, V3 d, HitRec& best) {
+  best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1;   // Acceleration::Cast(ray, FLT_MAX)
+  const int n = static_cast<int>(sc.n_objects);
+  for (int i = 0; i < n; ++i) {
+    const DevObject& ob = sc.objects[i];
+    IntersectObject(ob, i, o, d, best);
+  }
+}
+
+// position / normal of the winning hit, evaluated exactly as the reference's Intersect() does
+__device__ __forceinline__ void ResolveHit(const DevScene& sc, const HitRec& h, V3 o, V3 d, V3& pos, V3& normal, uint32_t& material) {
+  const DevObject* ob = sc.objects + h.idx;
+  const uint32_t kind = ob->kind;
+  material = ob->material;
+  const V3 A = ld3(ob->a);
+  if (kind == PRIM_TRIANGLE) {
+    pos = A + h.u * ld3(ob->e1) + h.v * ld3(ob->e2);     // primitive_triangle.cc:127
+    normal = ld3(ob->n);
+  } else if (kind == PRIM_SPHERE) {
+    pos = o + h.t * d;                                   // primitive_sphere.cc:91-95
+    normal = Normalize(o + h.t * d - A);
+  } else if (kind == PRIM_DISK) {
+    pos = o + h.t * d; normal = ld3(ob->e1);
+  } else {
+    const V3 N = ld3(ob->e1);
+    const float hh = Dot(h.t * d - (A - o), N);
+    pos = o + h.t * d;
+    normal = Normalize(o + h.t * d - A - hh * N);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// materials (src/amber/scene/material_*.cc)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ V3 PerfectReflection(V3 incident, V3 normal, float signed_cos) {   // geometry.h:38-47
+  return (2.0f * signed_cos) * normal - incident;
+}
+__device__ __forceinline__ V3 HemispherePSA(V3 w, uint64_t& rng) {          // sampling.h:234-265
+  V3 u, v; OrthonormalBasis(w, u, v);
+  const float r0 = Uniform(rng);
+  const float r1 = Uniform(rng);
+  const float cos_theta = Sqrt(r0);
+  const float sin_theta = Sqrt(1.0f - r0);
+  const float phi = 2.0f * 3.14159274f * r1;
+  float sp, cp; SinCos(phi, sp, cp);
+  return u * sin_theta * cp + v * sin_theta * sp + w * cos_theta;
+}
+__device__ __forceinline__ V3 CosinePower(V3 w, float exponent, uint64_t& rng) {   // sampling.h:267-300
+  V3 u, v; OrthonormalBasis(w, u, v);
+  const float r0 = Uniform(rng);
+  const float r1 = Uniform(rng);
+  const float cos_theta = Pow(r0, 1.0f / (exponent + 1.0f));
+  const float sin_theta = Sqrt(1.0f - cos_theta * cos_theta);
+  const float phi = 2.0f * 3.14159274f * r1;
+  float sp, cp; SinCos(phi, sp, cp);
+  return u * sin_theta * cp + v * sin_theta * sp + w * cos_theta;
+}
+
+// Scene::Radiance -> DiffuseLight::Radiance (material_diffuse_light.h:127-139)
+__device__ __forceinline__ V3 Radiance(const DevMaterial& m, V3 normal, V3 dir_out) {
+  if (m.kind != MAT_DIFFUSE_LIGHT) return v3(0.f, 0.f, 0.f);
+  if (Dot(dir_out, normal) <= 0.0f) return v3(0.f, 0.f, 0.f);
+  return ld3(m.rho);
+}
+
+// Scene::SampleLight -> Material::SampleLight (+ rho forwarders, material_basic.h:233-245, 327-338)
+__device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 dir_out, uint64_t& rng, V3& dir_in, V3& weight) {
+  const V3 rho = ld3(m.rho);
+  const uint32_t kind = m.kind;
+  if (kind == MAT_LAMBERTIAN) {                          // material_lambertian.cc:61-70
+    const V3 w = Dot(dir_out, normal) > 0.0f ? normal : -normal;
+    dir_in = HemispherePSA(w, rng);
+    weight = 1.0f * rho;
+  } else if (kind == MAT_PHONG) {                        // material_phong.cc:81-106
+    const float signed_cos_o = Dot(dir_out, normal);
+    const V3 refl = PerfectReflection(dir_out, normal, signed_cos_o);
+    for (;;) {
+      const V3 di = CosinePower(refl, m.param, rng);
+      const float signed_cos_i = Dot(di, normal);
+      if (signed_cos_o * signed_cos_i <= 0.0f) continue;
+      dir_in = di;
+      weight = ((m.param + 2.0f) / (m.param + 1.0f) * Abs(signed_cos_i)) * rho;
+      break;
+    }
+  } else if (kind == MAT_SPECULAR) {                     // material_specular.cc:62-70
+    dir_in = PerfectReflection(dir_out, normal, Dot(dir_out, normal));
+    weight = 1.0f * rho;
+  } else if (kind == MAT_REFRACTION) {                   // material_refraction.cc:177-220
+    const float signed_cos_alpha = Dot(dir_out, normal);
+    const float ior = signed_cos_alpha > 0.0f ? 1.0f / m.param : m.param;
+    const float squared_cos_beta = 1.0f - (1.0f - signed_cos_alpha * signed_cos_alpha) * (ior * ior);
+    const V3 dir_r = PerfectReflection(dir_out, normal, signed_cos_alpha);
+    if (squared_cos_beta < 0.0f) {
+      dir_in = dir_r; weight = 1.0f * rho;
+    } else {
+      const float cos_alpha = Abs(signed_cos_alpha);
+      const float cos_beta = Sqrt(squared_cos_beta);
+      const V3 dir_t = (-ior) * dir_out + ((signed_cos_alpha < 0.0f ? 1.0f : -1.0f) * cos_beta + ior * signed_cos_alpha) * normal;
+      // Schlick (material_refraction.cc:271-275): r0 + (1 - r0) * pow(1 - cos, 5) evaluated in double
+      const float rho_r = static_cast<float>(static_cast<double>(m.r0) + static_cast<double>(1.0f - m.r0) * Pow5(1.0f - cos_alpha));
+      const float rho_t = (1.0f - rho_r) * (ior * ior);
+      const float rho_s = rho_r + rho_t;
+      const float p_r = (rho_r / rho_s + 0.5f) / 2.0f;
+      const float p_t = (rho_t / rho_s + 0.5f) / 2.0f;
+      if (Uniform(rng) < p_r) { dir_in = dir_r; weight = (rho_r / p_r) * rho; }
+      else { dir_in = dir_t; weight = (rho_t / p_t) * rho; }
+    }
+  } else if (kind == MAT_EYE) {                          // material_eye.h:146-155
+    dir_in = -dir_out; weight = v3(1.f, 1.f, 1.f);
+  } else {                                               // DiffuseLight: Scatter() (material_diffuse_light.h:185-194)
+    dir_in = v3(0.f, 0.f, 0.f); weight = v3(0.f, 0.f, 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// eye ray: BasicThin::GenerateRay (lens_thin.cc:70-107) + Sensor::PixelBound::Uniform
+// (sensor.cc:111-120, jitter draw order Y then X -- the g++ order the reference outputs were made with)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void GenerateEyeRay(const DevScene& sc, uint32_t px, uint32_t py, uint64_t& rng,
+                                               V3& origin, V3& dir, float& weight) {
+  const DevLens& L = sc.lens;
+  const float fpos = __builtin_floorf(Uniform(rng) * L.n_blades_f);
+  uint32_t pos = static_cast<uint32_t>(fpos);
+  if (pos > L.n_blades - 1) pos = L.n_blades - 1;
+  const DevBlade* bl = sc.blades + pos;
+  float u = Uniform(rng);
+  float v = Uniform(rng);
+  if (u + v >= 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+  const V3 ap_origin = (1.0f - u - v) * ld3(bl->v0) + u * ld3(bl->v1) + v * ld3(bl->v2);   // primitive_triangle.cc:136-150
+  const V3 aperture_point = MatMul(L.local_, ap_origin - ld3(L.origin));
+  const float jy = Uniform(rng);
+  const float jx = Uniform(rng);
+  const float uvx = (static_cast<float>(px) + jx) / sc.sensor.wf;
+  const float uvy = (static_cast<float>(py) + jy) / sc.sensor.hf;
+  const V3 sensor_point = v3((uvx - 0.5f) * sc.sensor.sw, (uvy - 0.5f) * sc.sensor.sh, L.sensor_distance);
+  const V3 direction = Normalize(L.neg_fd_over_sd * sensor_point - aperture_point);
+  const double factor = Pow4(Normalize(sensor_point - aperture_point).z / direction.z);
+  const V3 ray_dir = Normalize(MatMul(L.global_, direction));
+  const V3 dloc = MatMul(L.local_, ray_dir);
+  const float pdf_dir = static_cast<float>(static_cast<double>(L.size_over_area) * L.sd2 / Pow4(dloc.z));
+  origin = ap_origin; dir = ray_dir;
+  weight = static_cast<float>(factor / static_cast<double>(L.p_area) / static_cast<double>(pdf_dir));
+}
+
+// ---------------------------------------------------------------------------------------------
+// one bounce of PathTracing::Thread::Render (algorithm_pt.cc:137-157).
+// Returns true if the path continues (o, d, weight updated), false if it ended.
+// ---------------------------------------------------------------------------------------------
+struct Bounce { int object; float t; V3 pos; V3 weight_before; };
+
+template <bool kTrace>
+__device__ __forceinline__ bool PathStep(const DevScene& sc, V3& o, V3& d, V3& weight, V3& measurement,
+                                         uint64_t& rng, uint32_t& casts, Bounce* trace) {
+  HitRec h;
+  ClosestHitList(sc, o, d, h);
+  casts++;
+  if (h.idx < 0) {
+    if (kTrace) { trace->object = -1; trace->t = __builtin_nanf(""); trace->pos = v3(0, 0, 0); trace->weight_before = v3(0, 0, 0); }
+    return false;
+  }
+  V3 pos, normal; uint32_t mat;
+  ResolveHit(sc, h, o, d, pos, normal, mat);
+  const DevMaterial m = sc.materials[mat];
+  const V3 dir_out = -d;
+  if (kTrace) { trace->object = h.idx; trace->t = h.t; trace->pos = pos; trace->weight_before = weight; }
+  measurement = measurement + weight * Radiance(m, normal, dir_out);        // algorithm_pt.cc:144
+  V3 dir_in, sw;
+  SampleLight(m, normal, dir_out, rng, dir_in, sw);                          // :145-146
+  float p_rr = 0.9375f;                                                      // std::min<real_type>(kRussianRoulette, Max(w)) :148-149
+  const float mw = Max3(sw);
+  if (mw < p_rr) p_rr = mw;
+  if (Uniform(rng) >= p_rr) return false;                                    // :151-153
+  if (sc.max_depth && casts >= sc.max_depth) return false;                   // build-side extension (BASELINE config 5)
+  o = pos; d = dir_in;                                                       // :155 Ray(pos, UnitVector3) -- no renormalisation
+  weight = weight * (sw / p_rr);                                             // :156
+  return true;
+}
+
+}  // namespace amber_dev

@@ -1,0 +1,542 @@
+// pt_engine.hip -- kernels and C ABI (include/amber_hip.h) of the gfx950 path-tracing engine.
+//
+// Engine MEGAKERNEL (this file): one lane owns one pixel of the band and walks its samples in
+// order; a lane whose path ended regenerates the next (pixel, sample) eye ray in place, so every
+// loop iteration of a wave performs one closest-hit query for each lane that still has work
+// (path regeneration, persistent lanes).  Ray / throughput / sampler state never leaves VGPRs;
+// the 25-object Cornell scene is read with wave-uniform indices, i.e. through scalar loads into
+// SGPRs.  HBM traffic is the final 12 B/pixel read-modify-write of the framebuffer only.
+//
+// Replaces: PathTracing<RGB>::Thread::operator() / Render
+//           (/root/reference/src/amber/rendering/algorithm_pt.cc:112-160).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/amber_hip.h"
+#include "pt_device.h"
+
+using namespace amber_dev;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int Fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return Fail(AMBER_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// render kernel
+// ------------------------------------------------------------------------------------------------
+struct RenderArgs {
+  DevScene scene;
+  float* fb;                 // band framebuffer: rows [row_begin,row_end) x width x RGB sums
+  unsigned long long* ray_count;
+  uint64_t hashed_seed;      // SplitMix64(global_seed)
+  uint32_t row_begin, row_end;
+  uint32_t first_sample, n_samples;
+  uint32_t tiles_x;
+};
+
+// One wave = one 8x8 pixel tile; 4 waves per workgroup.
+__global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
+  const DevScene& sc = a.scene;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+  const uint32_t px = tx * 8u + (lane & 7u);
+  const uint32_t py = a.row_begin + ty * 8u + (lane >> 3);
+  const bool valid = px < sc.sensor.w && py < a.row_end;
+  const uint32_t pixel = px + py * sc.sensor.w;          // Image index x + y*W (image.h:116-124)
+
+  uint32_t s = a.first_sample;
+  const uint32_t s_end = valid ? a.first_sample + a.n_samples : a.first_sample;
+  V3 sum = v3(0.f, 0.f, 0.f), meas = v3(0.f, 0.f, 0.f);
+  V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), w = v3(0.f, 0.f, 0.f);
+  uint64_t rng = 1;
+  uint32_t casts = 0, rays = 0;
+  bool alive = false;
+
+  for (;;) {
+    if (!alive) {
+      if (s >= s_end) break;
+      rng = XorShiftSeed(a.hashed_seed, pixel, s);
+      float ew;
+      GenerateEyeRay(sc, px, py, rng, o, d, ew);
+      w = v3(ew, ew, ew);                                 // Leading<RGB>(.., Radiant(weight)) lens_basic.h:139-144
+      meas = v3(0.f, 0.f, 0.f);
+      casts = 0;
+      alive = true;
+      ++s;
+    }
+    alive = PathStep<false>(sc, o, d, w, meas, rng, casts, nullptr);
+    ++rays;
+    if (!alive) sum = sum + meas;                         // per-pixel sequential sum over samples
+  }
+
+  if (valid) {
+    float* p = a.fb + (static_cast<size_t>(py - a.row_begin) * sc.sensor.w + px) * 3u;
+    p[0] += sum.x; p[1] += sum.y; p[2] += sum.z;
+  }
+  // one atomic per wave for the ray counter
+  unsigned long long r = rays;
+  for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
+  if (lane == 0 && r) atomicAdd(a.ray_count, r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// known-answer kernels (same device functions)
+// ------------------------------------------------------------------------------------------------
+__global__ void kat_cast_kernel(const DevScene sc, uint32_t n, const float* org, const float* dir,
+                                int32_t* out_obj, float* out_t, float* out_pos, float* out_n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t k = i < n ? i : n - 1;      // keep the object loop wave-uniform for every lane
+  const V3 o = ld3(org + 3 * k), d = ld3(dir + 3 * k);
+  HitRec h;
+  ClosestHitList(sc, o, d, h);
+  if (i >= n) return;
+  out_obj[i] = h.idx;
+  if (h.idx < 0) {
+    out_t[i] = __builtin_nanf("");
+    for (int c = 0; c < 3; c++) { out_pos[3 * i + c] = 0.f; out_n[3 * i + c] = 0.f; }
+    return;
+  }
+  V3 pos, nrm; uint32_t mat;
+  ResolveHit(sc, h, o, d, pos, nrm, mat);
+  out_t[i] = h.t;
+  out_pos[3 * i] = pos.x; out_pos[3 * i + 1] = pos.y; out_pos[3 * i + 2] = pos.z;
+  out_n[3 * i] = nrm.x; out_n[3 * i + 1] = nrm.y; out_n[3 * i + 2] = nrm.z;
+}
+
+__global__ void kat_sample_kernel(const DevScene sc, uint32_t n, const uint32_t* material, const float* normals,
+                                  const float* dirs_out, uint64_t* rng_state, float* out_dir, float* out_w) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const DevMaterial m = sc.materials[material[i]];
+  uint64_t rng = rng_state[i];
+  V3 di, w;
+  SampleLight(m, ld3(normals + 3 * i), ld3(dirs_out + 3 * i), rng, di, w);
+  rng_state[i] = rng;
+  out_dir[3 * i] = di.x; out_dir[3 * i + 1] = di.y; out_dir[3 * i + 2] = di.z;
+  out_w[3 * i] = w.x; out_w[3 * i + 1] = w.y; out_w[3 * i + 2] = w.z;
+}
+
+__global__ void kat_eye_kernel(const DevScene sc, uint64_t hashed_seed, uint32_t n, const uint32_t* pixel,
+                               const uint32_t* sample, float* out7) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t rng = XorShiftSeed(hashed_seed, pixel[i], sample[i]);
+  V3 o, d; float w;
+  GenerateEyeRay(sc, pixel[i] % sc.sensor.w, pixel[i] / sc.sensor.w, rng, o, d, w);
+  float* p = out7 + 7 * i;
+  p[0] = o.x; p[1] = o.y; p[2] = o.z; p[3] = d.x; p[4] = d.y; p[5] = d.z; p[6] = w;
+}
+
+__global__ void kat_trace_kernel(const DevScene sc, uint64_t hashed_seed, uint32_t n, const uint32_t* pixel,
+                                 const uint32_t* sample, uint32_t max_bounces, uint32_t* out_records, uint32_t* out_casts) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t k = i < n ? i : n - 1;
+  uint64_t rng = XorShiftSeed(hashed_seed, pixel[k], sample[k]);
+  V3 o, d; float ew;
+  GenerateEyeRay(sc, pixel[k] % sc.sensor.w, pixel[k] / sc.sensor.w, rng, o, d, ew);
+  V3 w = v3(ew, ew, ew), meas = v3(0.f, 0.f, 0.f);
+  uint32_t casts = 0;
+  bool alive = true;
+  // all lanes iterate together so that the scene loop stays wave-uniform; finished lanes idle
+  while (__any(alive)) {
+    if (alive) {
+      Bounce b;
+      alive = PathStep<true>(sc, o, d, w, meas, rng, casts, &b);
+      if (i < n && casts <= max_bounces) {
+        uint32_t* r = out_records + (static_cast<size_t>(i) * max_bounces + (casts - 1)) * 11u;
+        r[0] = static_cast<uint32_t>(b.object);
+        r[1] = __float_as_uint(b.t);
+        r[2] = __float_as_uint(b.pos.x); r[3] = __float_as_uint(b.pos.y); r[4] = __float_as_uint(b.pos.z);
+        r[5] = __float_as_uint(b.weight_before.x); r[6] = __float_as_uint(b.weight_before.y); r[7] = __float_as_uint(b.weight_before.z);
+        r[8] = __float_as_uint(meas.x); r[9] = __float_as_uint(meas.y); r[10] = __float_as_uint(meas.z);
+      }
+    }
+  }
+  if (i < n) out_casts[i] = casts;
+}
+
+__global__ void kat_math_kernel(int mode, uint32_t n, const float* x, float* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (mode == 0) { float s, c; SinCos(x[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; }
+  else out[i] = Pow(x[2 * i], x[2 * i + 1]);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+struct amber_hip_pt {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  DevScene scene{};
+  DevObject* d_objects = nullptr;
+  DevMaterial* d_materials = nullptr;
+  DevBlade* d_blades = nullptr;
+  float* d_fb = nullptr;
+  unsigned long long* d_rays = nullptr;
+  uint32_t row_begin = 0, row_end = 0;
+  uint64_t seed = 0, hashed_seed = 0;
+  uint32_t engine = AMBER_ENGINE_MEGAKERNEL;
+  uint32_t n_materials = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per timed launch
+  size_t events_used = 0;
+};
+
+namespace {
+
+uint64_t HostSplitMix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, (n ? n : 1) * sizeof(T)); }
+};
+
+int ValidateScene(const AmberFlatScene* s, const AmberSensor* sensor) {
+  if (!s || !sensor) return Fail(AMBER_EINVAL, "null scene or sensor");
+  if (!s->objects || s->n_objects == 0) return Fail(AMBER_EINVAL, "scene has no objects");
+  if (!s->materials || s->n_materials == 0) return Fail(AMBER_EINVAL, "scene has no materials");
+  if (sensor->width == 0 || sensor->height == 0) return Fail(AMBER_EINVAL, "empty sensor");
+  if (static_cast<uint64_t>(sensor->width) * sensor->height >= (1ull << 32)) return Fail(AMBER_EINVAL, "sensor too large");
+  for (uint32_t i = 0; i < s->n_objects; i++) {
+    if (s->objects[i].kind > AMBER_PRIM_CYLINDER) return Fail(AMBER_EINVAL, "object " + std::to_string(i) + ": unknown primitive kind");
+    if (s->objects[i].material >= s->n_materials) return Fail(AMBER_EINVAL, "object " + std::to_string(i) + ": material index out of range");
+  }
+  for (uint32_t i = 0; i < s->n_materials; i++)
+    if (s->materials[i].kind > AMBER_MAT_EYE) return Fail(AMBER_EINVAL, "material " + std::to_string(i) + ": unknown kind");
+  const AmberFlatThinLens& L = s->lens;
+  if (L.n_blades == 0) return Fail(AMBER_EINVAL, "lens has no aperture blades");
+  if (static_cast<uint64_t>(L.first_blade_object) + L.n_blades > s->n_objects) return Fail(AMBER_EINVAL, "aperture blade objects out of range");
+  for (uint32_t i = 0; i < L.n_blades; i++)
+    if (s->objects[L.first_blade_object + i].kind != AMBER_PRIM_TRIANGLE) return Fail(AMBER_EINVAL, "aperture blade is not a triangle");
+  return AMBER_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* amber_hip_last_error(void) { return g_last_error.c_str(); }
+int amber_hip_abi_version(void) { return AMBER_HIP_ABI_VERSION; }
+int amber_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, const AmberPtParams* params, amber_hip_pt** out) {
+  if (!out || !params) return Fail(AMBER_EINVAL, "null argument");
+  *out = nullptr;
+  int rc = ValidateScene(s, sensor);
+  if (rc != AMBER_OK) return rc;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return Fail(AMBER_ENODEVICE, "no HIP device available (this engine has no CPU fallback)");
+  if (params->device < 0 || params->device >= n_dev) return Fail(AMBER_ENODEVICE, "device ordinal out of range");
+  uint32_t rb = params->row_begin, re = params->row_end;
+  if (rb == 0 && re == 0) re = sensor->height;
+  if (rb >= re || re > sensor->height) return Fail(AMBER_EINVAL, "bad row band");
+  if (params->engine != AMBER_ENGINE_AUTO && params->engine != AMBER_ENGINE_MEGAKERNEL)
+    return Fail(AMBER_EINVAL, "engine not available in this build");
+
+  HIP_TRY(hipSetDevice(params->device));
+  auto* h = new amber_hip_pt();
+  h->device = params->device;
+  h->row_begin = rb; h->row_end = re;
+  h->seed = params->seed; h->hashed_seed = HostSplitMix64(params->seed);
+  if (params->stream) { h->stream = static_cast<hipStream_t>(params->stream); }
+  else {
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return Fail(AMBER_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    h->own_stream = true;
+  }
+
+  // ---- flatten -> device layout
+  std::vector<DevObject> objs(s->n_objects);
+  for (uint32_t i = 0; i < s->n_objects; i++) {
+    const AmberFlatObject& f = s->objects[i];
+    DevObject& o = objs[i];
+    std::memset(&o, 0, sizeof o);
+    o.kind = f.kind; o.material = f.material;
+    o.a[0] = f.p[0]; o.a[1] = f.p[1]; o.a[2] = f.p[2];
+    if (f.kind == AMBER_PRIM_TRIANGLE) {
+      // E1 = v1 - v0, E2 = v2 - v0 (primitive_triangle.cc:100-101): same binary32 subtraction the
+      // reference performs per intersection, hoisted to scene upload.
+      for (int c = 0; c < 3; c++) {
+        volatile float e1 = f.p[3 + c] - f.p[c];
+        volatile float e2 = f.p[6 + c] - f.p[c];
+        o.e1[c] = e1; o.e2[c] = e2; o.n[c] = f.p[9 + c];
+      }
+    } else if (f.kind == AMBER_PRIM_SPHERE) {
+      o.radius = f.p[3];
+    } else {
+      o.e1[0] = f.p[3]; o.e1[1] = f.p[4]; o.e1[2] = f.p[5]; o.radius = f.p[6]; o.height = f.p[7];
+    }
+  }
+  std::vector<DevMaterial> mats(s->n_materials);
+  for (uint32_t i = 0; i < s->n_materials; i++) {
+    const AmberFlatMaterial& f = s->materials[i];
+    DevMaterial& m = mats[i];
+    std::memset(&m, 0, sizeof m);
+    m.kind = f.kind; m.rho[0] = f.rho[0]; m.rho[1] = f.rho[1]; m.rho[2] = f.rho[2]; m.param = f.param; m.r0 = f.r0;
+  }
+  const AmberFlatThinLens& L = s->lens;
+  std::vector<DevBlade> blades(L.n_blades);
+  for (uint32_t i = 0; i < L.n_blades; i++) {
+    const AmberFlatObject& f = s->objects[L.first_blade_object + i];
+    for (int c = 0; c < 3; c++) { blades[i].v0[c] = f.p[c]; blades[i].v1[c] = f.p[3 + c]; blades[i].v2[c] = f.p[6 + c]; blades[i].n[c] = f.p[9 + c]; }
+  }
+
+  auto cleanup = [&](int code, const std::string& msg) { amber_hip_pt_destroy(h); return Fail(code, msg); };
+#define HIP_TRY_H(expr)                                                                            \
+  do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cleanup(AMBER_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+  HIP_TRY_H(hipMalloc(&h->d_objects, objs.size() * sizeof(DevObject)));
+  HIP_TRY_H(hipMalloc(&h->d_materials, mats.size() * sizeof(DevMaterial)));
+  HIP_TRY_H(hipMalloc(&h->d_blades, blades.size() * sizeof(DevBlade)));
+  HIP_TRY_H(hipMemcpy(h->d_objects, objs.data(), objs.size() * sizeof(DevObject), hipMemcpyHostToDevice));
+  HIP_TRY_H(hipMemcpy(h->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
+  HIP_TRY_H(hipMemcpy(h->d_blades, blades.data(), blades.size() * sizeof(DevBlade), hipMemcpyHostToDevice));
+  const size_t fb_floats = static_cast<size_t>(re - rb) * sensor->width * 3;
+  HIP_TRY_H(hipMalloc(&h->d_fb, fb_floats * sizeof(float)));
+  HIP_TRY_H(hipMalloc(&h->d_rays, sizeof(unsigned long long)));
+  HIP_TRY_H(hipMemsetAsync(h->d_fb, 0, fb_floats * sizeof(float), h->stream));
+  HIP_TRY_H(hipMemsetAsync(h->d_rays, 0, sizeof(unsigned long long), h->stream));
+
+  DevScene& sc = h->scene;
+  sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades;
+  sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;
+  h->n_materials = s->n_materials;
+  std::memcpy(sc.lens.origin, L.origin, sizeof L.origin);
+  std::memcpy(sc.lens.global_, L.global_, sizeof L.global_);
+  std::memcpy(sc.lens.local_, L.local_, sizeof L.local_);
+  sc.lens.focus_distance = L.focus_distance; sc.lens.sensor_distance = L.sensor_distance; sc.lens.p_area = L.p_area;
+  { volatile float q = -L.focus_distance / L.sensor_distance; sc.lens.neg_fd_over_sd = q; }
+  {
+    // sensor.Size() / sensor.SceneArea(): uint -> float, float*float, float/float (lens_thin.cc:145, sensor.cc:40-50)
+    volatile float size_f = static_cast<float>(static_cast<uint64_t>(sensor->width) * sensor->height);
+    volatile float area = sensor->scene_width * sensor->scene_height;
+    volatile float r = size_f / area;
+    sc.lens.size_over_area = r;
+  }
+  sc.lens.sd2 = static_cast<double>(L.sensor_distance) * static_cast<double>(L.sensor_distance);
+  sc.lens.n_blades = L.n_blades; sc.lens.n_blades_f = static_cast<float>(L.n_blades);
+  sc.sensor.w = sensor->width; sc.sensor.h = sensor->height;
+  sc.sensor.wf = static_cast<float>(sensor->width); sc.sensor.hf = static_cast<float>(sensor->height);
+  sc.sensor.sw = sensor->scene_width; sc.sensor.sh = sensor->scene_height;
+  *out = h;
+  return AMBER_OK;
+}
+
+int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples) {
+  if (!h) return Fail(AMBER_EINVAL, "null handle");
+  if (n_samples == 0) return AMBER_OK;
+  if (static_cast<uint64_t>(first_sample) + n_samples > 0xffffffffull) return Fail(AMBER_EINVAL, "sample index overflow");
+  HIP_TRY(hipSetDevice(h->device));
+  RenderArgs a;
+  a.scene = h->scene; a.fb = h->d_fb; a.ray_count = h->d_rays; a.hashed_seed = h->hashed_seed;
+  a.row_begin = h->row_begin; a.row_end = h->row_end; a.first_sample = first_sample; a.n_samples = n_samples;
+  a.tiles_x = (h->scene.sensor.w + 7) / 8;
+  const uint32_t tiles_y = (h->row_end - h->row_begin + 7) / 8;
+  const uint32_t n_tiles = a.tiles_x * tiles_y;
+  const uint32_t n_blocks = (n_tiles + 3) / 4;
+  if (h->events_used == h->events.size()) {
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    h->events.emplace_back(e0, e1);
+  }
+  auto& ev = h->events[h->events_used++];
+  HIP_TRY(hipEventRecord(ev.first, h->stream));
+  hipLaunchKernelGGL(pt_megakernel, dim3(n_blocks), dim3(256), 0, h->stream, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev.second, h->stream));
+  return AMBER_OK;
+}
+
+int amber_hip_pt_clear(amber_hip_pt* h) {
+  if (!h) return Fail(AMBER_EINVAL, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t fb_floats = static_cast<size_t>(h->row_end - h->row_begin) * h->scene.sensor.w * 3;
+  HIP_TRY(hipMemsetAsync(h->d_fb, 0, fb_floats * sizeof(float), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_rays, 0, sizeof(unsigned long long), h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->events_used = 0;
+  return AMBER_OK;
+}
+
+int amber_hip_pt_sync(amber_hip_pt* h) {
+  if (!h) return Fail(AMBER_EINVAL, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return AMBER_OK;
+}
+
+int amber_hip_pt_download(amber_hip_pt* h, float* rgb_sum, uint64_t* ray_count) {
+  if (!h) return Fail(AMBER_EINVAL, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t fb_floats = static_cast<size_t>(h->row_end - h->row_begin) * h->scene.sensor.w * 3;
+  if (rgb_sum) HIP_TRY(hipMemcpyAsync(rgb_sum, h->d_fb, fb_floats * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  unsigned long long r = 0;
+  HIP_TRY(hipMemcpyAsync(&r, h->d_rays, sizeof r, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (ray_count) *ray_count = r;
+  return AMBER_OK;
+}
+
+int amber_hip_pt_device_framebuffer(amber_hip_pt* h, void** dptr, uint64_t* n_floats) {
+  if (!h || !dptr) return Fail(AMBER_EINVAL, "null argument");
+  *dptr = h->d_fb;
+  if (n_floats) *n_floats = static_cast<uint64_t>(h->row_end - h->row_begin) * h->scene.sensor.w * 3;
+  return AMBER_OK;
+}
+
+int amber_hip_pt_kernel_time(amber_hip_pt* h, uint32_t* n_launches, double* total_ms) {
+  if (!h) return Fail(AMBER_EINVAL, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double tot = 0;
+  for (size_t i = 0; i < h->events_used; i++) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second));
+    tot += ms;
+  }
+  if (n_launches) *n_launches = static_cast<uint32_t>(h->events_used);
+  if (total_ms) *total_ms = tot;
+  return AMBER_OK;
+}
+
+void amber_hip_pt_destroy(amber_hip_pt* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& e : h->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (h->d_objects) (void)hipFree(h->d_objects);
+  if (h->d_materials) (void)hipFree(h->d_materials);
+  if (h->d_blades) (void)hipFree(h->d_blades);
+  if (h->d_fb) (void)hipFree(h->d_fb);
+  if (h->d_rays) (void)hipFree(h->d_rays);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+// ---- KAT entry points -----------------------------------------------------------------------------
+int amber_hip_kat_cast(amber_hip_pt* h, uint32_t n, const float* origins, const float* dirs,
+                       int32_t* out_object, float* out_t, float* out_pos, float* out_normal) {
+  if (!h || !origins || !dirs || !out_object || !out_t || !out_pos || !out_normal) return Fail(AMBER_EINVAL, "null argument");
+  if (n == 0) return AMBER_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  DevBuf<float> d_o, d_d, d_t, d_p, d_n; DevBuf<int32_t> d_i;
+  HIP_TRY(d_o.alloc(3 * n)); HIP_TRY(d_d.alloc(3 * n)); HIP_TRY(d_t.alloc(n)); HIP_TRY(d_p.alloc(3 * n)); HIP_TRY(d_n.alloc(3 * n)); HIP_TRY(d_i.alloc(n));
+  HIP_TRY(hipMemcpy(d_o.p, origins, 3ull * n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_d.p, dirs, 3ull * n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(kat_cast_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out_object, d_i.p, 4ull * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_t, d_t.p, 4ull * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_pos, d_p.p, 12ull * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_normal, d_n.p, 12ull * n, hipMemcpyDeviceToHost));
+  return AMBER_OK;
+}
+
+int amber_hip_kat_sample(amber_hip_pt* h, uint32_t n, const uint32_t* material, const float* normals,
+                         const float* dirs_out, uint64_t* rng_state, float* out_dir_in, float* out_weight) {
+  if (!h || !material || !normals || !dirs_out || !rng_state || !out_dir_in || !out_weight) return Fail(AMBER_EINVAL, "null argument");
+  if (n == 0) return AMBER_OK;
+  for (uint32_t i = 0; i < n; i++)
+    if (material[i] >= h->n_materials) return Fail(AMBER_EINVAL, "material index out of range");
+  HIP_TRY(hipSetDevice(h->device));
+  DevBuf<uint32_t> d_m; DevBuf<float> d_n, d_d, d_o, d_w; DevBuf<uint64_t> d_r;
+  HIP_TRY(d_m.alloc(n)); HIP_TRY(d_n.alloc(3 * n)); HIP_TRY(d_d.alloc(3 * n)); HIP_TRY(d_o.alloc(3 * n)); HIP_TRY(d_w.alloc(3 * n)); HIP_TRY(d_r.alloc(n));
+  HIP_TRY(hipMemcpy(d_m.p, material, 4ull * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_n.p, normals, 12ull * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_d.p, dirs_out, 12ull * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_r.p, rng_state, 8ull * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(kat_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_m.p, d_n.p, d_d.p, d_r.p, d_o.p, d_w.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(rng_state, d_r.p, 8ull * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_dir_in, d_o.p, 12ull * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_weight, d_w.p, 12ull * n, hipMemcpyDeviceToHost));
+  return AMBER_OK;
+}
+
+int amber_hip_kat_eye(amber_hip_pt* h, uint32_t n, const uint32_t* pixel, const uint32_t* sample, float* out7) {
+  if (!h || !pixel || !sample || !out7) return Fail(AMBER_EINVAL, "null argument");
+  if (n == 0) return AMBER_OK;
+  const uint32_t npx = h->scene.sensor.w * h->scene.sensor.h;
+  for (uint32_t i = 0; i < n; i++) if (pixel[i] >= npx) return Fail(AMBER_EINVAL, "pixel index out of range");
+  HIP_TRY(hipSetDevice(h->device));
+  DevBuf<uint32_t> d_p, d_s; DevBuf<float> d_o;
+  HIP_TRY(d_p.alloc(n)); HIP_TRY(d_s.alloc(n)); HIP_TRY(d_o.alloc(7 * n));
+  HIP_TRY(hipMemcpy(d_p.p, pixel, 4ull * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_s.p, sample, 4ull * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(kat_eye_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, d_o.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out7, d_o.p, 28ull * n, hipMemcpyDeviceToHost));
+  return AMBER_OK;
+}
+
+int amber_hip_kat_trace(amber_hip_pt* h, uint32_t n, const uint32_t* pixel, const uint32_t* sample,
+                        uint32_t max_bounces, uint32_t* out_records, uint32_t* out_casts) {
+  if (!h || !pixel || !sample || !out_records || !out_casts || max_bounces == 0) return Fail(AMBER_EINVAL, "bad argument");
+  if (n == 0) return AMBER_OK;
+  const uint32_t npx = h->scene.sensor.w * h->scene.sensor.h;
+  for (uint32_t i = 0; i < n; i++) if (pixel[i] >= npx) return Fail(AMBER_EINVAL, "pixel index out of range");
+  HIP_TRY(hipSetDevice(h->device));
+  DevBuf<uint32_t> d_p, d_s, d_r, d_c;
+  const size_t nrec = static_cast<size_t>(n) * max_bounces * 11;
+  HIP_TRY(d_p.alloc(n)); HIP_TRY(d_s.alloc(n)); HIP_TRY(d_r.alloc(nrec)); HIP_TRY(d_c.alloc(n));
+  HIP_TRY(hipMemcpy(d_p.p, pixel, 4ull * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_s.p, sample, 4ull * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemsetAsync(d_r.p, 0, nrec * 4, h->stream));
+  hipLaunchKernelGGL(kat_trace_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out_records, d_r.p, nrec * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_casts, d_c.p, 4ull * n, hipMemcpyDeviceToHost));
+  return AMBER_OK;
+}
+
+int amber_hip_kat_math(int device, int mode, uint32_t n, const float* x, float* out) {
+  if (!x || !out || (mode != 0 && mode != 1)) return Fail(AMBER_EINVAL, "bad argument");
+  if (n == 0) return AMBER_OK;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return Fail(AMBER_ENODEVICE, "no such HIP device");
+  HIP_TRY(hipSetDevice(device));
+  const size_t n_in = mode == 0 ? n : 2ull * n, n_out = mode == 0 ? 2ull * n : n;
+  DevBuf<float> d_x, d_o;
+  HIP_TRY(d_x.alloc(n_in)); HIP_TRY(d_o.alloc(n_out));
+  HIP_TRY(hipMemcpy(d_x.p, x, n_in * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(kat_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, mode, n, d_x.p, d_o.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, d_o.p, n_out * 4, hipMemcpyDeviceToHost));
+  return AMBER_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+/*
+ * amber_hip.h -- C ABI of the MI355X (gfx950) path-tracing engine.
+ *
+ * This is the drop-in boundary for amber's unidirectional path tracer.  The reference side of
+ * the boundary is
+ *     rendering::Algorithm<RGB>::Render(scene, sensor, context)
+ *         /root/reference/include/amber/rendering/algorithm.h:40-45
+ * as implemented by PathTracing<RGB>
+ *         /root/reference/src/amber/rendering/algorithm_pt.cc:82-160.
+ * The reference has no FFI; an integrator inside amber would be a C++ class deriving from
+ * Algorithm<RGB> that flattens the scene and calls the functions below (INTEGRATION.md shows
+ * that adapter; amber_amd/csrc/amber/ holds a complete one).  Plain pointers and sizes only.
+ *
+ * Threading: a handle is owned by ONE host thread at a time (one handle per GPU).
+ * Errors: every int-returning function returns AMBER_OK (0) or a negative AMBER_E* code and
+ * records a message retrievable with amber_hip_last_error() (thread-local).
+ * There is NO CPU fallback: without a usable HIP device amber_hip_pt_create fails with
+ * AMBER_ENODEVICE.
+ */
+#ifndef AMBER_HIP_H
+#define AMBER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMBER_HIP_ABI_VERSION 1
+
+enum {
+  AMBER_OK = 0,
+  AMBER_EINVAL = -1,     /* bad argument / malformed flat scene */
+  AMBER_ENODEVICE = -2,  /* no HIP device / device index out of range */
+  AMBER_EHIP = -3,       /* a HIP runtime call failed (message has hipGetErrorString) */
+  AMBER_ENOMEM = -4
+};
+
+/* ---- flattened scene -------------------------------------------------------------------
+ * Produced by scene::Scene::Flatten() (amber_amd/csrc/amber/scene.h).  Object order is the
+ * scene's insertion order: closest-hit ties are resolved toward the LOWER index, which is the
+ * semantics of the reference's List acceleration (acceleration_list.h:51-68).
+ */
+enum { AMBER_PRIM_TRIANGLE = 0, AMBER_PRIM_SPHERE = 1, AMBER_PRIM_DISK = 2, AMBER_PRIM_CYLINDER = 3 };
+enum {
+  AMBER_MAT_LAMBERTIAN = 0,    /* material_lambertian.cc:61-70   rho = kd               */
+  AMBER_MAT_PHONG = 1,         /* material_phong.cc:81-106       rho = ks, param = exponent */
+  AMBER_MAT_SPECULAR = 2,      /* material_specular.cc:62-70     rho = ks               */
+  AMBER_MAT_REFRACTION = 3,    /* material_refraction.cc:177-220 param = ior, r0 = Fresnel(ior) */
+  AMBER_MAT_DIFFUSE_LIGHT = 4, /* material_diffuse_light.h:127-194 rho = radiance       */
+  AMBER_MAT_EYE = 5            /* material_eye.h:146-155 (aperture pass-through)        */
+};
+
+typedef struct {
+  uint32_t kind;       /* AMBER_PRIM_* */
+  uint32_t material;   /* index into AmberFlatScene.materials */
+  /* triangle: v0[3] v1[3] v2[3] normal[3]   (normal = Normalize(Cross(v1-v0, v2-v0)),
+   *                                          primitive_triangle.cc:59-68, computed by the host)
+   * sphere:   center[3] radius
+   * disk:     center[3] normal[3] radius
+   * cylinder: center[3] normal[3] radius height */
+  float    p[12];
+} AmberFlatObject;
+
+typedef struct {
+  uint32_t kind;       /* AMBER_MAT_* */
+  float    rho[3];
+  float    param;
+  float    r0;
+} AmberFlatMaterial;
+
+/* thin lens, lens_thin.cc:32-57 (all derived values computed by the host object model) */
+typedef struct {
+  float    origin[3];
+  float    global_[9];         /* Matrix3, row-major */
+  float    local_[9];          /* global_.Inverse() */
+  float    focus_distance;
+  float    sensor_distance;    /* 1 / (1/focal_length - 1/focus_distance) */
+  float    p_area;             /* 1 / (blade area * n_blades) */
+  uint32_t n_blades;
+  uint32_t first_blade_object; /* objects[first_blade_object + i] is aperture blade i */
+} AmberFlatThinLens;
+
+typedef struct {
+  const AmberFlatObject*   objects;
+  uint32_t                 n_objects;
+  const AmberFlatMaterial* materials;
+  uint32_t                 n_materials;
+  AmberFlatThinLens        lens;
+} AmberFlatScene;
+
+/* rendering::Sensor, sensor.h:34-92 / application.cc:89-94 */
+typedef struct {
+  uint32_t width, height;
+  float    scene_width, scene_height;
+} AmberSensor;
+
+typedef struct {
+  uint64_t seed;        /* global seed of the per-(pixel,sample) XorShift sampler */
+  uint32_t max_depth;   /* 0 = Russian roulette only (reference behaviour, algorithm_pt.cc:137-157) */
+  int32_t  device;      /* HIP device ordinal */
+  uint32_t row_begin;   /* this handle renders framebuffer rows [row_begin, row_end) -- multi-GPU bands */
+  uint32_t row_end;     /* 0,0 = all rows */
+  void*    stream;      /* hipStream_t to launch on; NULL = a stream owned by the handle */
+  uint32_t engine;      /* AMBER_ENGINE_* */
+  uint32_t reserved;
+} AmberPtParams;
+
+enum {
+  AMBER_ENGINE_AUTO = 0,
+  AMBER_ENGINE_MEGAKERNEL = 1,  /* persistent per-lane path regeneration, scene in scalar registers */
+  AMBER_ENGINE_WAVEFRONT = 2    /* SoA ray streams in HBM, generate/extend/shade kernels, ballot compaction */
+};
+
+typedef struct amber_hip_pt amber_hip_pt;
+
+/* Uploads the flattened scene to HBM and allocates the band framebuffer (zeroed). */
+int  amber_hip_pt_create(const AmberFlatScene* scene, const AmberSensor* sensor,
+                         const AmberPtParams* params, amber_hip_pt** out);
+/* Adds, for every pixel of the band, the sequential f32 sum of the path measurements of samples
+ * [first_sample, first_sample + n_samples) to the device framebuffer.  Asynchronous. */
+int  amber_hip_pt_render_pass(amber_hip_pt*, uint32_t first_sample, uint32_t n_samples);
+/* Zeroes the device framebuffer and the ray counter (asynchronous). */
+int  amber_hip_pt_clear(amber_hip_pt*);
+/* Waits for the handle's stream. */
+int  amber_hip_pt_sync(amber_hip_pt*);
+/* Copies the band framebuffer (rows row_begin..row_end, width*3 floats per row, RGB sums --
+ * NOT divided by the sample count) and the ray count (Scene::Cast calls) to the host.  Synchronises. */
+int  amber_hip_pt_download(amber_hip_pt*, float* rgb_sum, uint64_t* ray_count);
+/* Device pointer of the band framebuffer (float, rows*width*3) for zero-copy hand-off to RCCL. */
+int  amber_hip_pt_device_framebuffer(amber_hip_pt*, void** dptr, uint64_t* n_floats);
+/* Per-launch timing of the dominant kernel, measured with hipEvents on the handle's stream:
+ * number of timed launches since create/clear and their total duration. */
+int  amber_hip_pt_kernel_time(amber_hip_pt*, uint32_t* n_launches, double* total_ms);
+void amber_hip_pt_destroy(amber_hip_pt*);
+
+const char* amber_hip_last_error(void);
+int         amber_hip_abi_version(void);
+int         amber_hip_device_count(void);
+
+/* ---- known-answer entry points (same device functions as the render kernels) --------------
+ * Used by tests/ to compare individual stages against the oracle.  All buffers are HOST
+ * pointers; n items; synchronous. */
+/* closest hit: out_object = object index or -1 */
+int amber_hip_kat_cast(amber_hip_pt*, uint32_t n, const float* origins /*n*3*/, const float* dirs /*n*3*/,
+                       int32_t* out_object, float* out_t, float* out_pos /*n*3*/, float* out_normal /*n*3*/);
+/* material sampling with a per-item XorShift state; returns dir_in, weight and the advanced state */
+int amber_hip_kat_sample(amber_hip_pt*, uint32_t n, const uint32_t* material /*n*/, const float* normals,
+                         const float* dirs_out, uint64_t* rng_state /*n, in/out*/, float* out_dir_in, float* out_weight);
+/* eye rays for (pixel index, sample) pairs: out = origin[3] dir[3] weight */
+int amber_hip_kat_eye(amber_hip_pt*, uint32_t n, const uint32_t* pixel, const uint32_t* sample, float* out7);
+/* full per-path trace: for item i writes up to max_bounces records of
+ * {object(int32 as float bits), t, pos[3], weight[3], measurement[3]} (11 x 4 bytes) and the cast count */
+int amber_hip_kat_trace(amber_hip_pt*, uint32_t n, const uint32_t* pixel, const uint32_t* sample,
+                        uint32_t max_bounces, uint32_t* out_records /*n*max_bounces*11*/, uint32_t* out_casts /*n*/);
+/* portable math on device: mode 0 = sincos(x[i]) -> out[2i], out[2i+1] ; mode 1 = pow(x[2i], x[2i+1]) -> out[i] */
+int amber_hip_kat_math(int device, int mode, uint32_t n, const float* x, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
