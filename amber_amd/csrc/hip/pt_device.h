@@ -75,7 +75,8 @@ __device__ __forceinline__ V3 operator/(V3 v, float s) { return V3{v.x / s, v.y 
 __device__ __forceinline__ V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 __device__ __forceinline__ float Dot(V3 u, V3 v) { return u.x * v.x + u.y * v.y + u.z * v.z; }
 __device__ __forceinline__ float SquaredLength(V3 v) { return Dot(v, v); }
-__device__ __forceinline__ float Sqrt(float x) { return __fsqrt_rn(x); }
+// __builtin_sqrtf lowers to the correctly rounded sequence (v_sqrt_f32 + one-ulp fix-up); __fsqrt_rn does NOT on ROCm 7.2
+__device__ __forceinline__ float Sqrt(float x) { return __builtin_sqrtf(x); }
 __device__ __forceinline__ V3 Normalize(V3 v) { const float l = Sqrt(SquaredLength(v)); return V3{v.x / l, v.y / l, v.z / l}; }
 __device__ __forceinline__ V3 Cross(V3 u, V3 v) {
   return V3{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
