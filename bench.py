@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""bench.py -- Mrays/s of the path-tracing hot path on N GPUs of one node (driver contract in the task prompt).
+
+A "step" is one complete render of BASELINE.json's configs[1]: Cornell box, 1024x1024, 1024 samples per
+pixel (1.07e9 paths, ~2.25e9 rays), i.e. one pass of the hot path over the whole job.  For N > 1 the
+framebuffer rows are split into N bands (strong scaling: the job is fixed), every rank renders its band with
+its own scene replica, and each step ends with the single gather of the band sums to rank 0 (RCCL).
+
+Prints ONE JSON line on rank 0.  `value` = rays of all ranks / max-over-ranks wall time of the K timed
+steps (inputs resident in HBM; barrier + synchronize on both sides).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+BYTES_PER_RAY = 96.0      # algorithmic ray-state bytes per bounce (DESIGN.md "Roofline")
+
+
+def cpu_baseline(width: int, seed: int, budget_s: float = 12.0):
+    """The CPU restatement (oracle, kind "port") on the host cores, reference threading model (rows of whole-image
+    1-spp passes pulled by T threads), on a bounded sample of the SAME workload: full 1024x1024 frame, few spp."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import numpy as np
+    import oracle_binding as O
+
+    cores = os.cpu_count() or 1
+    sc = O.Scene.cornell(O.ACCEL_BVH)          # the reference's own acceleration structure
+    t0 = time.perf_counter()
+    _, cnt = sc.render_xorshift(width, width, seed, 0, 1, math=O.MATH_LIBM, threads=cores)
+    dt1 = time.perf_counter() - t0
+    spp = max(1, min(64, int(budget_s / max(dt1, 1e-3))))
+    t0 = time.perf_counter()
+    _, cnt = sc.render_xorshift(width, width, seed, 1, spp, math=O.MATH_LIBM, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(cnt.casts / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"Cornell {width}x{width} @ {spp} spp of the 1024 ({cnt.casts} rays in {dt:.2f} s), oracle in BVH/libm mode, "
+                      f"{cores} threads; scale linearly in spp"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--spp-per-launch", type=int, default=1024)
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import amber_amd
+    from amber_amd.distributed import band_tensor, gather_bands, partition_rows
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: amber_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W = H = args.width
+    sensor = amber_amd.Sensor.default(W, H)
+    scene = amber_amd.HostScene.cornell_box()                      # etude::CornelBox(0.050, 0.050, 6), application.cc:68-73
+    bands = partition_rows(H, world)
+    y0, y1 = bands[rank]
+    stream = torch.cuda.current_stream().cuda_stream              # launch on torch's stream: ordered with the gather
+    tracer = amber_amd.PathTracer(scene, sensor, seed=args.seed, device=local_rank, rows=(y0, y1), stream=stream)
+    fb = band_tensor(tracer, f"cuda:{local_rank}")
+    launches = [(s, min(args.spp_per_launch, args.spp - s)) for s in range(0, args.spp, args.spp_per_launch)]
+
+    def step():
+        tracer.clear()
+        for first, n in launches:
+            tracer.render_pass(first, n)
+        return gather_bands(fb, bands, W, rank, world)             # the single collective of the job
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    rays_before = tracer.ray_count()                               # clear() in step() resets it; take the last step's count below
+    t0 = time.perf_counter()
+    total_rays_local, kernel_ms, n_launch = 0, 0.0, 0
+    for _ in range(args.steps):
+        img = step()
+        # ray counter and kernel times are read after the step's work is enqueued; download syncs the stream
+        total_rays_local += tracer.ray_count()
+        nl, ms = tracer.kernel_time()
+        kernel_ms += ms; n_launch += nl
+    fence()
+    dt = time.perf_counter() - t0
+
+    t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+    r = torch.tensor([total_rays_local], dtype=torch.int64, device=f"cuda:{local_rank}")
+    k = torch.tensor([kernel_ms / max(n_launch, 1)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+    dt_max, rays, kern_ms = float(t.item()), int(r.item()), float(k.item())
+
+    if rank == 0:
+        rays_per_launch_local = total_rays_local / max(n_launch, 1)
+        achieved = rays_per_launch_local * BYTES_PER_RAY / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/sec + wall-clock, Cornell 1024^2 @1024spp; 1/2/4/8 GPU",
+            "value": round(rays / dt_max / 1e6, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"Cornell box (etude::CornelBox(0.050,0.050,6)) {W}x{H} @ {args.spp} spp, RR-only path tracing, "
+                                   f"per-(pixel,sample) XorShift seed {args.seed}", "rays_per_step": rays // args.steps,
+                       "paths_per_step": W * H * args.spp, "wall_s_per_step": round(dt_max / args.steps, 4),
+                       "parallelism": f"bands{world}", "launches_per_step": len(launches), "engine": "megakernel"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "pt_megakernel", "kernel_ms": round(kern_ms, 3),
+                         "note": "achieved = rays per launch (rank 0) x 96 B algorithmic ray-state bytes / mean launch duration (hipEvents)"},
+        }
+        prof = ROOT / "profiles" / "r01_hbm_traffic.json"
+        if prof.exists():
+            try:
+                out["roofline"]["traffic"] = json.loads(prof.read_text()).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, args.seed)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

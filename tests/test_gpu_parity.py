@@ -1,0 +1,291 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle -- bit-exact.
+
+Everything the engine computes is binary32/binary64 arithmetic in the oracle's operation order with no
+library math on the path (DESIGN.md "Numerics"), so the bar is equality of bits, not a tolerance:
+object indices, hit distances, positions, weights, measurements, images and ray counts.
+The north-star tolerance (per-pixel L2 <= 1e-4 vs the CPU reference on identical seeds) is therefore
+met with 0.
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_binding as O
+from test_host_model import SCENE
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(Path(__file__).parent / "golden" / "oracle_vectors.npz")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def cornell(amber):
+    return amber.HostScene.cornell_box(), O.Scene.cornell(O.ACCEL_LIST)
+
+
+@pytest.fixture(scope="module")
+def generic(amber):
+    return amber.HostScene.create(**SCENE), O.Scene.create(**SCENE)
+
+
+def test_extension_is_loaded_and_device_present(amber):
+    assert amber.library_path().exists()
+    assert amber.device_count() >= 1
+
+
+def test_portable_math_bit_exact(amber, oracle):
+    x = np.concatenate([np.linspace(0, 2 * np.pi, 30001), [0.0, 6.2831855, 1e-8, np.pi / 4, np.pi / 2]]).astype(np.float32)
+    g = amber.kat_math(0, x)
+    s, c = C.c_float(), C.c_float()
+    for i in range(0, len(x), 3):
+        oracle.oracle_sincos(x[i], O.MATH_PORTABLE, C.byref(s), C.byref(c))
+        assert bits(g[i]).tolist() == bits([s.value, c.value]).tolist(), x[i]
+    rng = np.random.default_rng(0)
+    xy = np.stack([rng.random(6000), rng.choice([1 / 257, 1 / 33, 0.5, 1 / 3, 2.0], 6000)], 1).astype(np.float32)
+    xy[:4] = [[0, 0.5], [1, 0.3], [1e-38, 0.25], [0.5, 0]]
+    g = amber.kat_math(1, xy)
+    for i in range(len(xy)):
+        assert bits(g[i]) == bits(oracle.oracle_pow(xy[i, 0], xy[i, 1], O.MATH_PORTABLE)), xy[i]
+
+
+def _check_casts(pt, osc, org, d):
+    obj, t, pos, nrm = pt.kat_cast(org, d)
+    for i in range(len(org)):
+        oi, ot, op, on = osc.cast(org[i], d[i])
+        assert obj[i] == oi, (i, org[i], d[i])
+        if oi >= 0:
+            assert bits(t[i]) == bits(ot) and np.array_equal(bits(pos[i]), bits(op)) and np.array_equal(bits(nrm[i]), bits(on)), i
+    return obj
+
+
+def test_closest_hit_cornell(amber, cornell):
+    hs, osc = cornell
+    pt = amber.PathTracer(hs, amber.Sensor.default(32, 32))
+    rng = np.random.default_rng(11)
+    n = 3000
+    org = rng.uniform(-0.99, 0.99, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    # edge cases: axis-parallel rays (det = 0 for walls), rays along triangle diagonals (u+v = 1), origins on surfaces
+    # (kEPS self-hit rejection), rays grazing the sphere tangent points on the floor, zero direction
+    org[:6] = [[0, 0, 0], [0, 0, 0], [0.5, -1.0, 0.5], [0.4, -1.0, -0.5], [0, 0, 0], [0, 0.5, 0]]
+    d[:6] = [[1, 0, 0], [0, -1, 0], [0, 1, 0], [0, 1, 0], [0.70710678, -0.70710678, 0], [0, 0, 0]]
+    obj = _check_casts(pt, osc, org, d)
+    assert (obj >= 0).mean() > 0.95
+    # golden vectors
+    obj, t, pos, nrm = pt.kat_cast(GOLD["cast_org"], GOLD["cast_dir"])
+    assert np.array_equal(obj, GOLD["cast_obj"])
+    hit = obj >= 0
+    assert np.array_equal(bits(t[hit]), bits(GOLD["cast_t"][hit]))
+    assert np.array_equal(bits(pos[hit]), bits(GOLD["cast_pos"][hit])) and np.array_equal(bits(nrm[hit]), bits(GOLD["cast_n"][hit]))
+
+
+def test_closest_hit_all_primitive_kinds(amber, generic):
+    hs, osc = generic
+    pt = amber.PathTracer(hs, amber.Sensor.default(32, 32))
+    rng = np.random.default_rng(12)
+    n = 3000
+    org = (rng.uniform(-1.5, 1.5, (n, 3)) + [0, 0.3, 0]).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    obj = _check_casts(pt, osc, org, d)
+    kinds = {k for k, *_ in [osc.objects()[i] for i in set(obj[obj >= 0].tolist())]}
+    assert kinds == {0, 1, 2, 3}                                          # triangles, spheres, disk, cylinder all hit
+
+
+def test_eye_rays(amber, cornell):
+    hs, osc = cornell
+    W, H = 80, 56
+    pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=99)
+    px = np.arange(0, W * H, 7, dtype=np.uint32)
+    sm = (px * 2654435761 % 4096).astype(np.uint32)
+    eye = pt.kat_eye(px, sm)
+    for i in range(0, len(px), 5):
+        _, _, e = osc.trace(W, H, 99, int(px[i] % W), int(px[i] // W), int(sm[i]), max_bounces=1)
+        assert np.array_equal(bits(eye[i]), bits(e)), i
+
+
+def test_material_sampling(amber, oracle, generic, cornell):
+    """Every material kind incl. total internal reflection, both refraction branches and multi-try Phong."""
+    for hs, osc in (cornell, generic):
+        pt = amber.PathTracer(hs, amber.Sensor.default(32, 32))
+        _, mats, _ = hs.flatten()
+        rng = np.random.default_rng(21)
+        n = 4000
+        mat = rng.integers(0, len(mats), n).astype(np.uint32)
+        nrm = rng.normal(size=(n, 3)); nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+        do = rng.normal(size=(n, 3)); do = (do / np.linalg.norm(do, axis=1, keepdims=True)).astype(np.float32)
+        do[: n // 4] = (nrm[: n // 4] * 0.05 + do[: n // 4]).astype(np.float32)   # plenty of grazing directions (TIR, Phong rejections)
+        do = (do / np.linalg.norm(do, axis=1, keepdims=True)).astype(np.float32)
+        state = rng.integers(1, 2 ** 63, n).astype(np.uint64)
+        di, w, st = pt.kat_sample(mat, nrm, do, state)
+        kinds_seen, multi_try, tir = set(), 0, 0
+        for i in range(n):
+            m = mats[mat[i]]
+            om = O.OMaterial(m.kind, (C.c_float * 3)(*m.rho), m.param)
+            u = np.zeros(64, np.float64)
+            oracle.oracle_xorshift_uniforms(int(state[i]), 64, u.ctypes.data)
+            odi, ow = (C.c_float * 3)(), (C.c_float * 3)()
+            used = oracle.oracle_sample_material(C.byref(om), O.f3(nrm[i]), O.f3(do[i]), u.ctypes.data_as(C.POINTER(C.c_double)), 64,
+                                                 O.MATH_PORTABLE, odi, ow)
+            assert used <= 64
+            assert np.array_equal(bits(di[i]), bits(list(odi))) and np.array_equal(bits(w[i]), bits(list(ow))), (i, m.kind)
+            # the device consumed exactly as many draws as the oracle
+            s = int(state[i])
+            for _ in range(used):
+                s ^= (s << 13) & 0xFFFFFFFFFFFFFFFF; s ^= s >> 7; s ^= (s << 17) & 0xFFFFFFFFFFFFFFFF
+            assert s == int(st[i])
+            kinds_seen.add(m.kind)
+            multi_try += (m.kind == 1 and used > 2)
+            tir += (m.kind == 3 and used == 0)
+        assert kinds_seen >= {0, 1, 2, 3, 4}
+        assert multi_try > 0 and tir > 0
+
+
+def _compare_traces(pt, osc, W, H, seed, px, sm, maxb=12, max_depth=0):
+    rec, casts = pt.kat_trace(px, sm, maxb)
+    for i in range(len(px)):
+        n, orec, _ = osc.trace(W, H, seed, int(px[i] % W), int(px[i] // W), int(sm[i]), max_depth=max_depth, max_bounces=maxb)
+        assert n == casts[i], i
+        for b in range(min(n, maxb)):
+            assert np.int32(rec[i, b, 0]) == orec[b].object
+            if orec[b].object >= 0:
+                exp = np.array([orec[b].t, *orec[b].pos, *orec[b].weight, *orec[b].measurement], np.float32)
+                assert np.array_equal(rec[i, b, 1:], exp.view(np.uint32)), (i, b)
+    return casts
+
+
+def test_path_traces(amber, cornell, generic):
+    for (hs, osc), (W, H) in ((cornell, (72, 40)), (generic, (48, 48))):
+        pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=4242)
+        rng = np.random.default_rng(31)
+        px = rng.integers(0, W * H, 600).astype(np.uint32)
+        sm = rng.integers(0, 2 ** 20, 600).astype(np.uint32)
+        casts = _compare_traces(pt, osc, W, H, 4242, px, sm)
+        assert casts.max() >= 6 and 1.5 < casts.mean() < 4.5
+
+
+def test_path_traces_golden(amber, cornell):
+    hs, _ = cornell
+    W, H, seed = int(GOLD["W"]), int(GOLD["H"]), int(GOLD["seed"])
+    pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=seed)
+    rec, casts = pt.kat_trace(GOLD["trace_px"], GOLD["trace_sample"], GOLD["trace_rec"].shape[1])
+    assert np.array_equal(casts, GOLD["trace_casts"])
+    assert np.array_equal(rec, GOLD["trace_rec"])
+    assert np.array_equal(bits(pt.kat_eye(GOLD["trace_px"], GOLD["trace_sample"])), bits(GOLD["trace_eye"]))
+    pt = amber.PathTracer(hs, amber.Sensor.default(48, 48), seed=seed)
+    pt.render_pass(0, 8)
+    img, rays = pt.download()
+    assert rays == int(GOLD["img48_casts"]) and np.array_equal(bits(img), bits(GOLD["img48_sum"]))
+
+
+def test_max_depth_extension(amber, cornell):
+    hs, osc = cornell
+    W = H = 40
+    pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=5, max_depth=3)
+    px = np.arange(0, W * H, 3, dtype=np.uint32); sm = (px % 11).astype(np.uint32)
+    casts = _compare_traces(pt, osc, W, H, 5, px, sm, max_depth=3)
+    assert casts.max() == 3
+
+
+@pytest.mark.parametrize("which,W,H,passes", [("cornell", 128, 96, [(0, 5), (5, 11)]), ("cornell", 67, 45, [(0, 7)]), ("generic", 64, 64, [(3, 6), (9, 2)])])
+def test_render_images_bit_exact(amber, cornell, generic, which, W, H, passes):
+    """Whole-image parity incl. ragged sizes (not multiples of the 8x8 tile), several passes and sample offsets."""
+    hs, osc = cornell if which == "cornell" else generic
+    pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=2026)
+    ref = np.zeros((H, W, 3), np.float32)
+    total = 0
+    for first, n in passes:
+        pt.render_pass(first, n)
+        _, c = osc.render_xorshift(W, H, 2026, first, n, out=ref)
+        total += c.casts
+    img, rays = pt.download()
+    assert rays == total
+    assert np.array_equal(bits(img), bits(ref))
+    assert (img > 0).any()
+    # clear() resets both the framebuffer and the ray counter; a re-render reproduces the image
+    pt.clear()
+    z, r0 = pt.download()
+    assert r0 == 0 and not z.any()
+    for first, n in passes:
+        pt.render_pass(first, n)
+    again, _ = pt.download()
+    assert np.array_equal(bits(again), bits(img))
+
+
+def test_bands_tile_the_image(amber, cornell):
+    """Band handles (multi-GPU sharding unit) reproduce the single-handle image exactly, ray counts add up."""
+    from amber_amd.distributed import partition_rows
+    hs, _ = cornell
+    W, H, spp = 96, 100, 6
+    sn = amber.Sensor.default(W, H)
+    full = amber.PathTracer(hs, sn, seed=8)
+    full.render_pass(0, spp)
+    img, rays = full.download()
+    out, tot = np.zeros_like(img), 0
+    for y0, y1 in partition_rows(H, 3):
+        band = amber.PathTracer(hs, sn, seed=8, rows=(y0, y1))
+        band.render_pass(0, spp)
+        b, r = band.download()
+        assert b.shape == (y1 - y0, W, 3)
+        out[y0:y1] = b; tot += r
+    assert tot == rays and np.array_equal(bits(out), bits(img))
+
+
+def test_algorithm_render_honours_the_context_contract(amber, cornell):
+    """Algorithm<RGB>::Render through cli::Context(1, spp): spp passes, mean = sum / passes (accumulator.h:88-95)."""
+    hs, osc = cornell
+    W, H, spp = 64, 48, 10
+    img, st = hs.render(amber.Sensor.default(W, H), spp, seed=77, samples_per_launch=4)    # launches of 4, 4, 2 passes
+    assert st["passes"] == spp and st["launches"] == 3
+    ref = np.zeros((H, W, 3), np.float32)
+    casts = 0
+    for first, n in [(0, 4), (4, 4), (8, 2)]:
+        _, c = osc.render_xorshift(W, H, 77, first, n, out=ref)
+        casts += c.casts
+    assert st["rays"] == casts
+    assert np.array_equal(bits(img), bits(ref / np.float32(spp)))
+
+
+def test_full_size_properties(amber, cornell):
+    """BASELINE config 2 geometry (1024x1024) at a reduced sample count: properties that need no oracle run.
+    determinism, band invariance, rays-per-path and hit statistics of the reference scene."""
+    hs, _ = cornell
+    W = H = 1024
+    spp = 32
+    sn = amber.Sensor.default(W, H)
+    a = amber.PathTracer(hs, sn, seed=1)
+    a.render_pass(0, spp)
+    img, rays = a.download()
+    a.clear(); a.render_pass(0, spp)
+    img2, rays2 = a.download()
+    assert rays == rays2 and np.array_equal(bits(img), bits(img2))           # deterministic
+    rpp = rays / (W * H * spp)
+    assert 2.05 < rpp < 2.14                                                 # reference: 2.094 casts per path
+    top = amber.PathTracer(hs, sn, seed=1, rows=(0, 512)); top.render_pass(0, spp)
+    bot = amber.PathTracer(hs, sn, seed=1, rows=(512, 1024)); bot.render_pass(0, spp)
+    (t, rt), (b, rb) = top.download(), bot.download()
+    assert rt + rb == rays and np.array_equal(bits(np.concatenate([t, b])), bits(img))
+    assert np.isfinite(img).all() and (img >= 0).all()
+    lit = (img.max(2) > 0).mean()
+    assert 0.0005 < lit < 0.02                                                # light is hit with probability ~2e-5 per hit
+    # spot-check 64 random pixels of the full-size image against the oracle (same seeds, same sums)
+    osc = O.Scene.cornell(O.ACCEL_LIST)
+    rng = np.random.default_rng(2)
+    for x, y in zip(rng.integers(0, W, 64), rng.integers(0, H, 64)):
+        s = np.zeros(3, np.float32)
+        for k in range(spp):
+            n, rec, _ = osc.trace(W, H, 1, int(x), int(y), k, max_bounces=1)
+            # measurement after the last hit: trace again with a deep buffer only if the path was long
+            if n > 1:
+                n, rec, _ = osc.trace(W, H, 1, int(x), int(y), k, max_bounces=n)
+            last = None
+            for bnc in range(n):
+                if rec[bnc].object >= 0:
+                    last = rec[bnc]
+            if last is not None:
+                s = s + np.array(last.measurement[:], np.float32)
+        assert np.array_equal(bits(img[y, x]), bits(s))

@@ -1,0 +1,131 @@
+"""Host object model, C ABI surface and error behaviour (no GPU needed)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_binding as O
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol(amber):
+    lib = amber.load_library()
+    declared = set()
+    for header in ("amber_hip.h", "amber_host.h"):
+        text = (ROOT / "include" / header).read_text()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(amber_(?:hip|host)_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 20
+    from amber_amd.api import ABI_SYMBOLS
+    assert declared == set(ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.amber_hip_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header(amber):
+    from amber_amd import api
+    assert C.sizeof(api.FlatObject) == 56 and C.sizeof(api.FlatMaterial) == 24
+    assert C.sizeof(api.FlatThinLens) == 4 * (3 + 9 + 9 + 3 + 2)
+    assert C.sizeof(api.Sensor) == 16 and C.sizeof(api.PtParams) == 40
+
+
+def _resolved(objs, mats):
+    out = []
+    for o in objs:
+        m = mats[o.material]
+        out.append((o.kind, tuple(np.array(o.p[:], np.float32).view(np.uint32)), m.kind,
+                    tuple(np.array(m.rho[:], np.float32).view(np.uint32)), np.float32(m.param).view(np.uint32), np.float32(m.r0).view(np.uint32)))
+    return out
+
+
+def test_cornell_box_flattening_equals_the_oracles_scene(amber, oracle):
+    """etude::CornelBox built through the product's Make* factories == the oracle's independent restatement, bit for bit."""
+    objs, mats, lens = amber.HostScene.cornell_box().flatten()
+    osc = O.Scene.cornell(O.ACCEL_LIST)
+    oobjs, omats = osc.objects(), osc.materials()
+    assert len(objs) == len(oobjs) == 25 and lens.n_blades == 6 and lens.first_blade_object == 0
+    got = _resolved(objs, mats)
+    for g, (kind, mat, p, n) in zip(got, oobjs):
+        mk, rho, param, r0 = omats[mat]
+        pp = np.zeros(12, np.float32)
+        if kind == 0:
+            pp[:9], pp[9:] = p, n
+        else:
+            pp[:4] = p[:4]
+        assert g == (kind, tuple(pp.view(np.uint32)), mk, tuple(rho.view(np.uint32)), param.view(np.uint32), r0.view(np.uint32))
+    origin, g_, l_, fd, sd, pa = osc.lens()
+    assert np.array_equal(np.array(lens.origin[:], np.float32), origin)
+    assert np.array_equal(np.array(lens.global_[:], np.float32), g_) and np.array_equal(np.array(lens.local_[:], np.float32), l_)
+    assert (np.float32(lens.focus_distance), np.float32(lens.sensor_distance), np.float32(lens.p_area)) == (fd, sd, pa)
+    # application.cc:69-73 + cornel_box.cc:50-61: sensor distance of the thin lens
+    assert np.float32(lens.sensor_distance) == np.float32(1) / (np.float32(1) / np.float32(0.05) - np.float32(1) / np.float32(4))
+
+
+SCENE = dict(
+    materials=[(4, (30.0, 30.0, 30.0), 0.0), (0, (0.7, 0.6, 0.5), 0.0), (1, (0.9, 0.9, 0.9), 32.0), (2, (0.8, 0.8, 0.8), 0.0), (3, (1.0, 1.0, 1.0), 1.5)],
+    objects=[
+        (2, 0, [0.0, 1.5, 0.0, 0.0, -1.0, 0.0, 0.6]),                      # disk light facing down
+        (0, 1, [-3, -1, -3, 3, -1, 3, 3, -1, -3]), (0, 1, [-3, -1, -3, -3, -1, 3, 3, -1, 3]),   # floor
+        (3, 2, [-0.8, -1.0, 0.0, 0.0, 1.0, 0.0, 0.3, 0.9]),               # phong cylinder
+        (1, 3, [0.7, -0.6, -0.3, 0.4]), (1, 4, [0.0, -0.7, 0.8, 0.3]),    # mirror and glass spheres
+    ],
+    transform=[1, 0, 0, 0, 0, 1, 0, 0.2, 0, 0, 1, 5, 0, 0, 0, 1], focal_length=0.05, focus_distance=5.0, radius=0.02, n_blades=5,
+)
+
+
+def test_generic_scene_with_all_primitive_kinds(amber, oracle):
+    hs = amber.HostScene.create(**SCENE)
+    objs, mats, lens = hs.flatten()
+    osc = O.Scene.create(**SCENE)
+    oobjs, omats = osc.objects(), osc.materials()
+    assert len(objs) == len(oobjs) == 5 + 6 and lens.n_blades == 5
+    for o, (kind, mat, p, n) in zip(objs, oobjs):
+        assert o.kind == kind
+        k = {0: 9, 1: 4, 2: 7, 3: 8}[kind]
+        assert np.array_equal(np.array(o.p[:k], np.float32).view(np.uint32), p[:k].view(np.uint32))
+        if kind == 0:
+            assert np.array_equal(np.array(o.p[9:12], np.float32).view(np.uint32), n.view(np.uint32))
+        m, (mk, rho, param, r0) = mats[o.material], omats[mat]
+        assert (m.kind, np.float32(m.param), np.float32(m.r0)) == (mk, param, r0)
+        assert np.array_equal(np.array(m.rho[:], np.float32), rho)
+
+
+def test_errors_are_loud(amber):
+    lib = amber.load_library()
+    sc = amber.HostScene.cornell_box()
+    if amber.device_count() == 0:
+        with pytest.raises(amber.AmberError, match="no HIP device"):
+            amber.PathTracer(sc, amber.Sensor.default(32, 32))            # no CPU fallback
+    with pytest.raises(amber.AmberError, match="Unknown algorithm"):      # cli::UnknownAlgorithmError, algorithm_factory.h:30-37
+        sc.render(amber.Sensor.default(8, 8), 1, algorithm="bdpt")
+    with pytest.raises(amber.AmberError):
+        amber.HostScene.create(objects=[(0, 7, [0] * 9)], materials=[(0, (1, 1, 1), 0)], transform=SCENE["transform"],
+                               focal_length=0.05, focus_distance=5.0, radius=0.02, n_blades=5)   # material index out of range
+    with pytest.raises(amber.AmberError):
+        amber.HostScene.create(objects=[(9, 0, [0] * 9)], materials=[(0, (1, 1, 1), 0)], transform=SCENE["transform"],
+                               focal_length=0.05, focus_distance=5.0, radius=0.02, n_blades=5)   # unknown primitive
+    # malformed flat scenes are rejected before any device work
+    from amber_amd import api
+    fs = api.FlatSceneC()
+    h = C.c_void_p()
+    p = api.PtParams()
+    s = amber.Sensor.default(8, 8)
+    assert lib.amber_hip_pt_create(C.byref(fs), C.byref(s), C.byref(p), C.byref(h)) == -1
+    assert b"no objects" in lib.amber_hip_last_error()
+    assert lib.amber_hip_pt_render_pass(None, 0, 1) == -1
+
+
+def test_partition_rows():
+    from amber_amd.distributed import partition_rows
+    for h, g in [(1024, 1), (1024, 2), (1024, 8), (2160, 8), (100, 3), (8, 4), (20, 6)]:
+        bands = partition_rows(h, g)
+        assert len(bands) == g and bands[0][0] == 0 and bands[-1][1] == h
+        for (a0, a1), (b0, b1) in zip(bands, bands[1:]):
+            assert a1 == b0 and a0 <= a1
+        assert all(y0 % 8 == 0 for y0, y1 in bands if y1 > y0)
+        rows = [y1 - y0 for y0, y1 in bands]
+        assert max(rows) - min(rows) < 16 or h < 8 * g      # one tile row of slack + a truncated last tile

@@ -1,0 +1,149 @@
+"""Pins the CPU oracle: against the reference's recorded known answers and against itself.
+
+The reference has no tests or golden vectors for this path and cannot be built here, so
+the strongest available pin is the whole-image outputs of the unmodified reference recorded by the survey:
+the oracle's MT-stream / BVH / libm mode must reproduce them bit-for-bit (hash over every f32 of the image
+plus cast and hit counts, i.e. the entire sampler stream stayed in lock-step for 2.2 M casts).
+"""
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_binding as O
+
+KNOWN = json.loads((Path(__file__).parent / "golden" / "reference_known_answers.json").read_text())
+
+
+def test_mt19937_64_known_answers(oracle):
+    n = 10000
+    raw, u, uf = np.zeros(n, np.uint64), np.zeros(n, np.float64), np.zeros(n, np.float32)
+    oracle.oracle_mt_uniforms(5489, n, raw.ctypes.data, u.ctypes.data, uf.ctypes.data)   # default_seed
+    assert int(raw[-1]) == KNOWN["mt19937_64_default_10000th"]          # [rand.predef] known answer
+    oracle.oracle_mt_uniforms(12345, 3, raw.ctypes.data, u.ctypes.data, uf.ctypes.data)
+    assert [int(x) for x in raw[:3]] == KNOWN["mt19937_64_seed12345_first3"]
+    # GenericSampler::operator() (sampling.h:148-154): double(x) * 2^-64, clamped below 1
+    expect = raw[:3].astype(np.float64) * 2.0 ** -64
+    assert np.array_equal(u[:3], np.minimum(expect, np.nextafter(1.0, 0.0)))
+    assert np.array_equal(uf[:3], u[:3].astype(np.float32))             # Uniform<float> = (float)u
+
+
+def test_cornell_bvh_topology(oracle):
+    sc = O.Scene.cornell(O.ACCEL_BVH)
+    nodes, leaves, depth = sc.bvh_stats()
+    assert (nodes, leaves) == (KNOWN["cornell_bvh"]["nodes"], KNOWN["cornell_bvh"]["leaves"])   # root + 2 leaves
+    assert depth == 1
+
+
+@pytest.mark.parametrize("case", KNOWN["renders"], ids=lambda c: f"{c['width']}x{c['height']}@{c['spp']}")
+def test_mt_stream_reproduces_reference_outputs(oracle, case):
+    sc = O.Scene.cornell(O.ACCEL_BVH)
+    img, cnt = sc.render_mt(case["width"], case["height"], 12345, case["spp"], math=O.MATH_LIBM)
+    assert cnt.casts == case["casts"] and cnt.hits == case["hits"]
+    px = img.reshape(-1, 3)
+    assert int((px.max(1) > 0).sum()) == case["nonzero_pixels"]
+    # the survey harness' mean: sum over pixels of the f32 (x+y+z), accumulated in double, / (3*W*H)
+    mean = ((px[:, 0] + px[:, 1]) + px[:, 2]).astype(np.float64).sum() / (3.0 * case["width"] * case["height"])
+    assert f"{mean:.9g}" == f"{case['mean']:.9g}"
+    assert f"{O.survey_hash(img):016x}" == case["hash"]                  # every f32 of the image, bit-for-bit
+
+
+def test_bvh_and_list_agree(oracle):
+    bvh, lst = O.Scene.cornell(O.ACCEL_BVH), O.Scene.cornell(O.ACCEL_LIST)
+    rng = np.random.default_rng(5)
+    n_hit = 0
+    for _ in range(4000):
+        o = rng.uniform(-0.99, 0.99, 3).astype(np.float32)
+        d = rng.normal(size=3); d = (d / np.linalg.norm(d)).astype(np.float32)
+        a, b = bvh.cast(o, d), lst.cast(o, d)
+        assert a[0] == b[0]
+        if a[0] >= 0:
+            n_hit += 1
+            assert a[1].view(np.uint32) == b[1].view(np.uint32) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert n_hit > 3000
+
+
+def test_portable_math_close_to_libm(oracle):
+    s, c = C.c_float(), C.c_float()
+    s2, c2 = C.c_float(), C.c_float()
+    worst = 0.0
+    for phi in np.linspace(0, 2 * np.pi, 20001, dtype=np.float32):
+        oracle.oracle_sincos(phi, O.MATH_PORTABLE, C.byref(s), C.byref(c))
+        oracle.oracle_sincos(phi, O.MATH_LIBM, C.byref(s2), C.byref(c2))
+        worst = max(worst, abs(s.value - s2.value), abs(c.value - c2.value))
+    assert worst <= 1.2e-7                                               # ~1 ulp at magnitude 1
+    rng = np.random.default_rng(3)
+    for x in rng.random(5000).astype(np.float32):
+        a, b = oracle.oracle_pow(x, np.float32(1 / 257), O.MATH_PORTABLE), oracle.oracle_pow(x, np.float32(1 / 257), O.MATH_LIBM)
+        assert abs(a - b) <= 2.5e-7 * b
+    for x, y in [(0.0, 0.5), (1.0, 3.0), (0.25, 0.5), (0.5, 2.0), (1e-30, 0.01), (0.999, 300.0)]:
+        a, b = oracle.oracle_pow(x, y, O.MATH_PORTABLE), oracle.oracle_pow(x, y, O.MATH_LIBM)
+        assert abs(a - b) <= 1e-5 * max(abs(b), 1e-30)
+
+
+def test_xorshift_mode_thread_and_band_invariant(oracle):
+    sc = O.Scene.cornell(O.ACCEL_LIST)
+    a, ca = sc.render_xorshift(40, 24, 9, 0, 6, threads=1)
+    b, cb = sc.render_xorshift(40, 24, 9, 0, 6, threads=5)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ca.casts == cb.casts
+    c = np.zeros_like(a)
+    _, c0 = sc.render_xorshift(40, 24, 9, 0, 6, rows=(0, 8), out=c)
+    _, c1 = sc.render_xorshift(40, 24, 9, 0, 6, rows=(8, 24), out=c)
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32)) and c0.casts + c1.casts == ca.casts
+    # passes are additive in the ray count, and the sum of passes equals one long pass wherever at most one
+    # sample of a pixel is non-zero (always true at this size)
+    d = np.zeros_like(a)
+    _, d0 = sc.render_xorshift(40, 24, 9, 0, 2, out=d)
+    _, d1 = sc.render_xorshift(40, 24, 9, 2, 4, out=d)
+    assert d0.casts + d1.casts == ca.casts
+
+
+def test_xorshift_mode_statistics_match_mt_mode(oracle):
+    """The two sampler modes are different random streams over the same physics: path statistics must agree."""
+    W, spp = 96, 16
+    _, cm = O.Scene.cornell(O.ACCEL_BVH).render_mt(W, W, 2024, spp, math=O.MATH_LIBM)
+    _, cx = O.Scene.cornell(O.ACCEL_LIST).render_xorshift(W, W, 2024, 0, spp, math=O.MATH_PORTABLE)
+    rays_m, rays_x = cm.casts / cm.paths, cx.casts / cx.paths
+    assert abs(rays_m - rays_x) < 0.03 and 2.0 < rays_x < 2.2            # SURVEY: 2.094 casts per path
+    assert abs(cm.hits / cm.casts - cx.hits / cx.casts) < 0.01           # SURVEY: 15.8 % misses
+
+
+def test_primitive_known_answers(oracle):
+    """Hand-checkable intersections (primitive_triangle.cc:97-128, primitive_sphere.cc:75-107, disk, cylinder)."""
+    f3 = O.f3
+    t, pos, nrm = C.c_float(), (C.c_float * 3)(), (C.c_float * 3)()
+    tri = O.OObject(0, 0, (C.c_float * 9)(0, 0, 0, 1, 0, 0, 0, 1, 0))
+    assert oracle.oracle_intersect(C.byref(tri), f3([0.25, 0.25, 1]), f3([0, 0, -1]), C.byref(t), pos, nrm) == 1
+    assert t.value == 1.0 and list(pos) == [0.25, 0.25, 0.0] and list(nrm) == [0.0, 0.0, 1.0]   # unflipped geometric normal
+    assert oracle.oracle_intersect(C.byref(tri), f3([0.75, 0.75, 1]), f3([0, 0, -1]), C.byref(t), pos, nrm) == 0   # u+v > 1
+    assert oracle.oracle_intersect(C.byref(tri), f3([0.25, 0.25, 5e-7]), f3([0, 0, -1]), C.byref(t), pos, nrm) == 0  # t < kEPS
+    assert oracle.oracle_intersect(C.byref(tri), f3([0.25, 0.25, 1]), f3([1, 0, 0]), C.byref(t), pos, nrm) == 0    # det = 0
+    sph = O.OObject(1, 0, (C.c_float * 9)(0, 0, 0, 1))
+    assert oracle.oracle_intersect(C.byref(sph), f3([0, 0, 3]), f3([0, 0, -1]), C.byref(t), pos, nrm) == 1
+    assert t.value == 2.0 and list(nrm) == [0.0, 0.0, 1.0]
+    assert oracle.oracle_intersect(C.byref(sph), f3([0, 0, 0]), f3([0, 0, -1]), C.byref(t), pos, nrm) == 1          # from inside: far root
+    assert t.value == 1.0 and list(nrm) == [0.0, 0.0, -1.0]
+    assert oracle.oracle_intersect(C.byref(sph), f3([0, 2, 3]), f3([0, 0, -1]), C.byref(t), pos, nrm) == 0
+    disk = O.OObject(2, 0, (C.c_float * 9)(0, 0, 0, 0, 0, 1, 0.5))
+    assert oracle.oracle_intersect(C.byref(disk), f3([0.25, 0, 2]), f3([0, 0, -1]), C.byref(t), pos, nrm) == 1 and t.value == 2.0
+    assert oracle.oracle_intersect(C.byref(disk), f3([0.75, 0, 2]), f3([0, 0, -1]), C.byref(t), pos, nrm) == 0
+    cyl = O.OObject(3, 0, (C.c_float * 9)(0, 0, 0, 0, 0, 1, 0.5, 2.0))
+    assert oracle.oracle_intersect(C.byref(cyl), f3([2, 0, 1]), f3([-1, 0, 0]), C.byref(t), pos, nrm) == 1
+    assert t.value == 1.5 and list(nrm) == [1.0, 0.0, 0.0]
+    assert oracle.oracle_intersect(C.byref(cyl), f3([2, 0, 3]), f3([-1, 0, 0]), C.byref(t), pos, nrm) == 0          # above the cap
+
+
+def test_aabb_slab_semantics(oracle):
+    """prelude::Intersect (aabb.cc:28-62): t_min clamped at 0, t_max clamped at the current best, zero-thickness boxes."""
+    f3 = O.f3
+    tin, tout = C.c_float(), C.c_float()
+    assert oracle.oracle_aabb_intersect(f3([-1, -1, -1]), f3([1, 1, 1]), f3([0, 0, 3]), f3([0, 0, -1]), 1e30, C.byref(tin), C.byref(tout)) == 1
+    assert (tin.value, tout.value) == (2.0, 4.0)
+    assert oracle.oracle_aabb_intersect(f3([-1, -1, -1]), f3([1, 1, 1]), f3([0, 0, 3]), f3([0, 0, -1]), 1.5, C.byref(tin), C.byref(tout)) == 0
+    assert oracle.oracle_aabb_intersect(f3([-1, -1, -1]), f3([1, 1, 1]), f3([0, 0, 0]), f3([0, 0, -1]), 1e30, C.byref(tin), C.byref(tout)) == 1
+    assert tin.value == 0.0
+    # flat box (a wall) hit head-on
+    assert oracle.oracle_aabb_intersect(f3([-1, -1, -1]), f3([1, -1, 1]), f3([0, 0, 0]), f3([0, -1, 0]), 1e30, C.byref(tin), C.byref(tout)) == 1
+    assert tin.value == 1.0 and tout.value == 1.0
