@@ -25,14 +25,18 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-le
 BYTES_PER_RAY = 96.0      # algorithmic ray-state bytes per bounce (DESIGN.md "Roofline")
 
 
-def cpu_baseline(width: int, seed: int, budget_s: float = 12.0):
+def cpu_baseline(width: int, seed: int, budget_s: float = 15.0):
     """The CPU restatement (oracle, kind "port") on the host cores, reference threading model (rows of whole-image
     1-spp passes pulled by T threads), on a bounded sample of the SAME workload: full 1024x1024 frame, few spp."""
     sys.path.insert(0, str(ROOT / "tests"))
     import numpy as np
     import oracle_binding as O
 
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("AMBER_BENCH_CPU_THREADS", "16"))))   # a 1-GPU box's CPU share is 16 cores
     sc = O.Scene.cornell(O.ACCEL_BVH)          # the reference's own acceleration structure
     t0 = time.perf_counter()
     _, cnt = sc.render_xorshift(width, width, seed, 0, 1, math=O.MATH_LIBM, threads=cores)

@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Condenses gpurun_out/prof_<tag>/ (written by tools/profile.sh on the GPU box) into tracked files under profiles/."""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+kernel = sys.argv[2] if len(sys.argv) > 2 else "pt_megakernel"
+src = ROOT / "gpurun_out" / f"prof_{tag}"
+dst = ROOT / "profiles"
+dst.mkdir(exist_ok=True)
+
+stats = glob.glob(str(src / "trace" / "*" / "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], dst / f"{tag}_kernel_stats.csv")
+pmc = collections.OrderedDict()
+for f in sorted(glob.glob(str(src / "pmc_*" / "*" / "*_counter_collection.csv"))):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if kernel in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        pmc[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+summary = {"tag": tag, "kernel": kernel, "command": "rocprofv3 --kernel-trace --stats / --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+           "pmc": pmc}
+if stats:
+    for r in csv.DictReader(open(stats[0])):
+        if kernel in r["Name"]:
+            summary["kernel_trace"] = {"calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]),
+                                       "percentage": float(r["Percentage"])}
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes read.
+    # Calibrated on this kernel's own known read: the framebuffer read-modify-write reads W*H*12 B per launch.
+    fetch = pmc["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
+    write = pmc["WRITE_SIZE"]["mean_per_launch"] * 1024
+    summary["hbm"] = {"fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+                      "correction": "FETCH_SIZE x 2 (gfx950 counts 128-B requests as 64 B); WRITE_SIZE as is"}
+    (dst / f"{tag}_hbm_traffic.json").write_text(json.dumps({"hbm_bytes_per_launch": fetch + write, **summary["hbm"]}, indent=2) + "\n")
+if {"SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU"} <= pmc.keys():
+    summary["valu_lane_utilisation"] = pmc["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / (pmc["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 64)
+if "GRBM_GUI_ACTIVE" in pmc and "kernel_trace" in summary:
+    summary["effective_clock_ghz"] = pmc["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8 / summary["kernel_trace"]["average_ns"]
+(dst / f"{tag}_summary.json").write_text(json.dumps(summary, indent=2) + "\n")
+print(json.dumps({k: v for k, v in summary.items() if k != "pmc"}, indent=2))
