@@ -39,58 +39,108 @@ int Fail(int code, const std::string& msg) { g_last_error = msg; return code; }
 // ------------------------------------------------------------------------------------------------
 struct RenderArgs {
   DevScene scene;
-  float* fb;                 // band framebuffer: rows [row_begin,row_end) x width x RGB sums
+  float* partial;            // [n_chunks][n_pixels][3] per-item sums of this launch
   unsigned long long* ray_count;
+  unsigned int* next_item;   // work-queue head (zeroed before every launch)
   uint64_t hashed_seed;      // SplitMix64(global_seed)
-  uint32_t row_begin, row_end;
+  uint32_t row_begin;
+  uint32_t n_pixels;         // pixels of the band
   uint32_t first_sample, n_samples;
-  uint32_t tiles_x;
+  uint32_t n_chunks, n_items;
 };
 
-// One wave = one 8x8 pixel tile; 4 waves per workgroup.
+// Work item = (pixel of the band, chunk of AMBER_ACCUM_CHUNK consecutive samples).  Waves are persistent
+// workers: a wave claims 64 items at a time from the global queue head with ONE atomic, and hands them to
+// its lanes with a ballot + prefix count (mbcnt) whenever lanes run dry, so no lane idles until the queue is
+// empty.  A lane walks the samples of its item in order (sum += measurement), regenerating the eye ray in
+// place when a path ends, and stores the item's sum to partial[chunk][pixel]; reduce_partials_kernel adds the
+// chunks to the framebuffer in chunk order.  The summation order is therefore fixed.
 __global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
-  const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-  const uint32_t px = tx * 8u + (lane & 7u);
-  const uint32_t py = a.row_begin + ty * 8u + (lane >> 3);
-  const bool valid = px < sc.sensor.w && py < a.row_end;
-  const uint32_t pixel = px + py * sc.sensor.w;          // Image index x + y*W (image.h:116-124)
 
-  uint32_t s = a.first_sample;
-  const uint32_t s_end = valid ? a.first_sample + a.n_samples : a.first_sample;
+  uint32_t pool_next = 0, pool_end = 0;      // wave-uniform: items claimed by this wave, not yet handed out
+  bool exhausted = false;                    // wave-uniform: the global queue is empty
+  bool lane_done = false, have_item = false, alive = false;
+  uint32_t s = 0, s_end = 0, px = 0, py = 0, pixel = 0, slot = 0;
   V3 sum = v3(0.f, 0.f, 0.f), meas = v3(0.f, 0.f, 0.f);
   V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), w = v3(0.f, 0.f, 0.f);
   uint64_t rng = 1;
   uint32_t casts = 0, rays = 0;
-  bool alive = false;
 
   for (;;) {
-    if (!alive) {
-      if (s >= s_end) break;
+    bool need = !alive && s >= s_end && !lane_done;
+    if (need && have_item) {                                // item finished: publish its sum
+      float* p = a.partial + static_cast<size_t>(slot) * 3u;
+      p[0] = sum.x; p[1] = sum.y; p[2] = sum.z;
+      have_item = false;
+    }
+    unsigned long long mask = __ballot(need);
+    while (mask) {                                          // wave-uniform loop (usually one trip)
+      const uint32_t avail = pool_end - pool_next;
+      if (avail == 0) {
+        if (exhausted) break;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.next_item, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= a.n_items) { exhausted = true; break; }
+        pool_next = base;
+        pool_end = base + 64u < a.n_items ? base + 64u : a.n_items;
+        continue;
+      }
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+      if (need && rank < avail) {
+        const uint32_t item = pool_next + rank;
+        const uint32_t plocal = item / a.n_chunks, chunk = item - plocal * a.n_chunks;
+        px = plocal % sc.sensor.w;
+        py = a.row_begin + plocal / sc.sensor.w;
+        pixel = px + py * sc.sensor.w;                      // Image index x + y*W (image.h:116-124)
+        slot = chunk * a.n_pixels + plocal;
+        s = a.first_sample + chunk * AMBER_ACCUM_CHUNK;
+        const uint32_t e = s + AMBER_ACCUM_CHUNK, last = a.first_sample + a.n_samples;
+        s_end = e < last ? e : last;
+        sum = v3(0.f, 0.f, 0.f);
+        have_item = true;
+        need = false;
+      }
+      const uint32_t wanted = static_cast<uint32_t>(__popcll(mask));
+      pool_next += wanted < avail ? wanted : avail;
+      mask = __ballot(need);
+    }
+    if (need) lane_done = true;                             // queue empty: this lane retires
+    if (__ballot(!lane_done) == 0ull) break;
+
+    if (!alive && !lane_done) {                             // regenerate: next sample of the item
       rng = XorShiftSeed(a.hashed_seed, pixel, s);
       float ew;
       GenerateEyeRay(sc, px, py, rng, o, d, ew);
-      w = v3(ew, ew, ew);                                 // Leading<RGB>(.., Radiant(weight)) lens_basic.h:139-144
+      w = v3(ew, ew, ew);                                   // Leading<RGB>(.., Radiant(weight)) lens_basic.h:139-144
       meas = v3(0.f, 0.f, 0.f);
       casts = 0;
       alive = true;
       ++s;
     }
-    alive = PathStep<false>(sc, o, d, w, meas, rng, casts, nullptr);
-    ++rays;
-    if (!alive) sum = sum + meas;                         // per-pixel sequential sum over samples
+    if (alive) {
+      alive = PathStep<false>(sc, o, d, w, meas, rng, casts, nullptr);
+      ++rays;
+      if (!alive) sum = sum + meas;                         // sequential sum over the item's samples
+    }
   }
 
-  if (valid) {
-    float* p = a.fb + (static_cast<size_t>(py - a.row_begin) * sc.sensor.w + px) * 3u;
-    p[0] += sum.x; p[1] += sum.y; p[2] += sum.z;
-  }
   // one atomic per wave for the ray counter
   unsigned long long r = rays;
   for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
   if (lane == 0 && r) atomicAdd(a.ray_count, r);
+}
+
+// fb[e] += partial[0][e] + partial[1][e] + ... in chunk order (e = pixel*3 + channel of the band)
+__global__ void reduce_partials_kernel(float* __restrict__ fb, const float* __restrict__ partial, uint32_t n_elems, uint32_t n_chunks) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_elems) return;
+  float v = fb[e];
+  for (uint32_t c = 0; c < n_chunks; ++c) v = v + partial[static_cast<size_t>(c) * n_elems + e];
+  fb[e] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -191,6 +241,10 @@ struct amber_hip_pt {
   DevBlade* d_blades = nullptr;
   float* d_fb = nullptr;
   unsigned long long* d_rays = nullptr;
+  unsigned int* d_next = nullptr;
+  float* d_partial = nullptr;
+  size_t partial_floats = 0;
+  int n_cus = 256;
   uint32_t row_begin = 0, row_end = 0;
   uint64_t seed = 0, hashed_seed = 0;
   uint32_t engine = AMBER_ENGINE_MEGAKERNEL;
@@ -323,6 +377,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   const size_t fb_floats = static_cast<size_t>(re - rb) * sensor->width * 3;
   HIP_TRY_H(hipMalloc(&h->d_fb, fb_floats * sizeof(float)));
   HIP_TRY_H(hipMalloc(&h->d_rays, sizeof(unsigned long long)));
+  HIP_TRY_H(hipMalloc(&h->d_next, sizeof(unsigned int)));
+  { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, params->device) == hipSuccess && v > 0) h->n_cus = v; }
   HIP_TRY_H(hipMemsetAsync(h->d_fb, 0, fb_floats * sizeof(float), h->stream));
   HIP_TRY_H(hipMemsetAsync(h->d_rays, 0, sizeof(unsigned long long), h->stream));
 
@@ -356,23 +412,52 @@ int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
   if (n_samples == 0) return AMBER_OK;
   if (static_cast<uint64_t>(first_sample) + n_samples > 0xffffffffull) return Fail(AMBER_EINVAL, "sample index overflow");
   HIP_TRY(hipSetDevice(h->device));
-  RenderArgs a;
-  a.scene = h->scene; a.fb = h->d_fb; a.ray_count = h->d_rays; a.hashed_seed = h->hashed_seed;
-  a.row_begin = h->row_begin; a.row_end = h->row_end; a.first_sample = first_sample; a.n_samples = n_samples;
-  a.tiles_x = (h->scene.sensor.w + 7) / 8;
-  const uint32_t tiles_y = (h->row_end - h->row_begin + 7) / 8;
-  const uint32_t n_tiles = a.tiles_x * tiles_y;
-  const uint32_t n_blocks = (n_tiles + 3) / 4;
-  if (h->events_used == h->events.size()) {
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    h->events.emplace_back(e0, e1);
+  const uint32_t n_pixels = (h->row_end - h->row_begin) * h->scene.sensor.w;
+  // a launch covers at most kMaxPartialFloats of per-item sums and < 2^31 items; longer passes are split on
+  // chunk boundaries, which leaves the summation order (chunks in order) unchanged
+  const uint64_t kMaxPartialFloats = 384ull << 20;    // 1.5 GiB
+  uint64_t max_chunks = kMaxPartialFloats / (static_cast<uint64_t>(n_pixels) * 3u);
+  const uint64_t by_items = 0x7fffffffull / n_pixels;
+  if (by_items < max_chunks) max_chunks = by_items;
+  if (max_chunks == 0) return Fail(AMBER_EINVAL, "band too large for one launch");
+  uint32_t done = 0;
+  while (done < n_samples) {
+    uint32_t n = n_samples - done;
+    const uint64_t cap = max_chunks * AMBER_ACCUM_CHUNK;
+    if (n > cap) n = static_cast<uint32_t>(cap);
+    const uint32_t n_chunks = (n + AMBER_ACCUM_CHUNK - 1) / AMBER_ACCUM_CHUNK;
+    const size_t need = static_cast<size_t>(n_chunks) * n_pixels * 3u;
+    if (need > h->partial_floats) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (h->d_partial) { HIP_TRY(hipFree(h->d_partial)); h->d_partial = nullptr; h->partial_floats = 0; }
+      hipError_t e = hipMalloc(&h->d_partial, need * sizeof(float));
+      if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(partial sums): ") + hipGetErrorString(e));
+      h->partial_floats = need;
+    }
+    RenderArgs a;
+    a.scene = h->scene; a.partial = h->d_partial; a.ray_count = h->d_rays; a.next_item = h->d_next; a.hashed_seed = h->hashed_seed;
+    a.row_begin = h->row_begin; a.n_pixels = n_pixels; a.first_sample = first_sample + done; a.n_samples = n;
+    a.n_chunks = n_chunks; a.n_items = n_pixels * n_chunks;
+    // persistent workers: 5 workgroups of 4 waves per CU (90 VGPRs -> 5 waves/SIMD), fewer if the queue is short
+    uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * 5u;
+    const uint32_t by_work = (a.n_items + 255u) / 256u;
+    if (by_work < n_blocks) n_blocks = by_work;
+    HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
+    if (h->events_used == h->events.size()) {
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+      h->events.emplace_back(e0, e1);
+    }
+    auto& ev = h->events[h->events_used++];
+    HIP_TRY(hipEventRecord(ev.first, h->stream));
+    hipLaunchKernelGGL(pt_megakernel, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.second, h->stream));
+    const uint32_t n_elems = n_pixels * 3u;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_elems + 255u) / 256u), dim3(256), 0, h->stream, h->d_fb, h->d_partial, n_elems, n_chunks);
+    HIP_TRY(hipGetLastError());
+    done += n;
   }
-  auto& ev = h->events[h->events_used++];
-  HIP_TRY(hipEventRecord(ev.first, h->stream));
-  hipLaunchKernelGGL(pt_megakernel, dim3(n_blocks), dim3(256), 0, h->stream, a);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(ev.second, h->stream));
   return AMBER_OK;
 }
 
@@ -438,6 +523,8 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_blades) (void)hipFree(h->d_blades);
   if (h->d_fb) (void)hipFree(h->d_fb);
   if (h->d_rays) (void)hipFree(h->d_rays);
+  if (h->d_next) (void)hipFree(h->d_next);
+  if (h->d_partial) (void)hipFree(h->d_partial);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }

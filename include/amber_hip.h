@@ -28,6 +28,11 @@ extern "C" {
 
 #define AMBER_HIP_ABI_VERSION 1
 
+/* Accumulation granule: within a render pass the samples of a pixel are summed sequentially in chunks of
+ * AMBER_ACCUM_CHUNK consecutive samples (starting at first_sample), and the chunk sums are added to the
+ * framebuffer in chunk order.  Part of the numerical contract (the oracle restates it). */
+#define AMBER_ACCUM_CHUNK 32u
+
 enum {
   AMBER_OK = 0,
   AMBER_EINVAL = -1,     /* bad argument / malformed flat scene */
@@ -117,8 +122,8 @@ typedef struct amber_hip_pt amber_hip_pt;
 /* Uploads the flattened scene to HBM and allocates the band framebuffer (zeroed). */
 int  amber_hip_pt_create(const AmberFlatScene* scene, const AmberSensor* sensor,
                          const AmberPtParams* params, amber_hip_pt** out);
-/* Adds, for every pixel of the band, the sequential f32 sum of the path measurements of samples
- * [first_sample, first_sample + n_samples) to the device framebuffer.  Asynchronous. */
+/* Adds, for every pixel of the band, the path measurements of samples [first_sample, first_sample + n_samples)
+ * to the device framebuffer (binary32; order: see AMBER_ACCUM_CHUNK).  Asynchronous. */
 int  amber_hip_pt_render_pass(amber_hip_pt*, uint32_t first_sample, uint32_t n_samples);
 /* Zeroes the device framebuffer and the ray counter (asynchronous). */
 int  amber_hip_pt_clear(amber_hip_pt*);

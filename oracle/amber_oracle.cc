@@ -903,7 +903,7 @@ void oracle_render_mt(const oracle_scene* sc, const oracle_sensor* sensor, uint6
 
 void oracle_render_xorshift(const oracle_scene* sc, const oracle_sensor* sensor, uint64_t global_seed,
                             uint32_t first_sample, uint32_t n_samples, uint32_t y0, uint32_t y1,
-                            int math, uint32_t max_depth, uint32_t n_threads,
+                            int math, uint32_t max_depth, uint32_t n_threads, uint32_t chunk,
                             float* sum_rgb, oracle_counters* counters) {
   const Sensor S{sensor->width, sensor->height, sensor->scene_width, sensor->scene_height};
   const Math M{math};
@@ -914,15 +914,21 @@ void oracle_render_xorshift(const oracle_scene* sc, const oracle_sensor* sensor,
     for (uint64_t y = y0 + tid; y < y1; y += n_threads)
       for (uint64_t x = 0; x < S.w; x++) {
         const uint32_t pixel = static_cast<uint32_t>(x + y * S.w);
-        V3 sum = splat(0);
-        for (uint32_t s = first_sample; s < first_sample + n_samples; s++) {
-          XorShiftSampler smp(XorShiftSeed(global_seed, pixel, s));
-          const PathResult r = TracePath(*sc, S, x, y, smp, M, max_depth, nullptr, 0, nullptr);
-          sum = sum + r.measurement;
-          cnt.casts += r.casts; cnt.hits += r.hits; cnt.paths++;
-        }
         float* p = &sum_rgb[static_cast<std::size_t>(pixel) * 3];
-        p[0] += sum.x; p[1] += sum.y; p[2] += sum.z;
+        // accumulation granule (include/amber_hip.h AMBER_ACCUM_CHUNK): sequential sum inside a chunk of
+        // `chunk` samples, chunk sums added to the running pixel value in chunk order; 0 = one chunk
+        const uint32_t step = chunk ? chunk : n_samples;
+        for (uint32_t c0 = 0; c0 < n_samples; c0 += step) {
+          V3 sum = splat(0);
+          const uint32_t c1 = c0 + step < n_samples ? c0 + step : n_samples;
+          for (uint32_t s = first_sample + c0; s < first_sample + c1; s++) {
+            XorShiftSampler smp(XorShiftSeed(global_seed, pixel, s));
+            const PathResult r = TracePath(*sc, S, x, y, smp, M, max_depth, nullptr, 0, nullptr);
+            sum = sum + r.measurement;
+            cnt.casts += r.casts; cnt.hits += r.hits; cnt.paths++;
+          }
+          p[0] += sum.x; p[1] += sum.y; p[2] += sum.z;
+        }
       }
   };
   std::vector<std::thread> threads;

@@ -97,12 +97,13 @@ void oracle_render_mt(const oracle_scene*, const oracle_sensor*, uint64_t seed, 
                       int math, float* out_rgb, oracle_counters* counters);
 
 /* XorShift mode -- per-(pixel,sample) sampler: seed = hash(global_seed, pixel, sample).
- * Adds, for every pixel, the sequential f32 sum over samples [first_sample, first_sample+n)
- * of the path measurements to sum_rgb (W*H*3, caller zero-initialises before the first pass).
+ * Adds, for every pixel, the path measurements of samples [first_sample, first_sample+n) to sum_rgb
+ * (W*H*3, caller zero-initialises before the first pass): sequential f32 sums over chunks of `chunk`
+ * samples, chunk sums added in order (the engine's AMBER_ACCUM_CHUNK; 0 = a single chunk).
  * Rows [y0, y1) only.  n_threads > 1 splits rows across threads (results are identical). */
 void oracle_render_xorshift(const oracle_scene*, const oracle_sensor*, uint64_t global_seed,
                             uint32_t first_sample, uint32_t n_samples, uint32_t y0, uint32_t y1,
-                            int math, uint32_t max_depth, uint32_t n_threads,
+                            int math, uint32_t max_depth, uint32_t n_threads, uint32_t chunk,
                             float* sum_rgb, oracle_counters* counters);
 
 /* per-path trace in XorShift mode (for path-level parity tests) */

@@ -14,6 +14,7 @@ ROOT = Path(__file__).resolve().parent.parent
 LIB = ROOT / "oracle" / "liboracle.so"
 
 ACCEL_BVH, ACCEL_LIST = 0, 1
+ACCUM_CHUNK = 32   # include/amber_hip.h AMBER_ACCUM_CHUNK
 MATH_LIBM, MATH_PORTABLE = 0, 1
 
 
@@ -73,7 +74,7 @@ def load():
     L.oracle_scene_get_lens.argtypes = [vp] + [C.POINTER(f)] * 6
     L.oracle_scene_bvh_stats.argtypes = [vp] + [C.POINTER(u32)] * 3
     L.oracle_render_mt.argtypes = [vp, C.POINTER(OSensor), u64, u32, C.c_int, vp, C.POINTER(OCounters)]
-    L.oracle_render_xorshift.argtypes = [vp, C.POINTER(OSensor), u64, u32, u32, u32, u32, C.c_int, u32, u32, vp, C.POINTER(OCounters)]
+    L.oracle_render_xorshift.argtypes = [vp, C.POINTER(OSensor), u64, u32, u32, u32, u32, C.c_int, u32, u32, u32, vp, C.POINTER(OCounters)]
     L.oracle_trace_path.restype = u32
     L.oracle_trace_path.argtypes = [vp, C.POINTER(OSensor), u64, u32, u32, u32, C.c_int, u32, C.POINTER(OBounce), u32, C.POINTER(f)]
     L.oracle_cast.restype = C.c_int32
@@ -140,12 +141,12 @@ class Scene:
         self.L.oracle_render_mt(self.h, C.byref(s), seed, spp, math, img.ctypes.data, C.byref(cnt))
         return img, cnt
 
-    def render_xorshift(self, w, h, seed, first, n, math=MATH_PORTABLE, max_depth=0, threads=8, rows=None, out=None):
+    def render_xorshift(self, w, h, seed, first, n, math=MATH_PORTABLE, max_depth=0, threads=8, rows=None, out=None, chunk=ACCUM_CHUNK):
         s = sensor(w, h)
         img = np.zeros((h, w, 3), np.float32) if out is None else out
         cnt = OCounters()
         y0, y1 = rows if rows else (0, h)
-        self.L.oracle_render_xorshift(self.h, C.byref(s), seed, first, n, y0, y1, math, max_depth, threads, img.ctypes.data, C.byref(cnt))
+        self.L.oracle_render_xorshift(self.h, C.byref(s), seed, first, n, y0, y1, math, max_depth, threads, chunk, img.ctypes.data, C.byref(cnt))
         return img, cnt
 
     def trace(self, w, h, seed, px, py, sample, math=MATH_PORTABLE, max_depth=0, max_bounces=16):

@@ -194,7 +194,7 @@ def test_max_depth_extension(amber, cornell):
     assert casts.max() == 3
 
 
-@pytest.mark.parametrize("which,W,H,passes", [("cornell", 128, 96, [(0, 5), (5, 11)]), ("cornell", 67, 45, [(0, 7)]), ("generic", 64, 64, [(3, 6), (9, 2)])])
+@pytest.mark.parametrize("which,W,H,passes", [("cornell", 128, 96, [(0, 5), (5, 11)]), ("cornell", 67, 45, [(0, 7)]), ("generic", 64, 64, [(3, 70), (73, 40)]), ("cornell", 40, 40, [(0, 100)])])
 def test_render_images_bit_exact(amber, cornell, generic, which, W, H, passes):
     """Whole-image parity incl. ragged sizes (not multiples of the 8x8 tile), several passes and sample offsets."""
     hs, osc = cornell if which == "cornell" else generic
