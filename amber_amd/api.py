@@ -49,7 +49,8 @@ class Sensor(C.Structure):
 
 class PtParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("max_depth", C.c_uint32), ("device", C.c_int32), ("row_begin", C.c_uint32),
-                ("row_end", C.c_uint32), ("stream", C.c_void_p), ("engine", C.c_uint32), ("reserved", C.c_uint32)]
+                ("row_end", C.c_uint32), ("stream", C.c_void_p), ("engine", C.c_uint32), ("stripe_rows", C.c_uint32),
+                ("stripe_period", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class HostStats(C.Structure):
@@ -63,7 +64,7 @@ ENGINE_AUTO, ENGINE_MEGAKERNEL, ENGINE_WAVEFRONT = 0, 1, 2
 # every symbol include/amber_hip.h and include/amber_host.h declare
 ABI_SYMBOLS = [
     "amber_hip_pt_create", "amber_hip_pt_render_pass", "amber_hip_pt_clear", "amber_hip_pt_sync",
-    "amber_hip_pt_download", "amber_hip_pt_device_framebuffer", "amber_hip_pt_kernel_time", "amber_hip_pt_destroy",
+    "amber_hip_pt_download", "amber_hip_pt_device_framebuffer", "amber_hip_pt_local_rows", "amber_hip_pt_kernel_time", "amber_hip_pt_destroy",
     "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_device_count",
     "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math",
     "amber_host_cornell_box", "amber_host_scene_create", "amber_host_scene_destroy", "amber_host_scene_flatten",
@@ -100,6 +101,7 @@ def load_library() -> C.CDLL:
     lib.amber_hip_pt_sync.argtypes = [vp]
     lib.amber_hip_pt_download.argtypes = [vp, vp, C.POINTER(u64)]
     lib.amber_hip_pt_device_framebuffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    lib.amber_hip_pt_local_rows.argtypes = [vp, C.POINTER(u32)]
     lib.amber_hip_pt_kernel_time.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_double)]
     lib.amber_hip_pt_destroy.argtypes = [vp]
     lib.amber_hip_pt_destroy.restype = None
@@ -203,18 +205,25 @@ class PathTracer:
     """amber_hip_pt handle: the device-side engine for one band of the framebuffer on one GPU."""
 
     def __init__(self, scene: HostScene, sensor: Sensor, seed: int = 12345, max_depth: int = 0, device: int = 0,
-                 rows=None, stream: int | None = None, engine: int = ENGINE_AUTO):
+                 rows=None, stream: int | None = None, engine: int = ENGINE_AUTO, stripe=None):
+        """rows = (y0, y1) contiguous band; stripe = (S, period) keeps only rows with (y - y0) % period < S."""
         self.sensor = sensor
-        rb, re = rows if rows is not None else (0, 0)
-        self.rows = (rb, re) if rows is not None else (0, sensor.height)
-        p = PtParams(seed, max_depth, device, rb, re, stream, engine, 0)
+        rb, re = rows if rows is not None else (0, sensor.height)
+        s_rows, s_period = stripe if stripe else (0, 0)
+        p = PtParams(seed, max_depth, device, rb, re, stream, engine, s_rows, s_period, 0)
         h = C.c_void_p()
         _check(load_library().amber_host_pt_create(scene._h, C.byref(sensor), C.byref(p), C.byref(h)), host=True)
         self._h = h
+        ys = np.arange(rb, re)
+        self.row_index = ys[(ys - rb) % s_period < s_rows] if s_rows else ys   # global row of every local row
+        n = C.c_uint32()
+        _check(load_library().amber_hip_pt_local_rows(self._h, C.byref(n)))
+        assert n.value == len(self.row_index)
+        self.rows = (rb, re)
 
     @property
     def band_shape(self):
-        return (self.rows[1] - self.rows[0], self.sensor.width, 3)
+        return (len(self.row_index), self.sensor.width, 3)
 
     def render_pass(self, first_sample: int, n_samples: int) -> None:
         _check(load_library().amber_hip_pt_render_pass(self._h, first_sample, n_samples))

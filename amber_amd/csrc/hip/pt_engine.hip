@@ -44,6 +44,7 @@ struct RenderArgs {
   unsigned int* next_item;   // work-queue head (zeroed before every launch)
   uint64_t hashed_seed;      // SplitMix64(global_seed)
   uint32_t row_begin;
+  uint32_t stripe_rows, stripe_period;   // 0,0 = contiguous rows
   uint32_t n_pixels;         // pixels of the band
   uint32_t first_sample, n_samples;
   uint32_t n_chunks, n_items;
@@ -93,8 +94,9 @@ __global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
       if (need && rank < avail) {
         const uint32_t item = pool_next + rank;
         const uint32_t plocal = item / a.n_chunks, chunk = item - plocal * a.n_chunks;
-        px = plocal % sc.sensor.w;
-        py = a.row_begin + plocal / sc.sensor.w;
+        const uint32_t lrow = plocal / sc.sensor.w;
+        px = plocal - lrow * sc.sensor.w;
+        py = a.row_begin + (a.stripe_rows ? (lrow / a.stripe_rows) * a.stripe_period + lrow % a.stripe_rows : lrow);
         pixel = px + py * sc.sensor.w;                      // Image index x + y*W (image.h:116-124)
         slot = chunk * a.n_pixels + plocal;
         s = a.first_sample + chunk * AMBER_ACCUM_CHUNK;
@@ -245,7 +247,7 @@ struct amber_hip_pt {
   float* d_partial = nullptr;
   size_t partial_floats = 0;
   int n_cus = 256;
-  uint32_t row_begin = 0, row_end = 0;
+  uint32_t row_begin = 0, row_end = 0, stripe_rows = 0, stripe_period = 0, local_rows = 0;
   uint64_t seed = 0, hashed_seed = 0;
   uint32_t engine = AMBER_ENGINE_MEGAKERNEL;
   uint32_t n_materials = 0;
@@ -313,13 +315,20 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   uint32_t rb = params->row_begin, re = params->row_end;
   if (rb == 0 && re == 0) re = sensor->height;
   if (rb >= re || re > sensor->height) return Fail(AMBER_EINVAL, "bad row band");
+  uint32_t local_rows = re - rb;
+  if (params->stripe_rows) {
+    if (params->stripe_period < params->stripe_rows) return Fail(AMBER_EINVAL, "stripe_period must be >= stripe_rows");
+    const uint32_t q = (re - rb) / params->stripe_period, rem = (re - rb) % params->stripe_period;
+    local_rows = q * params->stripe_rows + (rem < params->stripe_rows ? rem : params->stripe_rows);
+  }
   if (params->engine != AMBER_ENGINE_AUTO && params->engine != AMBER_ENGINE_MEGAKERNEL)
     return Fail(AMBER_EINVAL, "engine not available in this build");
 
   HIP_TRY(hipSetDevice(params->device));
   auto* h = new amber_hip_pt();
   h->device = params->device;
-  h->row_begin = rb; h->row_end = re;
+  h->row_begin = rb; h->row_end = re; h->local_rows = local_rows;
+  h->stripe_rows = params->stripe_rows; h->stripe_period = params->stripe_rows ? params->stripe_period : 0;
   h->seed = params->seed; h->hashed_seed = HostSplitMix64(params->seed);
   if (params->stream) { h->stream = static_cast<hipStream_t>(params->stream); }
   else {
@@ -374,7 +383,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMemcpy(h->d_objects, objs.data(), objs.size() * sizeof(DevObject), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_blades, blades.data(), blades.size() * sizeof(DevBlade), hipMemcpyHostToDevice));
-  const size_t fb_floats = static_cast<size_t>(re - rb) * sensor->width * 3;
+  const size_t fb_floats = static_cast<size_t>(local_rows) * sensor->width * 3;
   HIP_TRY_H(hipMalloc(&h->d_fb, fb_floats * sizeof(float)));
   HIP_TRY_H(hipMalloc(&h->d_rays, sizeof(unsigned long long)));
   HIP_TRY_H(hipMalloc(&h->d_next, sizeof(unsigned int)));
@@ -412,7 +421,7 @@ int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
   if (n_samples == 0) return AMBER_OK;
   if (static_cast<uint64_t>(first_sample) + n_samples > 0xffffffffull) return Fail(AMBER_EINVAL, "sample index overflow");
   HIP_TRY(hipSetDevice(h->device));
-  const uint32_t n_pixels = (h->row_end - h->row_begin) * h->scene.sensor.w;
+  const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
   // a launch covers at most kMaxPartialFloats of per-item sums and < 2^31 items; longer passes are split on
   // chunk boundaries, which leaves the summation order (chunks in order) unchanged
   const uint64_t kMaxPartialFloats = 384ull << 20;    // 1.5 GiB
@@ -436,7 +445,7 @@ int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
     }
     RenderArgs a;
     a.scene = h->scene; a.partial = h->d_partial; a.ray_count = h->d_rays; a.next_item = h->d_next; a.hashed_seed = h->hashed_seed;
-    a.row_begin = h->row_begin; a.n_pixels = n_pixels; a.first_sample = first_sample + done; a.n_samples = n;
+    a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first_sample + done; a.n_samples = n;
     a.n_chunks = n_chunks; a.n_items = n_pixels * n_chunks;
     // persistent workers: 5 workgroups of 4 waves per CU (90 VGPRs -> 5 waves/SIMD), fewer if the queue is short
     uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * 5u;
@@ -464,7 +473,7 @@ int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
 int amber_hip_pt_clear(amber_hip_pt* h) {
   if (!h) return Fail(AMBER_EINVAL, "null handle");
   HIP_TRY(hipSetDevice(h->device));
-  const size_t fb_floats = static_cast<size_t>(h->row_end - h->row_begin) * h->scene.sensor.w * 3;
+  const size_t fb_floats = static_cast<size_t>(h->local_rows) * h->scene.sensor.w * 3;
   HIP_TRY(hipMemsetAsync(h->d_fb, 0, fb_floats * sizeof(float), h->stream));
   HIP_TRY(hipMemsetAsync(h->d_rays, 0, sizeof(unsigned long long), h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -482,7 +491,7 @@ int amber_hip_pt_sync(amber_hip_pt* h) {
 int amber_hip_pt_download(amber_hip_pt* h, float* rgb_sum, uint64_t* ray_count) {
   if (!h) return Fail(AMBER_EINVAL, "null handle");
   HIP_TRY(hipSetDevice(h->device));
-  const size_t fb_floats = static_cast<size_t>(h->row_end - h->row_begin) * h->scene.sensor.w * 3;
+  const size_t fb_floats = static_cast<size_t>(h->local_rows) * h->scene.sensor.w * 3;
   if (rgb_sum) HIP_TRY(hipMemcpyAsync(rgb_sum, h->d_fb, fb_floats * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   unsigned long long r = 0;
   HIP_TRY(hipMemcpyAsync(&r, h->d_rays, sizeof r, hipMemcpyDeviceToHost, h->stream));
@@ -494,7 +503,13 @@ int amber_hip_pt_download(amber_hip_pt* h, float* rgb_sum, uint64_t* ray_count) 
 int amber_hip_pt_device_framebuffer(amber_hip_pt* h, void** dptr, uint64_t* n_floats) {
   if (!h || !dptr) return Fail(AMBER_EINVAL, "null argument");
   *dptr = h->d_fb;
-  if (n_floats) *n_floats = static_cast<uint64_t>(h->row_end - h->row_begin) * h->scene.sensor.w * 3;
+  if (n_floats) *n_floats = static_cast<uint64_t>(h->local_rows) * h->scene.sensor.w * 3;
+  return AMBER_OK;
+}
+
+int amber_hip_pt_local_rows(amber_hip_pt* h, uint32_t* n_rows) {
+  if (!h || !n_rows) return Fail(AMBER_EINVAL, "null argument");
+  *n_rows = h->local_rows;
   return AMBER_OK;
 }
 

@@ -10,49 +10,75 @@ from __future__ import annotations
 
 import numpy as np
 
-TILE_ROWS = 8  # the engine works on 8x8 pixel tiles; bands are multiples of 8 rows
+STRIPE_ROWS = 8  # rows per stripe of the interleaved sharding
 
 
 def partition_rows(height: int, world_size: int):
-    """Contiguous bands of rows, multiples of TILE_ROWS, as even as possible.  Returns [(y0, y1)] per rank;
-    ranks beyond the number of tile rows get an empty band (y0 == y1)."""
+    """Contiguous bands of rows (multiples of 8, as even as possible).  Returns [(y0, y1)] per rank; ranks beyond
+    the number of 8-row groups get an empty band (y0 == y1).  Kept for callers that want contiguous output;
+    interleaved stripes (stripe_partition) balance the load much better on the Cornell scene."""
     if height <= 0 or world_size <= 0:
         raise ValueError("height and world_size must be positive")
-    n_tiles = (height + TILE_ROWS - 1) // TILE_ROWS
+    n_tiles = (height + 7) // 8
     base, extra = divmod(n_tiles, world_size)
     bands, t = [], 0
     for r in range(world_size):
         nt = base + (1 if r < extra else 0)
-        y0, y1 = min(t * TILE_ROWS, height), min((t + nt) * TILE_ROWS, height)
+        y0, y1 = min(t * 8, height), min((t + nt) * 8, height)
         bands.append((y0, y1))
         t += nt
     return bands
 
 
-def gather_bands(local_band, bands, width: int, rank: int, world_size: int, dst: int = 0):
-    """Gather the per-rank band sums (torch tensors, shape (rows_r, width, 3), on the backend's device) into
-    the full (height, width, 3) image on rank `dst`; returns None elsewhere.  One collective."""
+def stripe_partition(height: int, world_size: int, stripe_rows: int = STRIPE_ROWS):
+    """Interleaved sharding: rank r renders the rows y with (y // stripe_rows) % world_size == r, i.e. every
+    world_size-th stripe, so each rank sees the same mix of cheap and expensive image regions.
+    Returns per rank a dict(rows=(y0, y1), stripe=(S, period) or None, index=np.ndarray of global rows)."""
+    if height <= 0 or world_size <= 0 or stripe_rows <= 0:
+        raise ValueError("height, world_size and stripe_rows must be positive")
+    parts = []
+    ys = np.arange(height)
+    for r in range(world_size):
+        if world_size == 1:
+            parts.append(dict(rows=(0, height), stripe=None, index=ys))
+            continue
+        index = ys[(ys // stripe_rows) % world_size == r]
+        y0 = min(r * stripe_rows, height)
+        parts.append(dict(rows=(y0, height), stripe=(stripe_rows, stripe_rows * world_size), index=index))
+    return parts
+
+
+def gather_rows(local_rows, parts, width: int, rank: int, world_size: int, dst: int = 0):
+    """The job's single collective: gather every rank's rows (torch tensor (n_r, width, 3) on the backend's
+    device) to rank `dst` and scatter them to their global row positions.  Returns the (height, width, 3) image
+    on `dst`, None elsewhere."""
     import torch
     import torch.distributed as dist
 
-    max_rows = max(y1 - y0 for y0, y1 in bands)
-    dev = local_band.device
-    send = torch.zeros((max_rows, width, 3), dtype=torch.float32, device=dev)
-    rows = bands[rank][1] - bands[rank][0]
-    if rows:
-        send[:rows].copy_(local_band.reshape(rows, width, 3))
+    max_rows = max(len(p["index"]) for p in parts)
+    dev = local_rows.device
+    n = len(parts[rank]["index"])
     if world_size == 1:
-        return send[:rows].clone()
+        return local_rows.reshape(n, width, 3)
+    send = torch.zeros((max_rows, width, 3), dtype=torch.float32, device=dev)
+    if n:
+        send[:n].copy_(local_rows.reshape(n, width, 3))
     recv = [torch.empty_like(send) for _ in range(world_size)] if rank == dst else None
     dist.gather(send, gather_list=recv, dst=dst)
     if rank != dst:
         return None
-    height = bands[-1][1]
+    height = sum(len(p["index"]) for p in parts)
     full = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
-    for r, (y0, y1) in enumerate(bands):
-        if y1 > y0:
-            full[y0:y1].copy_(recv[r][: y1 - y0])
+    for r, p in enumerate(parts):
+        if len(p["index"]):
+            full.index_copy_(0, torch.as_tensor(p["index"], dtype=torch.long, device=dev), recv[r][: len(p["index"])])
     return full
+
+
+def gather_bands(local_band, bands, width: int, rank: int, world_size: int, dst: int = 0):
+    """gather_rows for contiguous bands [(y0, y1)]."""
+    parts = [dict(rows=b, stripe=None, index=np.arange(b[0], b[1])) for b in bands]
+    return gather_rows(local_band, parts, width, rank, world_size, dst)
 
 
 class DeviceArray:

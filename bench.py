@@ -3,8 +3,9 @@
 
 A "step" is one complete render of BASELINE.json's configs[1]: Cornell box, 1024x1024, 1024 samples per
 pixel (1.07e9 paths, ~2.25e9 rays), i.e. one pass of the hot path over the whole job.  For N > 1 the
-framebuffer rows are split into N bands (strong scaling: the job is fixed), every rank renders its band with
-its own scene replica, and each step ends with the single gather of the band sums to rank 0 (RCCL).
+framebuffer rows are dealt to the N ranks in interleaved 8-row stripes (strong scaling: the job is fixed), every
+rank renders its rows with its own scene replica, and each step ends with the single gather of the row sums
+to rank 0 (RCCL).
 
 Prints ONE JSON line on rank 0.  `value` = rays of all ranks / max-over-ranks wall time of the K timed
 steps (inputs resident in HBM; barrier + synchronize on both sides).
@@ -66,7 +67,7 @@ def main():
     import torch
 
     import amber_amd
-    from amber_amd.distributed import band_tensor, gather_bands, partition_rows
+    from amber_amd.distributed import band_tensor, gather_rows, stripe_partition
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,10 +86,11 @@ def main():
     W = H = args.width
     sensor = amber_amd.Sensor.default(W, H)
     scene = amber_amd.HostScene.cornell_box()                      # etude::CornelBox(0.050, 0.050, 6), application.cc:68-73
-    bands = partition_rows(H, world)
-    y0, y1 = bands[rank]
+    parts = stripe_partition(H, world)                             # interleaved 8-row stripes: equal work per rank
+    mine = parts[rank]
     stream = torch.cuda.current_stream().cuda_stream              # launch on torch's stream: ordered with the gather
-    tracer = amber_amd.PathTracer(scene, sensor, seed=args.seed, device=local_rank, rows=(y0, y1), stream=stream)
+    tracer = amber_amd.PathTracer(scene, sensor, seed=args.seed, device=local_rank, rows=mine["rows"], stripe=mine["stripe"],
+                                  stream=stream)
     fb = band_tensor(tracer, f"cuda:{local_rank}")
     launches = [(s, min(args.spp_per_launch, args.spp - s)) for s in range(0, args.spp, args.spp_per_launch)]
 
@@ -96,7 +98,7 @@ def main():
         tracer.clear()
         for first, n in launches:
             tracer.render_pass(first, n)
-        return gather_bands(fb, bands, W, rank, world)             # the single collective of the job
+        return gather_rows(fb, parts, W, rank, world)              # the single collective of the job
 
     def fence():
         torch.cuda.synchronize()
@@ -145,7 +147,7 @@ def main():
             "config": {"workload": f"Cornell box (etude::CornelBox(0.050,0.050,6)) {W}x{H} @ {args.spp} spp, RR-only path tracing, "
                                    f"per-(pixel,sample) XorShift seed {args.seed}", "rays_per_step": rays // args.steps,
                        "paths_per_step": W * H * args.spp, "wall_s_per_step": round(dt_max / args.steps, 4),
-                       "parallelism": f"bands{world}", "launches_per_step": len(launches), "engine": "megakernel"},
+                       "parallelism": f"stripes{world}x8rows", "launches_per_step": len(launches), "engine": "megakernel"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel": "pt_megakernel", "kernel_ms": round(kern_ms, 3),

@@ -104,11 +104,13 @@ typedef struct {
   uint64_t seed;        /* global seed of the per-(pixel,sample) XorShift sampler */
   uint32_t max_depth;   /* 0 = Russian roulette only (reference behaviour, algorithm_pt.cc:137-157) */
   int32_t  device;      /* HIP device ordinal */
-  uint32_t row_begin;   /* this handle renders framebuffer rows [row_begin, row_end) -- multi-GPU bands */
+  uint32_t row_begin;   /* this handle renders framebuffer rows [row_begin, row_end) -- multi-GPU sharding */
   uint32_t row_end;     /* 0,0 = all rows */
   void*    stream;      /* hipStream_t to launch on; NULL = a stream owned by the handle */
   uint32_t engine;      /* AMBER_ENGINE_* */
-  uint32_t reserved;
+  uint32_t stripe_rows; /* 0: every row of [row_begin,row_end).  S > 0: only the rows y with                */
+  uint32_t stripe_period; /* (y - row_begin) % stripe_period < S  (interleaved stripes: rank r of N uses     */
+  uint32_t reserved;    /* row_begin = r*S, row_end = height, stripe_period = N*S).  Local rows are compact. */
 } AmberPtParams;
 
 enum {
@@ -129,11 +131,13 @@ int  amber_hip_pt_render_pass(amber_hip_pt*, uint32_t first_sample, uint32_t n_s
 int  amber_hip_pt_clear(amber_hip_pt*);
 /* Waits for the handle's stream. */
 int  amber_hip_pt_sync(amber_hip_pt*);
-/* Copies the band framebuffer (rows row_begin..row_end, width*3 floats per row, RGB sums --
+/* Copies the band framebuffer (the handle's rows in increasing y, width*3 floats per row, RGB sums --
  * NOT divided by the sample count) and the ray count (Scene::Cast calls) to the host.  Synchronises. */
 int  amber_hip_pt_download(amber_hip_pt*, float* rgb_sum, uint64_t* ray_count);
 /* Device pointer of the band framebuffer (float, rows*width*3) for zero-copy hand-off to RCCL. */
 int  amber_hip_pt_device_framebuffer(amber_hip_pt*, void** dptr, uint64_t* n_floats);
+/* Number of framebuffer rows this handle owns (after striping). */
+int  amber_hip_pt_local_rows(amber_hip_pt*, uint32_t* n_rows);
 /* Per-launch timing of the dominant kernel, measured with hipEvents on the handle's stream:
  * number of timed launches since create/clear and their total duration. */
 int  amber_hip_pt_kernel_time(amber_hip_pt*, uint32_t* n_launches, double* total_ms);

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the N>1 path: band partition -> per-rank render -> one gather -> full image.
+"""world_size-2/3 gloo test of the N>1 path: stripe partition -> per-rank render -> one gather -> full image.
 
 There is no GPU here, so each rank renders its band with the ORACLE (tests may use it as a stand-in
 renderer); what is under test is amber_amd.distributed (partition, padding, the single gather, re-assembly)
@@ -19,18 +19,20 @@ import os, sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
 import numpy as np, torch, torch.distributed as dist
 import oracle_binding as O
-from amber_amd.distributed import partition_rows, gather_bands
+from amber_amd.distributed import stripe_partition, gather_rows
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 W, H, spp, seed = 40, 52, 3, 31
-bands = partition_rows(H, world)
-y0, y1 = bands[rank]
+parts = stripe_partition(H, world, 4)
+idx = parts[rank]["index"]
 sc = O.Scene.cornell(O.ACCEL_LIST)
-full, cnt = sc.render_xorshift(W, H, seed, 0, spp, rows=(y0, y1), threads=2)
-local = torch.from_numpy(full[y0:y1].copy())
-rays = torch.tensor([cnt.casts], dtype=torch.int64)
+full = np.zeros((H, W, 3), np.float32); casts = 0
+for y in idx:                       # the oracle stands in for the engine: render exactly this rank's rows
+    _, c = sc.render_xorshift(W, H, seed, 0, spp, rows=(int(y), int(y) + 1), threads=1, out=full); casts += c.casts
+local = torch.from_numpy(full[idx].copy())
+rays = torch.tensor([casts], dtype=torch.int64)
 dist.reduce(rays, dst=0)
-img = gather_bands(local, bands, W, rank, world)
+img = gather_rows(local, parts, W, rank, world)
 if rank == 0:
     np.save({out!r}, img.numpy()); np.save({out!r} + ".rays.npy", rays.numpy())
 dist.barrier(); dist.destroy_process_group()

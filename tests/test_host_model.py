@@ -30,7 +30,7 @@ def test_struct_layouts_match_the_header(amber):
     from amber_amd import api
     assert C.sizeof(api.FlatObject) == 56 and C.sizeof(api.FlatMaterial) == 24
     assert C.sizeof(api.FlatThinLens) == 4 * (3 + 9 + 9 + 3 + 2)
-    assert C.sizeof(api.Sensor) == 16 and C.sizeof(api.PtParams) == 40
+    assert C.sizeof(api.Sensor) == 16 and C.sizeof(api.PtParams) == 48
 
 
 def _resolved(objs, mats):
@@ -129,3 +129,21 @@ def test_partition_rows():
         assert all(y0 % 8 == 0 for y0, y1 in bands if y1 > y0)
         rows = [y1 - y0 for y0, y1 in bands]
         assert max(rows) - min(rows) < 16 or h < 8 * g      # one tile row of slack + a truncated last tile
+
+
+def test_stripe_partition_covers_every_row_once():
+    from amber_amd.distributed import stripe_partition
+    for h, g, s in [(1024, 8, 8), (1024, 1, 8), (2160, 8, 8), (100, 3, 4), (7, 4, 8), (52, 3, 4)]:
+        parts = stripe_partition(h, g, s)
+        allrows = np.concatenate([p["index"] for p in parts])
+        assert sorted(allrows.tolist()) == list(range(h))
+        for r, p in enumerate(parts):
+            y0, y1 = p["rows"]
+            ys = np.arange(y0, y1)
+            if p["stripe"]:
+                S, period = p["stripe"]
+                assert np.array_equal(ys[(ys - y0) % period < S], p["index"])      # exactly the rows the engine will own
+            else:
+                assert np.array_equal(ys, p["index"])
+        counts = [len(p["index"]) for p in parts]
+        assert max(counts) - min(counts) <= s
