@@ -6,6 +6,9 @@ package is a thin ctypes binding used by the tests, ``bench.py`` and the multi-G
 contains no rendering code of its own and has no CPU fallback.
 """
 from .api import (  # noqa: F401
+    ENGINE_AUTO,
+    ENGINE_LIST,
+    ENGINE_TWO_PHASE,
     AmberError,
     FlatMaterial,
     FlatObject,

@@ -31,6 +31,14 @@ struct alignas(16) DevMaterial {  // 32 B
 struct alignas(16) DevBlade {     // 48 B: aperture triangle with explicit vertices (SampleSurfacePoint)
   float v0[3], v1[3], v2[3], n[3];
 };
+// Phase-A record of the two-phase closest hit (conservative candidate filter).
+struct alignas(16) DevFilter {   // 64 B, scalar-loaded
+  float n[3];  float d0;          // triangle: unit plane normal, n.v0        | sphere: centre, radius^2
+  float A[3];  float a0;          // triangle: u = A.P + a0 for P on the plane
+  float B[3];  float b0;          //           v = B.P + b0
+  float ktol;  float kt;          // tolerance coefficients (multiplied by |1/(n.d)|) | sphere: relative tolerance
+  uint32_t kind; uint32_t pad;
+};
 struct DevLens {
   float origin[3];
   float global_[9];
@@ -50,8 +58,10 @@ struct DevScene {
   const DevObject* __restrict__ objects;
   const DevMaterial* __restrict__ materials;
   const DevBlade* __restrict__ blades;
+  const DevFilter* __restrict__ filters;
   uint32_t n_objects;
   uint32_t max_depth;
+  uint32_t tri_mask;           // bit i set: object i is a triangle (two-phase path, n_objects <= 32)
   DevLens lens;
   DevSensor sensor;
 };
@@ -198,74 +208,167 @@ __device__ __forceinline__ bool SolveQuadratic(float a, float b, float c, float&
   return true;
 }
 
-__device__ __forceinline__ void IntersectObject(const DevObject& ob, int i, V3 o, V3 d, HitRec& best) {
-  const V3 A = ld3(ob.a);
-  if (ob.kind == PRIM_TRIANGLE) {                       // primitive_triangle.cc:97-128
-    const V3 E1 = ld3(ob.e1), E2 = ld3(ob.e2);
-    const V3 P = Cross(d, E2);
-    const float det = Dot(P, E1);
-    const V3 T = o - A;
-    const float u = Dot(P, T) / det;
-    if (!(u > 1.0f || u < 0.0f)) {
-      const V3 Q = Cross(T, E1);
-      const float v = Dot(Q, d) / det;
-      if (!(v > 1.0f || v < 0.0f) && !(u + v > 1.0f)) {
-        const float t = Dot(Q, E2) / det;
-        if (!(t <= AMBER_KEPS) && IsFinite(t) && t < best.t) { best.t = t; best.u = u; best.v = v; best.idx = i; }
-      }
-    }
-  } else if (ob.kind == PRIM_SPHERE) {                  // primitive_sphere.cc:75-107
-    const V3 co = A - o;
-    const float b = -2.0f * Dot(co, d);
-    const float c = SquaredLength(co) - ob.radius * ob.radius;
-    float alpha, beta;
-    if (SolveQuadratic(1.0f, b, c, alpha, beta)) {
-      float t;
-      bool ok = true;
-      if (alpha > AMBER_KEPS) t = alpha; else if (beta > AMBER_KEPS) t = beta; else { ok = false; t = 0.f; }
-      if (ok && IsFinite(t) && t < best.t) { best.t = t; best.idx = i; }
-    }
-  } else if (ob.kind == PRIM_DISK) {                    // primitive_disk.cc:94-114
-    const V3 N = ld3(ob.e1);
-    const float cos_theta = Dot(d, N);
-    if (!(cos_theta == 0.0f)) {
-      const float t = Dot(A - o, N) / cos_theta;
-      if (!(t <= AMBER_KEPS)) {
-        const float sq = SquaredLength(o + t * d - A);
-        if (!(sq > ob.radius * ob.radius) && IsFinite(t) && t < best.t) { best.t = t; best.idx = i; }
-      }
-    }
-  } else {                                              // primitive_cylinder.cc:100-142
-    const V3 N = ld3(ob.e1);
-    const V3 OC = A - o;
-    const V3 uu = d - Dot(d, N) * N;
-    const V3 vv = OC - Dot(OC, N) * N;
-    const float a = SquaredLength(uu);
-    const float b = -2.0f * Dot(uu, vv);
-    const float c = SquaredLength(vv) - ob.radius * ob.radius;
-    float alpha, beta;
-    if (SolveQuadratic(a, b, c, alpha, beta)) {
-      bool ok = false; float t = 0.f;
-      if (alpha > AMBER_KEPS) {
-        const float h = Dot(alpha * d - OC, N);
-        if (h >= 0.0f && h <= ob.height) { ok = true; t = alpha; }
-      }
-      if (!ok && beta > AMBER_KEPS) {
-        const float h = Dot(beta * d - OC, N);
-        if (h >= 0.0f && h <= ob.height) { ok = true; t = beta; }
-      }
-      if (ok && IsFinite(t) && t < best.t) { best.t = t; best.idx = i; }
+// A hit replaces the best iff it is finite and strictly closer; kTie additionally lets an equally distant hit
+// of a LOWER object index win, which makes the result independent of the order in which candidates are visited
+// (the List scan visits indices in ascending order, where strict < alone already gives the lower index).
+template <bool kTie>
+__device__ __forceinline__ bool Closer(float t, int i, const HitRec& best) {
+  if (!IsFinite(t)) return false;
+  if (t < best.t) return true;
+  return kTie && t == best.t && i < best.idx;
+}
+
+template <bool kTie>
+__device__ __forceinline__ void IntersectTriangle(V3 A, V3 E1, V3 E2, int i, V3 o, V3 d, HitRec& best) {   // primitive_triangle.cc:97-128
+  const V3 P = Cross(d, E2);
+  const float det = Dot(P, E1);
+  const V3 T = o - A;
+  const float u = Dot(P, T) / det;
+  if (!(u > 1.0f || u < 0.0f)) {
+    const V3 Q = Cross(T, E1);
+    const float v = Dot(Q, d) / det;
+    if (!(v > 1.0f || v < 0.0f) && !(u + v > 1.0f)) {
+      const float t = Dot(Q, E2) / det;
+      if (!(t <= AMBER_KEPS) && Closer<kTie>(t, i, best)) { best.t = t; best.u = u; best.v = v; best.idx = i; }
     }
   }
 }
+template <bool kTie>
+__device__ __forceinline__ void IntersectSphere(V3 A, float radius, int i, V3 o, V3 d, HitRec& best) {      // primitive_sphere.cc:75-107
+  const V3 co = A - o;
+  const float b = -2.0f * Dot(co, d);
+  const float c = SquaredLength(co) - radius * radius;
+  float alpha, beta;
+  if (SolveQuadratic(1.0f, b, c, alpha, beta)) {
+    float t;
+    bool ok = true;
+    if (alpha > AMBER_KEPS) t = alpha; else if (beta > AMBER_KEPS) t = beta; else { ok = false; t = 0.f; }
+    if (ok && Closer<kTie>(t, i, best)) { best.t = t; best.idx = i; }
+  }
+}
+template <bool kTie>
+__device__ __forceinline__ void IntersectDisk(V3 A, V3 N, float radius, int i, V3 o, V3 d, HitRec& best) {  // primitive_disk.cc:94-114
+  const float cos_theta = Dot(d, N);
+  if (!(cos_theta == 0.0f)) {
+    const float t = Dot(A - o, N) / cos_theta;
+    if (!(t <= AMBER_KEPS)) {
+      const float sq = SquaredLength(o + t * d - A);
+      if (!(sq > radius * radius) && Closer<kTie>(t, i, best)) { best.t = t; best.idx = i; }
+    }
+  }
+}
+template <bool kTie>
+__device__ __forceinline__ void IntersectCylinder(V3 A, V3 N, float radius, float height, int i, V3 o, V3 d, HitRec& best) {   // primitive_cylinder.cc:100-142
+  const V3 OC = A - o;
+  const V3 uu = d - Dot(d, N) * N;
+  const V3 vv = OC - Dot(OC, N) * N;
+  const float a = SquaredLength(uu);
+  const float b = -2.0f * Dot(uu, vv);
+  const float c = SquaredLength(vv) - radius * radius;
+  float alpha, beta;
+  if (SolveQuadratic(a, b, c, alpha, beta)) {
+    bool ok = false; float t = 0.f;
+    if (alpha > AMBER_KEPS) {
+      const float h = Dot(alpha * d - OC, N);
+      if (h >= 0.0f && h <= height) { ok = true; t = alpha; }
+    }
+    if (!ok && beta > AMBER_KEPS) {
+      const float h = Dot(beta * d - OC, N);
+      if (h >= 0.0f && h <= height) { ok = true; t = beta; }
+    }
+    if (ok && Closer<kTie>(t, i, best)) { best.t = t; best.idx = i; }
+  }
+}
 
+template <bool kTie>
+__device__ __forceinline__ void IntersectObject(const DevObject& ob, int i, V3 o, V3 d, HitRec& best) {
+  const V3 A = ld3(ob.a);
+  if (ob.kind == PRIM_TRIANGLE) IntersectTriangle<kTie>(A, ld3(ob.e1), ld3(ob.e2), i, o, d, best);
+  else if (ob.kind == PRIM_SPHERE) IntersectSphere<kTie>(A, ob.radius, i, o, d, best);
+  else if (ob.kind == PRIM_DISK) IntersectDisk<kTie>(A, ld3(ob.e1), ob.radius, i, o, d, best);
+  else IntersectCylinder<kTie>(A, ld3(ob.e1), ob.radius, ob.height, i, o, d, best);
+}
+
+// Engine LIST: every object, exact test, wave-uniform index (object data in SGPRs).
 __device__ __forceinline__ void ClosestHitList(const DevScene& sc, V3 o, V3 d, HitRec& best) {
   best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1;   // Acceleration::Cast(ray, FLT_MAX)
   const int n = static_cast<int>(sc.n_objects);
   for (int i = 0; i < n; ++i) {
     const DevObject& ob = sc.objects[i];
-    IntersectObject(ob, i, o, d, best);
+    IntersectObject<false>(ob, i, o, d, best);
   }
+}
+
+// Engine TWO-PHASE (n_objects <= 32).
+//  Phase A, all lanes, wave-uniform object index, approximate arithmetic (FMA, v_rcp): a CONSERVATIVE filter that
+//  sets bit i of a per-lane mask unless object i certainly cannot pass the reference's exact test.  For a triangle:
+//  intersect the supporting plane, evaluate the barycentrics of the plane point as affine functions, and keep the
+//  object when they are inside [0,1] up to a tolerance that scales with 1/|n.d| (the conditioning of the
+//  reference's own arithmetic), when the ray is nearly parallel to the plane, or when anything is NaN.
+//  Phase B, per lane: the exact reference-arithmetic test (the same functions as engine LIST) on the candidates
+//  only, object records gathered from the LDS copy; the (t, index) tie rule makes the visiting order irrelevant.
+//  The result is identical to ClosestHitList (tests: full-image and per-ray equality of both engines).
+#define AMBER_GRAZING 1e-3f
+__device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const DevObject* lds_objects, V3 o, V3 d, HitRec& best) {
+  best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1;
+  const int n = static_cast<int>(sc.n_objects);
+  uint32_t cand = 0;
+  for (int i = 0; i < n; ++i) {
+    const DevFilter& f = sc.filters[i];
+    const uint32_t bit = 1u << i;
+    bool keep;
+    if (f.kind == PRIM_TRIANGLE) {
+      const float nd = __builtin_fmaf(f.n[0], d.x, __builtin_fmaf(f.n[1], d.y, f.n[2] * d.z));
+      const float no = __builtin_fmaf(f.n[0], o.x, __builtin_fmaf(f.n[1], o.y, f.n[2] * o.z));
+      const float rc = __builtin_amdgcn_rcpf(nd);
+      const float tp = (f.d0 - no) * rc;
+      const float rho = Abs(rc);
+      const float Px = __builtin_fmaf(tp, d.x, o.x), Py = __builtin_fmaf(tp, d.y, o.y), Pz = __builtin_fmaf(tp, d.z, o.z);
+      const float u = __builtin_fmaf(f.A[0], Px, __builtin_fmaf(f.A[1], Py, __builtin_fmaf(f.A[2], Pz, f.a0)));
+      const float v = __builtin_fmaf(f.B[0], Px, __builtin_fmaf(f.B[1], Py, __builtin_fmaf(f.B[2], Pz, f.b0)));
+      const float w = 1.0f - u - v;
+      const float m = __builtin_fminf(__builtin_fminf(u, v), w);
+      const bool inside = (m >= -f.ktol * rho) && (tp >= AMBER_KEPS - f.kt * rho);
+      const bool regular = Abs(nd) >= AMBER_GRAZING;          // false for NaN
+      keep = inside || !regular;
+    } else if (f.kind == PRIM_SPHERE) {
+      const float cx = f.n[0] - o.x, cy = f.n[1] - o.y, cz = f.n[2] - o.z;
+      const float bb = __builtin_fmaf(cx, d.x, __builtin_fmaf(cy, d.y, cz * d.z));       // co.d
+      const float c2 = __builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz));          // |co|^2
+      const float cc = c2 - f.d0;                                                         // |co|^2 - r^2
+      const float tol = f.ktol * (c2 + f.d0);
+      const bool miss = (__builtin_fmaf(bb, bb, -cc) < -tol) || (bb < -tol && cc > tol);  // no real root | both roots behind
+      keep = !miss;                                                                       // NaN -> keep
+    } else {
+      keep = true;                                                                        // disk, cylinder: always exact
+    }
+    cand |= keep ? bit : 0u;
+  }
+  // Phase B: triangles, then the rest (keeps the per-lane kind branch out of the hot loop)
+  uint32_t mt = cand & sc.tri_mask;
+  while (__any(mt != 0u)) {
+    if (mt != 0u) {
+      const int i = __builtin_ctz(mt);
+      mt &= mt - 1u;
+      const DevObject& ob = lds_objects[i];
+      IntersectTriangle<true>(ld3(ob.a), ld3(ob.e1), ld3(ob.e2), i, o, d, best);
+    }
+  }
+  uint32_t mo = cand & ~sc.tri_mask;
+  while (__any(mo != 0u)) {
+    if (mo != 0u) {
+      const int i = __builtin_ctz(mo);
+      mo &= mo - 1u;
+      const DevObject& ob = lds_objects[i];
+      IntersectObject<true>(ob, i, o, d, best);
+    }
+  }
+}
+
+template <bool kTwoPhase>
+__device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* lds_objects, V3 o, V3 d, HitRec& best) {
+  if (kTwoPhase) ClosestHitTwoPhase(sc, lds_objects, o, d, best);
+  else ClosestHitList(sc, o, d, best);
 }
 
 // position / normal of the winning hit, evaluated exactly as the reference's Intersect() does
@@ -288,6 +391,16 @@ __device__ __forceinline__ void ResolveHit(const DevScene& sc, const HitRec& h, 
     pos = o + h.t * d;
     normal = Normalize(o + h.t * d - A - hh * N);
   }
+}
+
+// Copies the object records into the workgroup's LDS image (two-phase engine only; n_objects <= 32).
+#define AMBER_MAX_LDS_OBJECTS 32
+__device__ __forceinline__ void StageObjects(const DevScene& sc, DevObject* lds_objects) {
+  const uint32_t n_dwords = sc.n_objects * (sizeof(DevObject) / 4u);
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.objects);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(lds_objects);
+  for (uint32_t k = threadIdx.x; k < n_dwords; k += blockDim.x) dst[k] = src[k];
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -409,11 +522,11 @@ __device__ __forceinline__ void GenerateEyeRay(const DevScene& sc, uint32_t px, 
 // ---------------------------------------------------------------------------------------------
 struct Bounce { int object; float t; V3 pos; V3 weight_before; };
 
-template <bool kTrace>
-__device__ __forceinline__ bool PathStep(const DevScene& sc, V3& o, V3& d, V3& weight, V3& measurement,
+template <bool kTrace, bool kTwoPhase>
+__device__ __forceinline__ bool PathStep(const DevScene& sc, const DevObject* lds_objects, V3& o, V3& d, V3& weight, V3& measurement,
                                          uint64_t& rng, uint32_t& casts, Bounce* trace) {
   HitRec h;
-  ClosestHitList(sc, o, d, h);
+  ClosestHit<kTwoPhase>(sc, lds_objects, o, d, h);
   casts++;
   if (h.idx < 0) {
     if (kTrace) { trace->object = -1; trace->t = __builtin_nanf(""); trace->pos = v3(0, 0, 0); trace->weight_before = v3(0, 0, 0); }

@@ -56,9 +56,12 @@ struct RenderArgs {
 // empty.  A lane walks the samples of its item in order (sum += measurement), regenerating the eye ray in
 // place when a path ends, and stores the item's sum to partial[chunk][pixel]; reduce_partials_kernel adds the
 // chunks to the framebuffer in chunk order.  The summation order is therefore fixed.
+template <bool kTwoPhase>
 __global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
+  __shared__ DevObject lds_objects[kTwoPhase ? AMBER_MAX_LDS_OBJECTS : 1];
+  if (kTwoPhase) StageObjects(sc, lds_objects);
 
   uint32_t pool_next = 0, pool_end = 0;      // wave-uniform: items claimed by this wave, not yet handed out
   bool exhausted = false;                    // wave-uniform: the global queue is empty
@@ -124,7 +127,7 @@ __global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
       ++s;
     }
     if (alive) {
-      alive = PathStep<false>(sc, o, d, w, meas, rng, casts, nullptr);
+      alive = PathStep<false, kTwoPhase>(sc, lds_objects, o, d, w, meas, rng, casts, nullptr);
       ++rays;
       if (!alive) sum = sum + meas;                         // sequential sum over the item's samples
     }
@@ -148,13 +151,16 @@ __global__ void reduce_partials_kernel(float* __restrict__ fb, const float* __re
 // ------------------------------------------------------------------------------------------------
 // known-answer kernels (same device functions)
 // ------------------------------------------------------------------------------------------------
+template <bool kTwoPhase>
 __global__ void kat_cast_kernel(const DevScene sc, uint32_t n, const float* org, const float* dir,
                                 int32_t* out_obj, float* out_t, float* out_pos, float* out_n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t k = i < n ? i : n - 1;      // keep the object loop wave-uniform for every lane
+  __shared__ DevObject lds_objects[kTwoPhase ? AMBER_MAX_LDS_OBJECTS : 1];
+  if (kTwoPhase) StageObjects(sc, lds_objects);
   const V3 o = ld3(org + 3 * k), d = ld3(dir + 3 * k);
   HitRec h;
-  ClosestHitList(sc, o, d, h);
+  ClosestHit<kTwoPhase>(sc, lds_objects, o, d, h);
   if (i >= n) return;
   out_obj[i] = h.idx;
   if (h.idx < 0) {
@@ -193,10 +199,13 @@ __global__ void kat_eye_kernel(const DevScene sc, uint64_t hashed_seed, uint32_t
   p[0] = o.x; p[1] = o.y; p[2] = o.z; p[3] = d.x; p[4] = d.y; p[5] = d.z; p[6] = w;
 }
 
+template <bool kTwoPhase>
 __global__ void kat_trace_kernel(const DevScene sc, uint64_t hashed_seed, uint32_t n, const uint32_t* pixel,
                                  const uint32_t* sample, uint32_t max_bounces, uint32_t* out_records, uint32_t* out_casts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t k = i < n ? i : n - 1;
+  __shared__ DevObject lds_objects[kTwoPhase ? AMBER_MAX_LDS_OBJECTS : 1];
+  if (kTwoPhase) StageObjects(sc, lds_objects);
   uint64_t rng = XorShiftSeed(hashed_seed, pixel[k], sample[k]);
   V3 o, d; float ew;
   GenerateEyeRay(sc, pixel[k] % sc.sensor.w, pixel[k] / sc.sensor.w, rng, o, d, ew);
@@ -207,7 +216,7 @@ __global__ void kat_trace_kernel(const DevScene sc, uint64_t hashed_seed, uint32
   while (__any(alive)) {
     if (alive) {
       Bounce b;
-      alive = PathStep<true>(sc, o, d, w, meas, rng, casts, &b);
+      alive = PathStep<true, kTwoPhase>(sc, lds_objects, o, d, w, meas, rng, casts, &b);
       if (i < n && casts <= max_bounces) {
         uint32_t* r = out_records + (static_cast<size_t>(i) * max_bounces + (casts - 1)) * 11u;
         r[0] = static_cast<uint32_t>(b.object);
@@ -241,6 +250,8 @@ struct amber_hip_pt {
   DevObject* d_objects = nullptr;
   DevMaterial* d_materials = nullptr;
   DevBlade* d_blades = nullptr;
+  DevFilter* d_filters = nullptr;
+  bool two_phase = false;
   float* d_fb = nullptr;
   unsigned long long* d_rays = nullptr;
   unsigned int* d_next = nullptr;
@@ -249,7 +260,7 @@ struct amber_hip_pt {
   int n_cus = 256;
   uint32_t row_begin = 0, row_end = 0, stripe_rows = 0, stripe_period = 0, local_rows = 0;
   uint64_t seed = 0, hashed_seed = 0;
-  uint32_t engine = AMBER_ENGINE_MEGAKERNEL;
+  uint32_t engine = AMBER_ENGINE_LIST;
   uint32_t n_materials = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per timed launch
   size_t events_used = 0;
@@ -270,6 +281,73 @@ struct DevBuf {
   ~DevBuf() { if (p) (void)hipFree(p); }
   hipError_t alloc(size_t n) { return hipMalloc(&p, (n ? n : 1) * sizeof(T)); }
 };
+
+// Phase-A records of the two-phase closest hit.  Everything here only has to be CONSERVATIVE: a candidate that
+// the filter keeps is decided by the exact reference-arithmetic test, so these values are computed in double and
+// rounded once.  Tolerances: the reference's binary32 Moeller-Trumbore has an absolute error of at most
+// ~6 eps (|o - v0| + 1.5 |E|) / |cos| in world units along the triangle's plane; with eps = 2^-24 and a safety
+// factor the bound used is  c / |n.d|,  c = 32 eps (scene diameter + 1.5 max edge), turned into barycentric units
+// with the gradient magnitudes of the affine barycentric maps.
+void BuildFilters(const std::vector<DevObject>& objs, std::vector<DevFilter>& filters, uint32_t& tri_mask) {
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, e_max = 0;
+  auto grow = [&](double x, double y, double z) {
+    const double p[3] = {x, y, z};
+    for (int c = 0; c < 3; c++) { if (p[c] < lo[c]) lo[c] = p[c]; if (p[c] > hi[c]) hi[c] = p[c]; }
+  };
+  for (const DevObject& o : objs) {
+    if (o.kind == AMBER_PRIM_TRIANGLE) {
+      grow(o.a[0], o.a[1], o.a[2]);
+      grow(o.a[0] + o.e1[0], o.a[1] + o.e1[1], o.a[2] + o.e1[2]);
+      grow(o.a[0] + o.e2[0], o.a[1] + o.e2[1], o.a[2] + o.e2[2]);
+      const double l1 = std::sqrt(double(o.e1[0]) * o.e1[0] + double(o.e1[1]) * o.e1[1] + double(o.e1[2]) * o.e1[2]);
+      const double l2 = std::sqrt(double(o.e2[0]) * o.e2[0] + double(o.e2[1]) * o.e2[1] + double(o.e2[2]) * o.e2[2]);
+      if (l1 > e_max) e_max = l1;
+      if (l2 > e_max) e_max = l2;
+    } else {
+      const double r = std::fabs(double(o.radius)) + std::fabs(double(o.height));
+      grow(o.a[0] - r, o.a[1] - r, o.a[2] - r); grow(o.a[0] + r, o.a[1] + r, o.a[2] + r);
+    }
+  }
+  const double diam = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+  const double c = 32.0 * 5.9604644775390625e-08 * (diam + 1.5 * e_max);
+  tri_mask = 0;
+  for (size_t i = 0; i < objs.size(); i++) {
+    const DevObject& o = objs[i];
+    DevFilter& f = filters[i];
+    std::memset(&f, 0, sizeof f);
+    f.kind = 0xffu;                                  // default: always a candidate
+    if (o.kind == AMBER_PRIM_TRIANGLE) {
+      if (i < 32) tri_mask |= 1u << i;
+      const double v0[3] = {o.a[0], o.a[1], o.a[2]}, E1[3] = {o.e1[0], o.e1[1], o.e1[2]}, E2[3] = {o.e2[0], o.e2[1], o.e2[2]};
+      const double nr[3] = {E1[1] * E2[2] - E1[2] * E2[1], E1[2] * E2[0] - E1[0] * E2[2], E1[0] * E2[1] - E1[1] * E2[0]};
+      const double n2 = nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2];
+      const double l1 = std::sqrt(E1[0] * E1[0] + E1[1] * E1[1] + E1[2] * E1[2]), l2 = std::sqrt(E2[0] * E2[0] + E2[1] * E2[1] + E2[2] * E2[2]);
+      if (!(n2 > 1e-60) || !std::isfinite(n2)) continue;
+      const double nl = std::sqrt(n2);
+      // u = A.(P - v0), A = (E2 x nr)/|nr|^2 ; v = B.(P - v0), B = (nr x E1)/|nr|^2
+      const double A[3] = {(E2[1] * nr[2] - E2[2] * nr[1]) / n2, (E2[2] * nr[0] - E2[0] * nr[2]) / n2, (E2[0] * nr[1] - E2[1] * nr[0]) / n2};
+      const double B[3] = {(nr[1] * E1[2] - nr[2] * E1[1]) / n2, (nr[2] * E1[0] - nr[0] * E1[2]) / n2, (nr[0] * E1[1] - nr[1] * E1[0]) / n2};
+      const double gA = std::sqrt(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]), gB = std::sqrt(B[0] * B[0] + B[1] * B[1] + B[2] * B[2]);
+      const double gAB = std::sqrt((A[0] + B[0]) * (A[0] + B[0]) + (A[1] + B[1]) * (A[1] + B[1]) + (A[2] + B[2]) * (A[2] + B[2]));
+      const double g = std::max(gA, std::max(gB, gAB));
+      const double inv_sin = l1 * l2 / nl;
+      f.kind = AMBER_PRIM_TRIANGLE;
+      for (int k = 0; k < 3; k++) { f.n[k] = static_cast<float>(nr[k] / nl); f.A[k] = static_cast<float>(A[k]); f.B[k] = static_cast<float>(B[k]); }
+      f.d0 = static_cast<float>((nr[0] * v0[0] + nr[1] * v0[1] + nr[2] * v0[2]) / nl);
+      f.a0 = static_cast<float>(-(A[0] * v0[0] + A[1] * v0[1] + A[2] * v0[2]));
+      f.b0 = static_cast<float>(-(B[0] * v0[0] + B[1] * v0[1] + B[2] * v0[2]));
+      f.ktol = static_cast<float>(c * g * 1.0001 + 1e-7);
+      f.kt = static_cast<float>(2.0 * c * std::max(1.0, inv_sin) + 1e-7);
+      if (!std::isfinite(f.ktol) || !std::isfinite(f.kt) || !std::isfinite(f.a0) || !std::isfinite(f.b0)) { std::memset(&f, 0, sizeof f); f.kind = 0xffu; }
+    } else if (o.kind == AMBER_PRIM_SPHERE) {
+      f.kind = AMBER_PRIM_SPHERE;
+      f.n[0] = o.a[0]; f.n[1] = o.a[1]; f.n[2] = o.a[2];
+      f.d0 = static_cast<float>(double(o.radius) * double(o.radius));
+      f.ktol = 1e-5f;
+      if (!std::isfinite(f.d0)) { std::memset(&f, 0, sizeof f); f.kind = 0xffu; }
+    }
+  }
+}
 
 int ValidateScene(const AmberFlatScene* s, const AmberSensor* sensor) {
   if (!s || !sensor) return Fail(AMBER_EINVAL, "null scene or sensor");
@@ -321,8 +399,10 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     const uint32_t q = (re - rb) / params->stripe_period, rem = (re - rb) % params->stripe_period;
     local_rows = q * params->stripe_rows + (rem < params->stripe_rows ? rem : params->stripe_rows);
   }
-  if (params->engine != AMBER_ENGINE_AUTO && params->engine != AMBER_ENGINE_MEGAKERNEL)
+  if (params->engine != AMBER_ENGINE_AUTO && params->engine != AMBER_ENGINE_LIST && params->engine != AMBER_ENGINE_TWO_PHASE)
     return Fail(AMBER_EINVAL, "engine not available in this build");
+  if (params->engine == AMBER_ENGINE_TWO_PHASE && s->n_objects > AMBER_MAX_LDS_OBJECTS)
+    return Fail(AMBER_EINVAL, "AMBER_ENGINE_TWO_PHASE supports at most 32 objects");
 
   HIP_TRY(hipSetDevice(params->device));
   auto* h = new amber_hip_pt();
@@ -373,6 +453,12 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     for (int c = 0; c < 3; c++) { blades[i].v0[c] = f.p[c]; blades[i].v1[c] = f.p[3 + c]; blades[i].v2[c] = f.p[6 + c]; blades[i].n[c] = f.p[9 + c]; }
   }
 
+  h->two_phase = params->engine == AMBER_ENGINE_TWO_PHASE || (params->engine == AMBER_ENGINE_AUTO && s->n_objects <= AMBER_MAX_LDS_OBJECTS);
+  h->engine = h->two_phase ? AMBER_ENGINE_TWO_PHASE : AMBER_ENGINE_LIST;
+  std::vector<DevFilter> filters(s->n_objects);
+  uint32_t tri_mask = 0;
+  BuildFilters(objs, filters, tri_mask);
+
   auto cleanup = [&](int code, const std::string& msg) { amber_hip_pt_destroy(h); return Fail(code, msg); };
 #define HIP_TRY_H(expr)                                                                            \
   do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cleanup(AMBER_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
@@ -380,6 +466,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMalloc(&h->d_objects, objs.size() * sizeof(DevObject)));
   HIP_TRY_H(hipMalloc(&h->d_materials, mats.size() * sizeof(DevMaterial)));
   HIP_TRY_H(hipMalloc(&h->d_blades, blades.size() * sizeof(DevBlade)));
+  HIP_TRY_H(hipMalloc(&h->d_filters, filters.size() * sizeof(DevFilter)));
+  HIP_TRY_H(hipMemcpy(h->d_filters, filters.data(), filters.size() * sizeof(DevFilter), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_objects, objs.data(), objs.size() * sizeof(DevObject), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_blades, blades.data(), blades.size() * sizeof(DevBlade), hipMemcpyHostToDevice));
@@ -392,7 +480,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMemsetAsync(h->d_rays, 0, sizeof(unsigned long long), h->stream));
 
   DevScene& sc = h->scene;
-  sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades;
+  sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades; sc.filters = h->d_filters;
+  sc.tri_mask = tri_mask;
   sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;
   h->n_materials = s->n_materials;
   std::memcpy(sc.lens.origin, L.origin, sizeof L.origin);
@@ -459,7 +548,8 @@ int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
     }
     auto& ev = h->events[h->events_used++];
     HIP_TRY(hipEventRecord(ev.first, h->stream));
-    hipLaunchKernelGGL(pt_megakernel, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    if (h->two_phase) hipLaunchKernelGGL(pt_megakernel<true>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL(pt_megakernel<false>, dim3(n_blocks), dim3(256), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, h->stream));
     const uint32_t n_elems = n_pixels * 3u;
@@ -536,6 +626,7 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_objects) (void)hipFree(h->d_objects);
   if (h->d_materials) (void)hipFree(h->d_materials);
   if (h->d_blades) (void)hipFree(h->d_blades);
+  if (h->d_filters) (void)hipFree(h->d_filters);
   if (h->d_fb) (void)hipFree(h->d_fb);
   if (h->d_rays) (void)hipFree(h->d_rays);
   if (h->d_next) (void)hipFree(h->d_next);
@@ -554,7 +645,8 @@ int amber_hip_kat_cast(amber_hip_pt* h, uint32_t n, const float* origins, const 
   HIP_TRY(d_o.alloc(3 * n)); HIP_TRY(d_d.alloc(3 * n)); HIP_TRY(d_t.alloc(n)); HIP_TRY(d_p.alloc(3 * n)); HIP_TRY(d_n.alloc(3 * n)); HIP_TRY(d_i.alloc(n));
   HIP_TRY(hipMemcpy(d_o.p, origins, 3ull * n * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_d.p, dirs, 3ull * n * 4, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(kat_cast_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
+  if (h->two_phase) hipLaunchKernelGGL(kat_cast_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
+  else hipLaunchKernelGGL(kat_cast_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out_object, d_i.p, 4ull * n, hipMemcpyDeviceToHost));
@@ -616,7 +708,8 @@ int amber_hip_kat_trace(amber_hip_pt* h, uint32_t n, const uint32_t* pixel, cons
   HIP_TRY(hipMemcpy(d_p.p, pixel, 4ull * n, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_s.p, sample, 4ull * n, hipMemcpyHostToDevice));
   HIP_TRY(hipMemsetAsync(d_r.p, 0, nrec * 4, h->stream));
-  hipLaunchKernelGGL(kat_trace_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
+  if (h->two_phase) hipLaunchKernelGGL(kat_trace_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
+  else hipLaunchKernelGGL(kat_trace_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out_records, d_r.p, nrec * 4, hipMemcpyDeviceToHost));

@@ -113,10 +113,11 @@ typedef struct {
   uint32_t reserved;    /* row_begin = r*S, row_end = height, stripe_period = N*S).  Local rows are compact. */
 } AmberPtParams;
 
+/* Both engines are the same persistent work-queue kernel; they differ in how a lane finds its closest hit. */
 enum {
-  AMBER_ENGINE_AUTO = 0,
-  AMBER_ENGINE_MEGAKERNEL = 1,  /* persistent per-lane path regeneration, scene in scalar registers */
-  AMBER_ENGINE_WAVEFRONT = 2    /* SoA ray streams in HBM, generate/extend/shade kernels, ballot compaction */
+  AMBER_ENGINE_AUTO = 0,       /* TWO_PHASE when the scene has <= 32 objects, LIST otherwise */
+  AMBER_ENGINE_LIST = 1,       /* exact test of every object, wave-uniform scan (object data in SGPRs) */
+  AMBER_ENGINE_TWO_PHASE = 2   /* conservative wave-uniform candidate filter, then exact tests of the candidates only */
 };
 
 typedef struct amber_hip_pt amber_hip_pt;
