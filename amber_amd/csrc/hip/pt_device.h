@@ -75,6 +75,11 @@ enum { MAT_LAMBERTIAN = 0, MAT_PHONG = 1, MAT_SPECULAR = 2, MAT_REFRACTION = 3, 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
 __device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+// Wave-uniform reads of scene records go through the constant address space: hipcc then emits scalar loads
+// (s_load_dwordx4/x8/x16, operands in SGPRs) even though the kernel also stores to global memory in its loop.
+typedef const uint32_t __attribute__((address_space(4)))* ConstWords;
+__device__ __forceinline__ float cw_f(ConstWords w, int k) { return __uint_as_float(w[k]); }
+__device__ __forceinline__ V3 cw_v3(ConstWords w, int k) { return V3{cw_f(w, k), cw_f(w, k + 1), cw_f(w, k + 2)}; }
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
@@ -293,9 +298,15 @@ __device__ __forceinline__ void IntersectObject(const DevObject& ob, int i, V3 o
 __device__ __forceinline__ void ClosestHitList(const DevScene& sc, V3 o, V3 d, HitRec& best) {
   best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1;   // Acceleration::Cast(ray, FLT_MAX)
   const int n = static_cast<int>(sc.n_objects);
+  const ConstWords base = (ConstWords)(sc.objects);
   for (int i = 0; i < n; ++i) {
-    const DevObject& ob = sc.objects[i];
-    IntersectObject<false>(ob, i, o, d, best);
+    const ConstWords w = base + i * 16;                 // DevObject = 16 dwords
+    const uint32_t kind = w[3];
+    const V3 A = cw_v3(w, 0);
+    if (kind == PRIM_TRIANGLE) IntersectTriangle<false>(A, cw_v3(w, 4), cw_v3(w, 8), i, o, d, best);
+    else if (kind == PRIM_SPHERE) IntersectSphere<false>(A, cw_f(w, 7), i, o, d, best);
+    else if (kind == PRIM_DISK) IntersectDisk<false>(A, cw_v3(w, 4), cw_f(w, 7), i, o, d, best);
+    else IntersectCylinder<false>(A, cw_v3(w, 4), cw_f(w, 7), cw_f(w, 11), i, o, d, best);
   }
 }
 
@@ -313,34 +324,37 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
   best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1;
   const int n = static_cast<int>(sc.n_objects);
   uint32_t cand = 0;
+  const ConstWords fbase = (ConstWords)(sc.filters);
   for (int i = 0; i < n; ++i) {
-    const DevFilter& f = sc.filters[i];
+    const ConstWords f = fbase + i * 16;                // DevFilter = 16 dwords: n d0 | A a0 | B b0 | ktol kt kind pad
     const uint32_t bit = 1u << i;
+    const uint32_t kind = f[14];
     bool keep;
-    if (f.kind == PRIM_TRIANGLE) {
-      const float nd = __builtin_fmaf(f.n[0], d.x, __builtin_fmaf(f.n[1], d.y, f.n[2] * d.z));
-      const float no = __builtin_fmaf(f.n[0], o.x, __builtin_fmaf(f.n[1], o.y, f.n[2] * o.z));
+    if (kind == PRIM_TRIANGLE) {
+      const float nd = __builtin_fmaf(cw_f(f, 0), d.x, __builtin_fmaf(cw_f(f, 1), d.y, cw_f(f, 2) * d.z));
+      const float no = __builtin_fmaf(cw_f(f, 0), o.x, __builtin_fmaf(cw_f(f, 1), o.y, cw_f(f, 2) * o.z));
       const float rc = __builtin_amdgcn_rcpf(nd);
-      const float tp = (f.d0 - no) * rc;
+      const float tp = (cw_f(f, 3) - no) * rc;
       const float rho = Abs(rc);
       const float Px = __builtin_fmaf(tp, d.x, o.x), Py = __builtin_fmaf(tp, d.y, o.y), Pz = __builtin_fmaf(tp, d.z, o.z);
-      const float u = __builtin_fmaf(f.A[0], Px, __builtin_fmaf(f.A[1], Py, __builtin_fmaf(f.A[2], Pz, f.a0)));
-      const float v = __builtin_fmaf(f.B[0], Px, __builtin_fmaf(f.B[1], Py, __builtin_fmaf(f.B[2], Pz, f.b0)));
+      const float u = __builtin_fmaf(cw_f(f, 4), Px, __builtin_fmaf(cw_f(f, 5), Py, __builtin_fmaf(cw_f(f, 6), Pz, cw_f(f, 7))));
+      const float v = __builtin_fmaf(cw_f(f, 8), Px, __builtin_fmaf(cw_f(f, 9), Py, __builtin_fmaf(cw_f(f, 10), Pz, cw_f(f, 11))));
       const float w = 1.0f - u - v;
       const float m = __builtin_fminf(__builtin_fminf(u, v), w);
-      const bool inside = (m >= -f.ktol * rho) && (tp >= AMBER_KEPS - f.kt * rho);
+      const bool inside = (m >= -cw_f(f, 12) * rho) && (tp >= AMBER_KEPS - cw_f(f, 13) * rho);
       const bool regular = Abs(nd) >= AMBER_GRAZING;          // false for NaN
       keep = inside || !regular;
-    } else if (f.kind == PRIM_SPHERE) {
-      const float cx = f.n[0] - o.x, cy = f.n[1] - o.y, cz = f.n[2] - o.z;
+    } else if (kind == PRIM_SPHERE) {
+      const float cx = cw_f(f, 0) - o.x, cy = cw_f(f, 1) - o.y, cz = cw_f(f, 2) - o.z;
       const float bb = __builtin_fmaf(cx, d.x, __builtin_fmaf(cy, d.y, cz * d.z));       // co.d
       const float c2 = __builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz));          // |co|^2
-      const float cc = c2 - f.d0;                                                         // |co|^2 - r^2
-      const float tol = f.ktol * (c2 + f.d0);
-      const bool miss = (__builtin_fmaf(bb, bb, -cc) < -tol) || (bb < -tol && cc > tol);  // no real root | both roots behind
+      const float r2 = cw_f(f, 3);
+      const float cc = c2 - r2;                                                           // |co|^2 - r^2
+      const float tol = cw_f(f, 12) * (c2 + r2);
+      const bool miss = (__builtin_fmaf(bb, bb, -cc) < -tol) || (bb < 0.0f && cc > tol);  // no real root | both roots behind
       keep = !miss;                                                                       // NaN -> keep
     } else {
-      keep = true;                                                                        // disk, cylinder: always exact
+      keep = true;                                                                        // disk, cylinder, degenerate: always exact
     }
     cand |= keep ? bit : 0u;
   }
@@ -372,8 +386,8 @@ __device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* 
 }
 
 // position / normal of the winning hit, evaluated exactly as the reference's Intersect() does
-__device__ __forceinline__ void ResolveHit(const DevScene& sc, const HitRec& h, V3 o, V3 d, V3& pos, V3& normal, uint32_t& material) {
-  const DevObject* ob = sc.objects + h.idx;
+__device__ __forceinline__ void ResolveHit(const DevObject* objects, const HitRec& h, V3 o, V3 d, V3& pos, V3& normal, uint32_t& material) {
+  const DevObject* ob = objects + h.idx;
   const uint32_t kind = ob->kind;
   material = ob->material;
   const V3 A = ld3(ob->a);
@@ -533,7 +547,7 @@ __device__ __forceinline__ bool PathStep(const DevScene& sc, const DevObject* ld
     return false;
   }
   V3 pos, normal; uint32_t mat;
-  ResolveHit(sc, h, o, d, pos, normal, mat);
+  ResolveHit(kTwoPhase ? lds_objects : sc.objects, h, o, d, pos, normal, mat);
   const DevMaterial m = sc.materials[mat];
   const V3 dir_out = -d;
   if (kTrace) { trace->object = h.idx; trace->t = h.t; trace->pos = pos; trace->weight_before = weight; }

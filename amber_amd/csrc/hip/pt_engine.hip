@@ -169,7 +169,7 @@ __global__ void kat_cast_kernel(const DevScene sc, uint32_t n, const float* org,
     return;
   }
   V3 pos, nrm; uint32_t mat;
-  ResolveHit(sc, h, o, d, pos, nrm, mat);
+  ResolveHit(kTwoPhase ? lds_objects : sc.objects, h, o, d, pos, nrm, mat);
   out_t[i] = h.t;
   out_pos[3 * i] = pos.x; out_pos[3 * i + 1] = pos.y; out_pos[3 * i + 2] = pos.z;
   out_n[3 * i] = nrm.x; out_n[3 * i + 1] = nrm.y; out_n[3 * i + 2] = nrm.z;
