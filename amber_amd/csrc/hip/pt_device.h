@@ -15,6 +15,27 @@
 
 namespace amber_dev {
 
+// Diagnostic build only (-DAMBER_STAMPS, tools/stamps.py): s_memtime stamps around the sections of one loop
+// iteration, summed per wave.  Never compiled into libamber_hip.so; the stamped build's run time is not quoted.
+#ifdef AMBER_STAMPS
+struct StampCtx { unsigned long long last; unsigned long long acc[8]; };
+__device__ __forceinline__ void StampAt(StampCtx* c, int k) {
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long t = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  c->acc[k] += t - c->last;
+  c->last = t;
+  __builtin_amdgcn_sched_barrier(0);
+}
+#define AMBER_STAMP_PARAM , StampCtx* stamp_ctx
+#define AMBER_STAMP_ARG , stamp_ctx
+#define AMBER_STAMP(k) StampAt(stamp_ctx, k)
+#else
+#define AMBER_STAMP_PARAM
+#define AMBER_STAMP_ARG
+#define AMBER_STAMP(k)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // device-side scene layout (HBM, read through the scalar cache when the index is wave-uniform)
 // ---------------------------------------------------------------------------------------------
@@ -31,13 +52,23 @@ struct alignas(16) DevMaterial {  // 32 B
 struct alignas(16) DevBlade {     // 48 B: aperture triangle with explicit vertices (SampleSurfacePoint)
   float v0[3], v1[3], v2[3], n[3];
 };
-// Phase-A record of the two-phase closest hit (conservative candidate filter).
-struct alignas(16) DevFilter {   // 64 B, scalar-loaded
-  float n[3];  float d0;          // triangle: unit plane normal, n.v0        | sphere: centre, radius^2
-  float A[3];  float a0;          // triangle: u = A.P + a0 for P on the plane
-  float B[3];  float b0;          //           v = B.P + b0
-  float ktol;  float kt;          // tolerance coefficients (multiplied by |1/(n.d)|) | sphere: relative tolerance
-  uint32_t kind; uint32_t pad;
+// Phase-A program of the two-phase closest hit (conservative candidate filter): coplanar
+// triangles share one plane record, so the plane hit point is computed once per plane.  All wave-uniform, scalar-loaded.
+struct alignas(16) DevPlane {       // 32 B
+  float n[3]; float d0;             // unit normal, n.v0
+  float kt;                         // tolerance of the t >= kEPS test (multiplied by |1/(n.d)|)
+  uint32_t first_tri, n_tris, pad;
+};
+struct alignas(16) DevTriFilter {   // 48 B
+  float A[3]; float a0;             // u = A.P + a0 for P on the plane
+  float B[3]; float b0;             // v = B.P + b0
+  float ktol;                       // barycentric tolerance (multiplied by |1/(n.d)|)
+  uint32_t bit;                     // 1 << object index
+  uint32_t pad[2];
+};
+struct alignas(16) DevSphereFilter { // 32 B
+  float c[3]; float r2;
+  float ktol; uint32_t bit; uint32_t pad[2];
 };
 struct DevLens {
   float origin[3];
@@ -58,7 +89,11 @@ struct DevScene {
   const DevObject* __restrict__ objects;
   const DevMaterial* __restrict__ materials;
   const DevBlade* __restrict__ blades;
-  const DevFilter* __restrict__ filters;
+  const DevPlane* __restrict__ planes;
+  const DevTriFilter* __restrict__ tri_filters;
+  const DevSphereFilter* __restrict__ sphere_filters;
+  uint32_t n_planes, n_sphere_filters;
+  uint32_t always_mask;        // objects that are always candidates (disks, cylinders, degenerate triangles)
   uint32_t n_objects;
   uint32_t max_depth;
   uint32_t tri_mask;           // bit i set: object i is a triangle (two-phase path, n_objects <= 32)
@@ -320,44 +355,47 @@ __device__ __forceinline__ void ClosestHitList(const DevScene& sc, V3 o, V3 d, H
 //  only, object records gathered from the LDS copy; the (t, index) tie rule makes the visiting order irrelevant.
 //  The result is identical to ClosestHitList (tests: full-image and per-ray equality of both engines).
 #define AMBER_GRAZING 1e-3f
-__device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const DevObject* lds_objects, V3 o, V3 d, HitRec& best) {
+__device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const DevObject* lds_objects, V3 o, V3 d, HitRec& best AMBER_STAMP_PARAM) {
   best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1;
-  const int n = static_cast<int>(sc.n_objects);
-  uint32_t cand = 0;
-  const ConstWords fbase = (ConstWords)(sc.filters);
-  for (int i = 0; i < n; ++i) {
-    const ConstWords f = fbase + i * 16;                // DevFilter = 16 dwords: n d0 | A a0 | B b0 | ktol kt kind pad
-    const uint32_t bit = 1u << i;
-    const uint32_t kind = f[14];
-    bool keep;
-    if (kind == PRIM_TRIANGLE) {
-      const float nd = __builtin_fmaf(cw_f(f, 0), d.x, __builtin_fmaf(cw_f(f, 1), d.y, cw_f(f, 2) * d.z));
-      const float no = __builtin_fmaf(cw_f(f, 0), o.x, __builtin_fmaf(cw_f(f, 1), o.y, cw_f(f, 2) * o.z));
+  uint32_t cand = sc.always_mask;
+  {
+    ConstWords pl = (ConstWords)(sc.planes);
+    const ConstWords tris = (ConstWords)(sc.tri_filters);
+    const int n_planes = static_cast<int>(sc.n_planes);
+    for (int p = 0; p < n_planes; ++p, pl += 8) {           // DevPlane = 8 dwords
+      const float nd = __builtin_fmaf(cw_f(pl, 0), d.x, __builtin_fmaf(cw_f(pl, 1), d.y, cw_f(pl, 2) * d.z));
+      const float no = __builtin_fmaf(cw_f(pl, 0), o.x, __builtin_fmaf(cw_f(pl, 1), o.y, cw_f(pl, 2) * o.z));
       const float rc = __builtin_amdgcn_rcpf(nd);
-      const float tp = (cw_f(f, 3) - no) * rc;
+      const float tp = (cw_f(pl, 3) - no) * rc;
       const float rho = Abs(rc);
       const float Px = __builtin_fmaf(tp, d.x, o.x), Py = __builtin_fmaf(tp, d.y, o.y), Pz = __builtin_fmaf(tp, d.z, o.z);
-      const float u = __builtin_fmaf(cw_f(f, 4), Px, __builtin_fmaf(cw_f(f, 5), Py, __builtin_fmaf(cw_f(f, 6), Pz, cw_f(f, 7))));
-      const float v = __builtin_fmaf(cw_f(f, 8), Px, __builtin_fmaf(cw_f(f, 9), Py, __builtin_fmaf(cw_f(f, 10), Pz, cw_f(f, 11))));
-      const float w = 1.0f - u - v;
-      const float m = __builtin_fminf(__builtin_fminf(u, v), w);
-      const bool inside = (m >= -cw_f(f, 12) * rho) && (tp >= AMBER_KEPS - cw_f(f, 13) * rho);
-      const bool regular = Abs(nd) >= AMBER_GRAZING;          // false for NaN
-      keep = inside || !regular;
-    } else if (kind == PRIM_SPHERE) {
-      const float cx = cw_f(f, 0) - o.x, cy = cw_f(f, 1) - o.y, cz = cw_f(f, 2) - o.z;
+      const bool t_ok = tp >= AMBER_KEPS - cw_f(pl, 4) * rho;
+      const bool grazing = !(Abs(nd) >= AMBER_GRAZING);     // true for NaN
+      ConstWords tr = tris + pl[5] * 12u;                   // DevTriFilter = 12 dwords
+      const int nt = static_cast<int>(pl[6]);
+      for (int k = 0; k < nt; ++k, tr += 12) {
+        const float u = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 1), Py, __builtin_fmaf(cw_f(tr, 2), Pz, cw_f(tr, 3))));
+        const float v = __builtin_fmaf(cw_f(tr, 4), Px, __builtin_fmaf(cw_f(tr, 5), Py, __builtin_fmaf(cw_f(tr, 6), Pz, cw_f(tr, 7))));
+        const float w = 1.0f - u - v;
+        const float m = __builtin_fminf(__builtin_fminf(u, v), w);
+        const bool keep = ((m >= -cw_f(tr, 8) * rho) && t_ok) || grazing;
+        cand |= keep ? tr[9] : 0u;
+      }
+    }
+    ConstWords sp = (ConstWords)(sc.sphere_filters);
+    const int ns = static_cast<int>(sc.n_sphere_filters);
+    for (int k = 0; k < ns; ++k, sp += 8) {                 // DevSphereFilter = 8 dwords
+      const float cx = cw_f(sp, 0) - o.x, cy = cw_f(sp, 1) - o.y, cz = cw_f(sp, 2) - o.z;
       const float bb = __builtin_fmaf(cx, d.x, __builtin_fmaf(cy, d.y, cz * d.z));       // co.d
       const float c2 = __builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz));          // |co|^2
-      const float r2 = cw_f(f, 3);
+      const float r2 = cw_f(sp, 3);
       const float cc = c2 - r2;                                                           // |co|^2 - r^2
-      const float tol = cw_f(f, 12) * (c2 + r2);
+      const float tol = cw_f(sp, 4) * (c2 + r2);
       const bool miss = (__builtin_fmaf(bb, bb, -cc) < -tol) || (bb < 0.0f && cc > tol);  // no real root | both roots behind
-      keep = !miss;                                                                       // NaN -> keep
-    } else {
-      keep = true;                                                                        // disk, cylinder, degenerate: always exact
+      cand |= miss ? 0u : sp[5];                                                          // NaN -> keep
     }
-    cand |= keep ? bit : 0u;
   }
+  AMBER_STAMP(2);
   // Phase B: triangles, then the rest (keeps the per-lane kind branch out of the hot loop)
   uint32_t mt = cand & sc.tri_mask;
   while (__any(mt != 0u)) {
@@ -380,9 +418,10 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
 }
 
 template <bool kTwoPhase>
-__device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* lds_objects, V3 o, V3 d, HitRec& best) {
-  if (kTwoPhase) ClosestHitTwoPhase(sc, lds_objects, o, d, best);
+__device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* lds_objects, V3 o, V3 d, HitRec& best AMBER_STAMP_PARAM) {
+  if (kTwoPhase) ClosestHitTwoPhase(sc, lds_objects, o, d, best AMBER_STAMP_ARG);
   else ClosestHitList(sc, o, d, best);
+  AMBER_STAMP(3);
 }
 
 // position / normal of the winning hit, evaluated exactly as the reference's Intersect() does
@@ -538,9 +577,9 @@ struct Bounce { int object; float t; V3 pos; V3 weight_before; };
 
 template <bool kTrace, bool kTwoPhase>
 __device__ __forceinline__ bool PathStep(const DevScene& sc, const DevObject* lds_objects, V3& o, V3& d, V3& weight, V3& measurement,
-                                         uint64_t& rng, uint32_t& casts, Bounce* trace) {
+                                         uint64_t& rng, uint32_t& casts, Bounce* trace AMBER_STAMP_PARAM) {
   HitRec h;
-  ClosestHit<kTwoPhase>(sc, lds_objects, o, d, h);
+  ClosestHit<kTwoPhase>(sc, lds_objects, o, d, h AMBER_STAMP_ARG);
   casts++;
   if (h.idx < 0) {
     if (kTrace) { trace->object = -1; trace->t = __builtin_nanf(""); trace->pos = v3(0, 0, 0); trace->weight_before = v3(0, 0, 0); }
@@ -552,8 +591,10 @@ __device__ __forceinline__ bool PathStep(const DevScene& sc, const DevObject* ld
   const V3 dir_out = -d;
   if (kTrace) { trace->object = h.idx; trace->t = h.t; trace->pos = pos; trace->weight_before = weight; }
   measurement = measurement + weight * Radiance(m, normal, dir_out);        // algorithm_pt.cc:144
+  AMBER_STAMP(4);
   V3 dir_in, sw;
   SampleLight(m, normal, dir_out, rng, dir_in, sw);                          // :145-146
+  AMBER_STAMP(5);
   float p_rr = 0.9375f;                                                      // std::min<real_type>(kRussianRoulette, Max(w)) :148-149
   const float mw = Max3(sw);
   if (mw < p_rr) p_rr = mw;

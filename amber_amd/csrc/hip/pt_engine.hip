@@ -42,6 +42,7 @@ struct RenderArgs {
   float* partial;            // [n_chunks][n_pixels][3] per-item sums of this launch
   unsigned long long* ray_count;
   unsigned int* next_item;   // work-queue head (zeroed before every launch)
+  unsigned long long* stamps; // diagnostic build only (AMBER_STAMPS): 8 section sums
   uint64_t hashed_seed;      // SplitMix64(global_seed)
   uint32_t row_begin;
   uint32_t stripe_rows, stripe_period;   // 0,0 = contiguous rows
@@ -71,8 +72,13 @@ __global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
   V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), w = v3(0.f, 0.f, 0.f);
   uint64_t rng = 1;
   uint32_t casts = 0, rays = 0;
+#ifdef AMBER_STAMPS
+  StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
+  stamp_ctx->last = __builtin_amdgcn_s_memtime();
+#endif
 
   for (;;) {
+    AMBER_STAMP(6);
     bool need = !alive && s >= s_end && !lane_done;
     if (need && have_item) {                                // item finished: publish its sum
       float* p = a.partial + static_cast<size_t>(slot) * 3u;
@@ -116,6 +122,7 @@ __global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
     if (need) lane_done = true;                             // queue empty: this lane retires
     if (__ballot(!lane_done) == 0ull) break;
 
+    AMBER_STAMP(0);
     if (!alive && !lane_done) {                             // regenerate: next sample of the item
       rng = XorShiftSeed(a.hashed_seed, pixel, s);
       float ew;
@@ -126,13 +133,17 @@ __global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
       alive = true;
       ++s;
     }
+    AMBER_STAMP(1);
     if (alive) {
-      alive = PathStep<false, kTwoPhase>(sc, lds_objects, o, d, w, meas, rng, casts, nullptr);
+      alive = PathStep<false, kTwoPhase>(sc, lds_objects, o, d, w, meas, rng, casts, nullptr AMBER_STAMP_ARG);
       ++rays;
       if (!alive) sum = sum + meas;                         // sequential sum over the item's samples
     }
   }
 
+#ifdef AMBER_STAMPS
+  if (lane == 0 && a.stamps) for (int k = 0; k < 8; k++) atomicAdd(a.stamps + k, stamp_ctx->acc[k]);
+#endif
   // one atomic per wave for the ray counter
   unsigned long long r = rays;
   for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
@@ -160,7 +171,10 @@ __global__ void kat_cast_kernel(const DevScene sc, uint32_t n, const float* org,
   if (kTwoPhase) StageObjects(sc, lds_objects);
   const V3 o = ld3(org + 3 * k), d = ld3(dir + 3 * k);
   HitRec h;
-  ClosestHit<kTwoPhase>(sc, lds_objects, o, d, h);
+#ifdef AMBER_STAMPS
+  StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
+#endif
+  ClosestHit<kTwoPhase>(sc, lds_objects, o, d, h AMBER_STAMP_ARG);
   if (i >= n) return;
   out_obj[i] = h.idx;
   if (h.idx < 0) {
@@ -216,7 +230,10 @@ __global__ void kat_trace_kernel(const DevScene sc, uint64_t hashed_seed, uint32
   while (__any(alive)) {
     if (alive) {
       Bounce b;
-      alive = PathStep<true, kTwoPhase>(sc, lds_objects, o, d, w, meas, rng, casts, &b);
+#ifdef AMBER_STAMPS
+      StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
+#endif
+      alive = PathStep<true, kTwoPhase>(sc, lds_objects, o, d, w, meas, rng, casts, &b AMBER_STAMP_ARG);
       if (i < n && casts <= max_bounces) {
         uint32_t* r = out_records + (static_cast<size_t>(i) * max_bounces + (casts - 1)) * 11u;
         r[0] = static_cast<uint32_t>(b.object);
@@ -250,11 +267,14 @@ struct amber_hip_pt {
   DevObject* d_objects = nullptr;
   DevMaterial* d_materials = nullptr;
   DevBlade* d_blades = nullptr;
-  DevFilter* d_filters = nullptr;
+  DevPlane* d_planes = nullptr;
+  DevTriFilter* d_tri_filters = nullptr;
+  DevSphereFilter* d_sphere_filters = nullptr;
   bool two_phase = false;
   float* d_fb = nullptr;
   unsigned long long* d_rays = nullptr;
   unsigned int* d_next = nullptr;
+  unsigned long long* d_stamps = nullptr;
   float* d_partial = nullptr;
   size_t partial_floats = 0;
   int n_cus = 256;
@@ -282,70 +302,103 @@ struct DevBuf {
   hipError_t alloc(size_t n) { return hipMalloc(&p, (n ? n : 1) * sizeof(T)); }
 };
 
-// Phase-A records of the two-phase closest hit.  Everything here only has to be CONSERVATIVE: a candidate that
+// Phase-A program of the two-phase closest hit.  Everything here only has to be CONSERVATIVE: a candidate that
 // the filter keeps is decided by the exact reference-arithmetic test, so these values are computed in double and
 // rounded once.  Tolerances: the reference's binary32 Moeller-Trumbore has an absolute error of at most
 // ~6 eps (|o - v0| + 1.5 |E|) / |cos| in world units along the triangle's plane; with eps = 2^-24 and a safety
 // factor the bound used is  c / |n.d|,  c = 32 eps (scene diameter + 1.5 max edge), turned into barycentric units
-// with the gradient magnitudes of the affine barycentric maps.
-void BuildFilters(const std::vector<DevObject>& objs, std::vector<DevFilter>& filters, uint32_t& tri_mask) {
+// with the gradient magnitudes of the affine barycentric maps.  Coplanar triangles (all vertices within 4 eps of
+// the scene diameter of the first triangle's plane) share a plane record; their distance to it joins the tolerance.
+struct FilterProgram {
+  std::vector<DevPlane> planes;
+  std::vector<DevTriFilter> tris;
+  std::vector<DevSphereFilter> spheres;
+  uint32_t tri_mask = 0, always_mask = 0;
+};
+
+void BuildFilterProgram(const std::vector<DevObject>& objs, FilterProgram& fp) {
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, e_max = 0;
   auto grow = [&](double x, double y, double z) {
     const double p[3] = {x, y, z};
     for (int c = 0; c < 3; c++) { if (p[c] < lo[c]) lo[c] = p[c]; if (p[c] > hi[c]) hi[c] = p[c]; }
   };
+  auto len3 = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
   for (const DevObject& o : objs) {
     if (o.kind == AMBER_PRIM_TRIANGLE) {
       grow(o.a[0], o.a[1], o.a[2]);
-      grow(o.a[0] + o.e1[0], o.a[1] + o.e1[1], o.a[2] + o.e1[2]);
-      grow(o.a[0] + o.e2[0], o.a[1] + o.e2[1], o.a[2] + o.e2[2]);
-      const double l1 = std::sqrt(double(o.e1[0]) * o.e1[0] + double(o.e1[1]) * o.e1[1] + double(o.e1[2]) * o.e1[2]);
-      const double l2 = std::sqrt(double(o.e2[0]) * o.e2[0] + double(o.e2[1]) * o.e2[1] + double(o.e2[2]) * o.e2[2]);
-      if (l1 > e_max) e_max = l1;
-      if (l2 > e_max) e_max = l2;
+      grow(double(o.a[0]) + o.e1[0], double(o.a[1]) + o.e1[1], double(o.a[2]) + o.e1[2]);
+      grow(double(o.a[0]) + o.e2[0], double(o.a[1]) + o.e2[1], double(o.a[2]) + o.e2[2]);
+      const double E1[3] = {o.e1[0], o.e1[1], o.e1[2]}, E2[3] = {o.e2[0], o.e2[1], o.e2[2]};
+      e_max = std::max(e_max, std::max(len3(E1), len3(E2)));
     } else {
       const double r = std::fabs(double(o.radius)) + std::fabs(double(o.height));
       grow(o.a[0] - r, o.a[1] - r, o.a[2] - r); grow(o.a[0] + r, o.a[1] + r, o.a[2] + r);
     }
   }
   const double diam = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
-  const double c = 32.0 * 5.9604644775390625e-08 * (diam + 1.5 * e_max);
-  tri_mask = 0;
-  for (size_t i = 0; i < objs.size(); i++) {
+  const double eps = 5.9604644775390625e-08;
+  const double c = 32.0 * eps * (diam + 1.5 * e_max);
+  struct Group { double n[3], d0, kt; std::vector<DevTriFilter> tris; };
+  std::vector<Group> groups;
+  for (size_t i = 0; i < objs.size() && i < 32; i++) {
     const DevObject& o = objs[i];
-    DevFilter& f = filters[i];
-    std::memset(&f, 0, sizeof f);
-    f.kind = 0xffu;                                  // default: always a candidate
+    const uint32_t bit = 1u << i;
     if (o.kind == AMBER_PRIM_TRIANGLE) {
-      if (i < 32) tri_mask |= 1u << i;
+      fp.tri_mask |= bit;
       const double v0[3] = {o.a[0], o.a[1], o.a[2]}, E1[3] = {o.e1[0], o.e1[1], o.e1[2]}, E2[3] = {o.e2[0], o.e2[1], o.e2[2]};
       const double nr[3] = {E1[1] * E2[2] - E1[2] * E2[1], E1[2] * E2[0] - E1[0] * E2[2], E1[0] * E2[1] - E1[1] * E2[0]};
       const double n2 = nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2];
-      const double l1 = std::sqrt(E1[0] * E1[0] + E1[1] * E1[1] + E1[2] * E1[2]), l2 = std::sqrt(E2[0] * E2[0] + E2[1] * E2[1] + E2[2] * E2[2]);
-      if (!(n2 > 1e-60) || !std::isfinite(n2)) continue;
+      if (!(n2 > 1e-60) || !std::isfinite(n2)) { fp.always_mask |= bit; continue; }
       const double nl = std::sqrt(n2);
+      const double n[3] = {nr[0] / nl, nr[1] / nl, nr[2] / nl};
+      const double d0 = n[0] * v0[0] + n[1] * v0[1] + n[2] * v0[2];
       // u = A.(P - v0), A = (E2 x nr)/|nr|^2 ; v = B.(P - v0), B = (nr x E1)/|nr|^2
       const double A[3] = {(E2[1] * nr[2] - E2[2] * nr[1]) / n2, (E2[2] * nr[0] - E2[0] * nr[2]) / n2, (E2[0] * nr[1] - E2[1] * nr[0]) / n2};
       const double B[3] = {(nr[1] * E1[2] - nr[2] * E1[1]) / n2, (nr[2] * E1[0] - nr[0] * E1[2]) / n2, (nr[0] * E1[1] - nr[1] * E1[0]) / n2};
-      const double gA = std::sqrt(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]), gB = std::sqrt(B[0] * B[0] + B[1] * B[1] + B[2] * B[2]);
-      const double gAB = std::sqrt((A[0] + B[0]) * (A[0] + B[0]) + (A[1] + B[1]) * (A[1] + B[1]) + (A[2] + B[2]) * (A[2] + B[2]));
-      const double g = std::max(gA, std::max(gB, gAB));
-      const double inv_sin = l1 * l2 / nl;
-      f.kind = AMBER_PRIM_TRIANGLE;
-      for (int k = 0; k < 3; k++) { f.n[k] = static_cast<float>(nr[k] / nl); f.A[k] = static_cast<float>(A[k]); f.B[k] = static_cast<float>(B[k]); }
-      f.d0 = static_cast<float>((nr[0] * v0[0] + nr[1] * v0[1] + nr[2] * v0[2]) / nl);
+      const double AB[3] = {A[0] + B[0], A[1] + B[1], A[2] + B[2]};
+      const double g = std::max(len3(A), std::max(len3(B), len3(AB)));
+      const double inv_sin = len3(E1) * len3(E2) / nl;
+      // find a plane group that contains all three vertices
+      const double verts[3][3] = {{v0[0], v0[1], v0[2]}, {v0[0] + E1[0], v0[1] + E1[1], v0[2] + E1[2]}, {v0[0] + E2[0], v0[1] + E2[1], v0[2] + E2[2]}};
+      Group* grp = nullptr; double dist = 0;
+      for (Group& gq : groups) {
+        double dmax = 0;
+        for (const auto& vtx : verts) dmax = std::max(dmax, std::fabs(gq.n[0] * vtx[0] + gq.n[1] * vtx[1] + gq.n[2] * vtx[2] - gq.d0));
+        if (dmax <= 4.0 * eps * diam) { grp = &gq; dist = dmax; break; }
+      }
+      if (!grp) { groups.push_back(Group{{n[0], n[1], n[2]}, d0, 0.0, {}}); grp = &groups.back(); }
+      DevTriFilter f;
+      std::memset(&f, 0, sizeof f);
+      for (int k = 0; k < 3; k++) { f.A[k] = static_cast<float>(A[k]); f.B[k] = static_cast<float>(B[k]); }
       f.a0 = static_cast<float>(-(A[0] * v0[0] + A[1] * v0[1] + A[2] * v0[2]));
       f.b0 = static_cast<float>(-(B[0] * v0[0] + B[1] * v0[1] + B[2] * v0[2]));
-      f.ktol = static_cast<float>(c * g * 1.0001 + 1e-7);
-      f.kt = static_cast<float>(2.0 * c * std::max(1.0, inv_sin) + 1e-7);
-      if (!std::isfinite(f.ktol) || !std::isfinite(f.kt) || !std::isfinite(f.a0) || !std::isfinite(f.b0)) { std::memset(&f, 0, sizeof f); f.kind = 0xffu; }
+      f.ktol = static_cast<float>((c + dist) * g * 1.0001 + 1e-7);
+      f.bit = bit;
+      const double kt = 2.0 * (c + dist) * std::max(1.0, inv_sin) + 1e-7;
+      if (!std::isfinite(f.ktol) || !std::isfinite(f.a0) || !std::isfinite(f.b0) || !std::isfinite(kt)) { fp.always_mask |= bit; continue; }
+      grp->kt = std::max(grp->kt, kt);
+      grp->tris.push_back(f);
     } else if (o.kind == AMBER_PRIM_SPHERE) {
-      f.kind = AMBER_PRIM_SPHERE;
-      f.n[0] = o.a[0]; f.n[1] = o.a[1]; f.n[2] = o.a[2];
-      f.d0 = static_cast<float>(double(o.radius) * double(o.radius));
-      f.ktol = 1e-5f;
-      if (!std::isfinite(f.d0)) { std::memset(&f, 0, sizeof f); f.kind = 0xffu; }
+      DevSphereFilter f;
+      std::memset(&f, 0, sizeof f);
+      f.c[0] = o.a[0]; f.c[1] = o.a[1]; f.c[2] = o.a[2];
+      f.r2 = static_cast<float>(double(o.radius) * double(o.radius));
+      f.ktol = 1e-5f; f.bit = bit;
+      if (!std::isfinite(f.r2)) { fp.always_mask |= bit; continue; }
+      fp.spheres.push_back(f);
+    } else {
+      fp.always_mask |= bit;                         // disk, cylinder: always tested exactly
     }
+  }
+  for (const Group& g : groups) {
+    if (g.tris.empty()) continue;
+    DevPlane p;
+    std::memset(&p, 0, sizeof p);
+    for (int k = 0; k < 3; k++) p.n[k] = static_cast<float>(g.n[k]);
+    p.d0 = static_cast<float>(g.d0); p.kt = static_cast<float>(g.kt);
+    p.first_tri = static_cast<uint32_t>(fp.tris.size()); p.n_tris = static_cast<uint32_t>(g.tris.size());
+    fp.planes.push_back(p);
+    fp.tris.insert(fp.tris.end(), g.tris.begin(), g.tris.end());
   }
 }
 
@@ -455,9 +508,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
 
   h->two_phase = params->engine == AMBER_ENGINE_TWO_PHASE || (params->engine == AMBER_ENGINE_AUTO && s->n_objects <= AMBER_MAX_LDS_OBJECTS);
   h->engine = h->two_phase ? AMBER_ENGINE_TWO_PHASE : AMBER_ENGINE_LIST;
-  std::vector<DevFilter> filters(s->n_objects);
-  uint32_t tri_mask = 0;
-  BuildFilters(objs, filters, tri_mask);
+  FilterProgram fprog;
+  if (h->two_phase) BuildFilterProgram(objs, fprog);
 
   auto cleanup = [&](int code, const std::string& msg) { amber_hip_pt_destroy(h); return Fail(code, msg); };
 #define HIP_TRY_H(expr)                                                                            \
@@ -466,8 +518,12 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMalloc(&h->d_objects, objs.size() * sizeof(DevObject)));
   HIP_TRY_H(hipMalloc(&h->d_materials, mats.size() * sizeof(DevMaterial)));
   HIP_TRY_H(hipMalloc(&h->d_blades, blades.size() * sizeof(DevBlade)));
-  HIP_TRY_H(hipMalloc(&h->d_filters, filters.size() * sizeof(DevFilter)));
-  HIP_TRY_H(hipMemcpy(h->d_filters, filters.data(), filters.size() * sizeof(DevFilter), hipMemcpyHostToDevice));
+  HIP_TRY_H(hipMalloc(&h->d_planes, (fprog.planes.size() + 1) * sizeof(DevPlane)));
+  HIP_TRY_H(hipMalloc(&h->d_tri_filters, (fprog.tris.size() + 1) * sizeof(DevTriFilter)));
+  HIP_TRY_H(hipMalloc(&h->d_sphere_filters, (fprog.spheres.size() + 1) * sizeof(DevSphereFilter)));
+  if (!fprog.planes.empty()) HIP_TRY_H(hipMemcpy(h->d_planes, fprog.planes.data(), fprog.planes.size() * sizeof(DevPlane), hipMemcpyHostToDevice));
+  if (!fprog.tris.empty()) HIP_TRY_H(hipMemcpy(h->d_tri_filters, fprog.tris.data(), fprog.tris.size() * sizeof(DevTriFilter), hipMemcpyHostToDevice));
+  if (!fprog.spheres.empty()) HIP_TRY_H(hipMemcpy(h->d_sphere_filters, fprog.spheres.data(), fprog.spheres.size() * sizeof(DevSphereFilter), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_objects, objs.data(), objs.size() * sizeof(DevObject), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_blades, blades.data(), blades.size() * sizeof(DevBlade), hipMemcpyHostToDevice));
@@ -475,13 +531,19 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMalloc(&h->d_fb, fb_floats * sizeof(float)));
   HIP_TRY_H(hipMalloc(&h->d_rays, sizeof(unsigned long long)));
   HIP_TRY_H(hipMalloc(&h->d_next, sizeof(unsigned int)));
+#ifdef AMBER_STAMPS
+  HIP_TRY_H(hipMalloc(&h->d_stamps, 8 * sizeof(unsigned long long)));
+  HIP_TRY_H(hipMemset(h->d_stamps, 0, 8 * sizeof(unsigned long long)));
+#endif
   { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, params->device) == hipSuccess && v > 0) h->n_cus = v; }
   HIP_TRY_H(hipMemsetAsync(h->d_fb, 0, fb_floats * sizeof(float), h->stream));
   HIP_TRY_H(hipMemsetAsync(h->d_rays, 0, sizeof(unsigned long long), h->stream));
 
   DevScene& sc = h->scene;
-  sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades; sc.filters = h->d_filters;
-  sc.tri_mask = tri_mask;
+  sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades;
+  sc.planes = h->d_planes; sc.tri_filters = h->d_tri_filters; sc.sphere_filters = h->d_sphere_filters;
+  sc.n_planes = static_cast<uint32_t>(fprog.planes.size()); sc.n_sphere_filters = static_cast<uint32_t>(fprog.spheres.size());
+  sc.tri_mask = fprog.tri_mask; sc.always_mask = fprog.always_mask;
   sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;
   h->n_materials = s->n_materials;
   std::memcpy(sc.lens.origin, L.origin, sizeof L.origin);
@@ -533,7 +595,7 @@ int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
       h->partial_floats = need;
     }
     RenderArgs a;
-    a.scene = h->scene; a.partial = h->d_partial; a.ray_count = h->d_rays; a.next_item = h->d_next; a.hashed_seed = h->hashed_seed;
+    a.scene = h->scene; a.partial = h->d_partial; a.ray_count = h->d_rays; a.next_item = h->d_next; a.stamps = h->d_stamps; a.hashed_seed = h->hashed_seed;
     a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first_sample + done; a.n_samples = n;
     a.n_chunks = n_chunks; a.n_items = n_pixels * n_chunks;
     // persistent workers: 5 workgroups of 4 waves per CU (90 VGPRs -> 5 waves/SIMD), fewer if the queue is short
@@ -618,6 +680,14 @@ int amber_hip_pt_kernel_time(amber_hip_pt* h, uint32_t* n_launches, double* tota
   return AMBER_OK;
 }
 
+#ifdef AMBER_STAMPS
+extern "C" int amber_hip_pt_read_stamps(amber_hip_pt* h, unsigned long long out[8]) {
+  if (!h || !h->d_stamps) return AMBER_EINVAL;
+  (void)hipStreamSynchronize(h->stream);
+  return hipMemcpy(out, h->d_stamps, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? AMBER_OK : AMBER_EHIP;
+}
+#endif
+
 void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
@@ -626,10 +696,13 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_objects) (void)hipFree(h->d_objects);
   if (h->d_materials) (void)hipFree(h->d_materials);
   if (h->d_blades) (void)hipFree(h->d_blades);
-  if (h->d_filters) (void)hipFree(h->d_filters);
+  if (h->d_planes) (void)hipFree(h->d_planes);
+  if (h->d_tri_filters) (void)hipFree(h->d_tri_filters);
+  if (h->d_sphere_filters) (void)hipFree(h->d_sphere_filters);
   if (h->d_fb) (void)hipFree(h->d_fb);
   if (h->d_rays) (void)hipFree(h->d_rays);
   if (h->d_next) (void)hipFree(h->d_next);
+  if (h->d_stamps) (void)hipFree(h->d_stamps);
   if (h->d_partial) (void)hipFree(h->d_partial);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
