@@ -54,21 +54,19 @@ struct alignas(16) DevBlade {     // 48 B: aperture triangle with explicit verti
 };
 // Phase-A program of the two-phase closest hit (conservative candidate filter): coplanar
 // triangles share one plane record, so the plane hit point is computed once per plane.  All wave-uniform, scalar-loaded.
-struct alignas(16) DevPlane {       // 32 B
+struct alignas(16) DevPlane {       // 32 B: one s_load_dwordx8
   float n[3]; float d0;             // unit normal, n.v0
-  float kt;                         // tolerance of the t >= kEPS test (multiplied by |1/(n.d)|)
-  uint32_t first_tri, n_tris, pad;
+  float kt;                         // tolerance of the t >= kEPS test   (multiplied by |1/(n.d)|)
+  float ktol;                       // barycentric tolerance, max over the plane's triangles (same factor)
+  uint32_t n_tris, pad;
 };
-struct alignas(16) DevTriFilter {   // 48 B
+struct alignas(16) DevTriFilter {   // 32 B: one s_load_dwordx8.  Candidate bit = position in the program.
   float A[3]; float a0;             // u = A.P + a0 for P on the plane
   float B[3]; float b0;             // v = B.P + b0
-  float ktol;                       // barycentric tolerance (multiplied by |1/(n.d)|)
-  uint32_t bit;                     // 1 << object index
-  uint32_t pad[2];
 };
 struct alignas(16) DevSphereFilter { // 32 B
   float c[3]; float r2;
-  float ktol; uint32_t bit; uint32_t pad[2];
+  float ktol; uint32_t pad[3];
 };
 struct DevLens {
   float origin[3];
@@ -93,10 +91,11 @@ struct DevScene {
   const DevTriFilter* __restrict__ tri_filters;
   const DevSphereFilter* __restrict__ sphere_filters;
   uint32_t n_planes, n_sphere_filters;
-  uint32_t always_mask;        // objects that are always candidates (disks, cylinders, degenerate triangles)
+  uint32_t always_mask;        // program slots that are always candidates (disks, cylinders, degenerate triangles)
+  uint32_t n_prog_tris;        // program slots [0, n_prog_tris) are filtered triangles, then spheres, then the rest
+  const DevObject* __restrict__ prog_objects;   // objects in program order, kind |= scene index << 8 (staged to LDS)
   uint32_t n_objects;
   uint32_t max_depth;
-  uint32_t tri_mask;           // bit i set: object i is a triangle (two-phase path, n_objects <= 32)
   DevLens lens;
   DevSensor sensor;
 };
@@ -234,7 +233,7 @@ __device__ __forceinline__ double Pow5(float x) { const double d = x; const doub
 // ---------------------------------------------------------------------------------------------
 #define AMBER_KEPS 1e-6f   // (t < kEPS) <=> (t <= 1e-6f) ; (t > kEPS) <=> (t > 1e-6f): 1e-6f < 1e-6L < nextafterf(1e-6f)
 
-struct HitRec { float t, u, v; int idx; };
+struct HitRec { float t, u, v; int idx; int slot; };   // idx: object index (scene order); slot: index into the array the engine scans
 
 // algebra.h:31-52
 __device__ __forceinline__ bool SolveQuadratic(float a, float b, float c, float& alpha, float& beta) {
@@ -259,7 +258,7 @@ __device__ __forceinline__ bool Closer(float t, int i, const HitRec& best) {
 }
 
 template <bool kTie>
-__device__ __forceinline__ void IntersectTriangle(V3 A, V3 E1, V3 E2, int i, V3 o, V3 d, HitRec& best) {   // primitive_triangle.cc:97-128
+__device__ __forceinline__ void IntersectTriangle(V3 A, V3 E1, V3 E2, int i, int slot, V3 o, V3 d, HitRec& best) {   // primitive_triangle.cc:97-128
   const V3 P = Cross(d, E2);
   const float det = Dot(P, E1);
   const V3 T = o - A;
@@ -269,12 +268,12 @@ __device__ __forceinline__ void IntersectTriangle(V3 A, V3 E1, V3 E2, int i, V3 
     const float v = Dot(Q, d) / det;
     if (!(v > 1.0f || v < 0.0f) && !(u + v > 1.0f)) {
       const float t = Dot(Q, E2) / det;
-      if (!(t <= AMBER_KEPS) && Closer<kTie>(t, i, best)) { best.t = t; best.u = u; best.v = v; best.idx = i; }
+      if (!(t <= AMBER_KEPS) && Closer<kTie>(t, i, best)) { best.t = t; best.u = u; best.v = v; best.idx = i; best.slot = slot; }
     }
   }
 }
 template <bool kTie>
-__device__ __forceinline__ void IntersectSphere(V3 A, float radius, int i, V3 o, V3 d, HitRec& best) {      // primitive_sphere.cc:75-107
+__device__ __forceinline__ void IntersectSphere(V3 A, float radius, int i, int slot, V3 o, V3 d, HitRec& best) {      // primitive_sphere.cc:75-107
   const V3 co = A - o;
   const float b = -2.0f * Dot(co, d);
   const float c = SquaredLength(co) - radius * radius;
@@ -283,22 +282,22 @@ __device__ __forceinline__ void IntersectSphere(V3 A, float radius, int i, V3 o,
     float t;
     bool ok = true;
     if (alpha > AMBER_KEPS) t = alpha; else if (beta > AMBER_KEPS) t = beta; else { ok = false; t = 0.f; }
-    if (ok && Closer<kTie>(t, i, best)) { best.t = t; best.idx = i; }
+    if (ok && Closer<kTie>(t, i, best)) { best.t = t; best.idx = i; best.slot = slot; }
   }
 }
 template <bool kTie>
-__device__ __forceinline__ void IntersectDisk(V3 A, V3 N, float radius, int i, V3 o, V3 d, HitRec& best) {  // primitive_disk.cc:94-114
+__device__ __forceinline__ void IntersectDisk(V3 A, V3 N, float radius, int i, int slot, V3 o, V3 d, HitRec& best) {  // primitive_disk.cc:94-114
   const float cos_theta = Dot(d, N);
   if (!(cos_theta == 0.0f)) {
     const float t = Dot(A - o, N) / cos_theta;
     if (!(t <= AMBER_KEPS)) {
       const float sq = SquaredLength(o + t * d - A);
-      if (!(sq > radius * radius) && Closer<kTie>(t, i, best)) { best.t = t; best.idx = i; }
+      if (!(sq > radius * radius) && Closer<kTie>(t, i, best)) { best.t = t; best.idx = i; best.slot = slot; }
     }
   }
 }
 template <bool kTie>
-__device__ __forceinline__ void IntersectCylinder(V3 A, V3 N, float radius, float height, int i, V3 o, V3 d, HitRec& best) {   // primitive_cylinder.cc:100-142
+__device__ __forceinline__ void IntersectCylinder(V3 A, V3 N, float radius, float height, int i, int slot, V3 o, V3 d, HitRec& best) {   // primitive_cylinder.cc:100-142
   const V3 OC = A - o;
   const V3 uu = d - Dot(d, N) * N;
   const V3 vv = OC - Dot(OC, N) * N;
@@ -316,32 +315,32 @@ __device__ __forceinline__ void IntersectCylinder(V3 A, V3 N, float radius, floa
       const float h = Dot(beta * d - OC, N);
       if (h >= 0.0f && h <= height) { ok = true; t = beta; }
     }
-    if (ok && Closer<kTie>(t, i, best)) { best.t = t; best.idx = i; }
+    if (ok && Closer<kTie>(t, i, best)) { best.t = t; best.idx = i; best.slot = slot; }
   }
 }
 
 template <bool kTie>
-__device__ __forceinline__ void IntersectObject(const DevObject& ob, int i, V3 o, V3 d, HitRec& best) {
+__device__ __forceinline__ void IntersectObject(const DevObject& ob, uint32_t kind, int i, int slot, V3 o, V3 d, HitRec& best) {
   const V3 A = ld3(ob.a);
-  if (ob.kind == PRIM_TRIANGLE) IntersectTriangle<kTie>(A, ld3(ob.e1), ld3(ob.e2), i, o, d, best);
-  else if (ob.kind == PRIM_SPHERE) IntersectSphere<kTie>(A, ob.radius, i, o, d, best);
-  else if (ob.kind == PRIM_DISK) IntersectDisk<kTie>(A, ld3(ob.e1), ob.radius, i, o, d, best);
-  else IntersectCylinder<kTie>(A, ld3(ob.e1), ob.radius, ob.height, i, o, d, best);
+  if (kind == PRIM_TRIANGLE) IntersectTriangle<kTie>(A, ld3(ob.e1), ld3(ob.e2), i, slot, o, d, best);
+  else if (kind == PRIM_SPHERE) IntersectSphere<kTie>(A, ob.radius, i, slot, o, d, best);
+  else if (kind == PRIM_DISK) IntersectDisk<kTie>(A, ld3(ob.e1), ob.radius, i, slot, o, d, best);
+  else IntersectCylinder<kTie>(A, ld3(ob.e1), ob.radius, ob.height, i, slot, o, d, best);
 }
 
 // Engine LIST: every object, exact test, wave-uniform index (object data in SGPRs).
 __device__ __forceinline__ void ClosestHitList(const DevScene& sc, V3 o, V3 d, HitRec& best) {
-  best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1;   // Acceleration::Cast(ray, FLT_MAX)
+  best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;   // Acceleration::Cast(ray, FLT_MAX)
   const int n = static_cast<int>(sc.n_objects);
   const ConstWords base = (ConstWords)(sc.objects);
   for (int i = 0; i < n; ++i) {
     const ConstWords w = base + i * 16;                 // DevObject = 16 dwords
     const uint32_t kind = w[3];
     const V3 A = cw_v3(w, 0);
-    if (kind == PRIM_TRIANGLE) IntersectTriangle<false>(A, cw_v3(w, 4), cw_v3(w, 8), i, o, d, best);
-    else if (kind == PRIM_SPHERE) IntersectSphere<false>(A, cw_f(w, 7), i, o, d, best);
-    else if (kind == PRIM_DISK) IntersectDisk<false>(A, cw_v3(w, 4), cw_f(w, 7), i, o, d, best);
-    else IntersectCylinder<false>(A, cw_v3(w, 4), cw_f(w, 7), cw_f(w, 11), i, o, d, best);
+    if (kind == PRIM_TRIANGLE) IntersectTriangle<false>(A, cw_v3(w, 4), cw_v3(w, 8), i, i, o, d, best);
+    else if (kind == PRIM_SPHERE) IntersectSphere<false>(A, cw_f(w, 7), i, i, o, d, best);
+    else if (kind == PRIM_DISK) IntersectDisk<false>(A, cw_v3(w, 4), cw_f(w, 7), i, i, o, d, best);
+    else IntersectCylinder<false>(A, cw_v3(w, 4), cw_f(w, 7), cw_f(w, 11), i, i, o, d, best);
   }
 }
 
@@ -356,12 +355,13 @@ __device__ __forceinline__ void ClosestHitList(const DevScene& sc, V3 o, V3 d, H
 //  The result is identical to ClosestHitList (tests: full-image and per-ray equality of both engines).
 #define AMBER_GRAZING 1e-3f
 __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const DevObject* lds_objects, V3 o, V3 d, HitRec& best AMBER_STAMP_PARAM) {
-  best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1;
+  best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;
   uint32_t cand = sc.always_mask;
   {
     ConstWords pl = (ConstWords)(sc.planes);
-    const ConstWords tris = (ConstWords)(sc.tri_filters);
+    ConstWords tr = (ConstWords)(sc.tri_filters);
     const int n_planes = static_cast<int>(sc.n_planes);
+    uint32_t bit = 1u;                                       // candidate bit of the next program triangle (SALU)
     for (int p = 0; p < n_planes; ++p, pl += 8) {           // DevPlane = 8 dwords
       const float nd = __builtin_fmaf(cw_f(pl, 0), d.x, __builtin_fmaf(cw_f(pl, 1), d.y, cw_f(pl, 2) * d.z));
       const float no = __builtin_fmaf(cw_f(pl, 0), o.x, __builtin_fmaf(cw_f(pl, 1), o.y, cw_f(pl, 2) * o.z));
@@ -371,20 +371,20 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
       const float Px = __builtin_fmaf(tp, d.x, o.x), Py = __builtin_fmaf(tp, d.y, o.y), Pz = __builtin_fmaf(tp, d.z, o.z);
       const bool t_ok = tp >= AMBER_KEPS - cw_f(pl, 4) * rho;
       const bool grazing = !(Abs(nd) >= AMBER_GRAZING);     // true for NaN
-      ConstWords tr = tris + pl[5] * 12u;                   // DevTriFilter = 12 dwords
+      const float mtol = -cw_f(pl, 5) * rho;
       const int nt = static_cast<int>(pl[6]);
-      for (int k = 0; k < nt; ++k, tr += 12) {
+      for (int k = 0; k < nt; ++k, tr += 8, bit <<= 1) {    // DevTriFilter = 8 dwords
         const float u = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 1), Py, __builtin_fmaf(cw_f(tr, 2), Pz, cw_f(tr, 3))));
         const float v = __builtin_fmaf(cw_f(tr, 4), Px, __builtin_fmaf(cw_f(tr, 5), Py, __builtin_fmaf(cw_f(tr, 6), Pz, cw_f(tr, 7))));
         const float w = 1.0f - u - v;
         const float m = __builtin_fminf(__builtin_fminf(u, v), w);
-        const bool keep = ((m >= -cw_f(tr, 8) * rho) && t_ok) || grazing;
-        cand |= keep ? tr[9] : 0u;
+        const bool keep = ((m >= mtol) && t_ok) || grazing;
+        cand |= keep ? bit : 0u;
       }
     }
     ConstWords sp = (ConstWords)(sc.sphere_filters);
     const int ns = static_cast<int>(sc.n_sphere_filters);
-    for (int k = 0; k < ns; ++k, sp += 8) {                 // DevSphereFilter = 8 dwords
+    for (int k = 0; k < ns; ++k, sp += 8, bit <<= 1) {      // DevSphereFilter = 8 dwords
       const float cx = cw_f(sp, 0) - o.x, cy = cw_f(sp, 1) - o.y, cz = cw_f(sp, 2) - o.z;
       const float bb = __builtin_fmaf(cx, d.x, __builtin_fmaf(cy, d.y, cz * d.z));       // co.d
       const float c2 = __builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz));          // |co|^2
@@ -392,27 +392,31 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
       const float cc = c2 - r2;                                                           // |co|^2 - r^2
       const float tol = cw_f(sp, 4) * (c2 + r2);
       const bool miss = (__builtin_fmaf(bb, bb, -cc) < -tol) || (bb < 0.0f && cc > tol);  // no real root | both roots behind
-      cand |= miss ? 0u : sp[5];                                                          // NaN -> keep
+      cand |= miss ? 0u : bit;                                                            // NaN -> keep
     }
   }
   AMBER_STAMP(2);
-  // Phase B: triangles, then the rest (keeps the per-lane kind branch out of the hot loop)
-  uint32_t mt = cand & sc.tri_mask;
+  // Phase B: filtered triangles first, then everything else (keeps the per-lane kind branch out of the hot loop)
+  const uint32_t tri_bits = sc.n_prog_tris >= 32u ? 0xffffffffu : ((1u << sc.n_prog_tris) - 1u);
+  uint32_t mt = cand & tri_bits;
   while (__any(mt != 0u)) {
+#ifdef AMBER_STAMPS
+    stamp_ctx->acc[7] += 1ull + (static_cast<unsigned long long>(__popcll(__ballot(mt != 0u))) << 32);   // lo: wave trips, hi: lane tests
+#endif
     if (mt != 0u) {
-      const int i = __builtin_ctz(mt);
+      const int slot = __builtin_ctz(mt);
       mt &= mt - 1u;
-      const DevObject& ob = lds_objects[i];
-      IntersectTriangle<true>(ld3(ob.a), ld3(ob.e1), ld3(ob.e2), i, o, d, best);
+      const DevObject& ob = lds_objects[slot];
+      IntersectTriangle<true>(ld3(ob.a), ld3(ob.e1), ld3(ob.e2), static_cast<int>(ob.kind >> 8), slot, o, d, best);
     }
   }
-  uint32_t mo = cand & ~sc.tri_mask;
+  uint32_t mo = cand & ~tri_bits;
   while (__any(mo != 0u)) {
     if (mo != 0u) {
-      const int i = __builtin_ctz(mo);
+      const int slot = __builtin_ctz(mo);
       mo &= mo - 1u;
-      const DevObject& ob = lds_objects[i];
-      IntersectObject<true>(ob, i, o, d, best);
+      const DevObject& ob = lds_objects[slot];
+      IntersectObject<true>(ob, ob.kind & 0xffu, static_cast<int>(ob.kind >> 8), slot, o, d, best);
     }
   }
 }
@@ -426,8 +430,8 @@ __device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* 
 
 // position / normal of the winning hit, evaluated exactly as the reference's Intersect() does
 __device__ __forceinline__ void ResolveHit(const DevObject* objects, const HitRec& h, V3 o, V3 d, V3& pos, V3& normal, uint32_t& material) {
-  const DevObject* ob = objects + h.idx;
-  const uint32_t kind = ob->kind;
+  const DevObject* ob = objects + h.slot;
+  const uint32_t kind = ob->kind & 0xffu;             // the LDS image of the two-phase engine tags kind with index << 8
   material = ob->material;
   const V3 A = ld3(ob->a);
   if (kind == PRIM_TRIANGLE) {
@@ -450,7 +454,7 @@ __device__ __forceinline__ void ResolveHit(const DevObject* objects, const HitRe
 #define AMBER_MAX_LDS_OBJECTS 32
 __device__ __forceinline__ void StageObjects(const DevScene& sc, DevObject* lds_objects) {
   const uint32_t n_dwords = sc.n_objects * (sizeof(DevObject) / 4u);
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.objects);
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.prog_objects);
   uint32_t* dst = reinterpret_cast<uint32_t*>(lds_objects);
   for (uint32_t k = threadIdx.x; k < n_dwords; k += blockDim.x) dst[k] = src[k];
   __syncthreads();

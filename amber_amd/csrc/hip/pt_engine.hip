@@ -270,6 +270,7 @@ struct amber_hip_pt {
   DevPlane* d_planes = nullptr;
   DevTriFilter* d_tri_filters = nullptr;
   DevSphereFilter* d_sphere_filters = nullptr;
+  DevObject* d_prog_objects = nullptr;
   bool two_phase = false;
   float* d_fb = nullptr;
   unsigned long long* d_rays = nullptr;
@@ -313,7 +314,8 @@ struct FilterProgram {
   std::vector<DevPlane> planes;
   std::vector<DevTriFilter> tris;
   std::vector<DevSphereFilter> spheres;
-  uint32_t tri_mask = 0, always_mask = 0;
+  std::vector<uint32_t> order;          // program slot -> scene object index
+  uint32_t n_prog_tris = 0, always_mask = 0;
 };
 
 void BuildFilterProgram(const std::vector<DevObject>& objs, FilterProgram& fp) {
@@ -338,17 +340,17 @@ void BuildFilterProgram(const std::vector<DevObject>& objs, FilterProgram& fp) {
   const double diam = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
   const double eps = 5.9604644775390625e-08;
   const double c = 32.0 * eps * (diam + 1.5 * e_max);
-  struct Group { double n[3], d0, kt; std::vector<DevTriFilter> tris; };
+  struct Group { double n[3], d0, kt, ktol; std::vector<DevTriFilter> tris; std::vector<uint32_t> index; };
   std::vector<Group> groups;
+  std::vector<uint32_t> sphere_index, always_index;
   for (size_t i = 0; i < objs.size() && i < 32; i++) {
     const DevObject& o = objs[i];
-    const uint32_t bit = 1u << i;
+    const uint32_t idx = static_cast<uint32_t>(i);
     if (o.kind == AMBER_PRIM_TRIANGLE) {
-      fp.tri_mask |= bit;
       const double v0[3] = {o.a[0], o.a[1], o.a[2]}, E1[3] = {o.e1[0], o.e1[1], o.e1[2]}, E2[3] = {o.e2[0], o.e2[1], o.e2[2]};
       const double nr[3] = {E1[1] * E2[2] - E1[2] * E2[1], E1[2] * E2[0] - E1[0] * E2[2], E1[0] * E2[1] - E1[1] * E2[0]};
       const double n2 = nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2];
-      if (!(n2 > 1e-60) || !std::isfinite(n2)) { fp.always_mask |= bit; continue; }
+      if (!(n2 > 1e-60) || !std::isfinite(n2)) { always_index.push_back(idx); continue; }
       const double nl = std::sqrt(n2);
       const double n[3] = {nr[0] / nl, nr[1] / nl, nr[2] / nl};
       const double d0 = n[0] * v0[0] + n[1] * v0[1] + n[2] * v0[2];
@@ -366,40 +368,45 @@ void BuildFilterProgram(const std::vector<DevObject>& objs, FilterProgram& fp) {
         for (const auto& vtx : verts) dmax = std::max(dmax, std::fabs(gq.n[0] * vtx[0] + gq.n[1] * vtx[1] + gq.n[2] * vtx[2] - gq.d0));
         if (dmax <= 4.0 * eps * diam) { grp = &gq; dist = dmax; break; }
       }
-      if (!grp) { groups.push_back(Group{{n[0], n[1], n[2]}, d0, 0.0, {}}); grp = &groups.back(); }
       DevTriFilter f;
       std::memset(&f, 0, sizeof f);
       for (int k = 0; k < 3; k++) { f.A[k] = static_cast<float>(A[k]); f.B[k] = static_cast<float>(B[k]); }
       f.a0 = static_cast<float>(-(A[0] * v0[0] + A[1] * v0[1] + A[2] * v0[2]));
       f.b0 = static_cast<float>(-(B[0] * v0[0] + B[1] * v0[1] + B[2] * v0[2]));
-      f.ktol = static_cast<float>((c + dist) * g * 1.0001 + 1e-7);
-      f.bit = bit;
+      const double ktol = (c + dist) * g * 1.0001 + 1e-7;
       const double kt = 2.0 * (c + dist) * std::max(1.0, inv_sin) + 1e-7;
-      if (!std::isfinite(f.ktol) || !std::isfinite(f.a0) || !std::isfinite(f.b0) || !std::isfinite(kt)) { fp.always_mask |= bit; continue; }
+      if (!std::isfinite(ktol) || !std::isfinite(f.a0) || !std::isfinite(f.b0) || !std::isfinite(kt)) { always_index.push_back(idx); continue; }
+      if (!grp) { groups.push_back(Group{{n[0], n[1], n[2]}, d0, 0.0, 0.0, {}, {}}); grp = &groups.back(); }
       grp->kt = std::max(grp->kt, kt);
+      grp->ktol = std::max(grp->ktol, ktol);
       grp->tris.push_back(f);
+      grp->index.push_back(idx);
     } else if (o.kind == AMBER_PRIM_SPHERE) {
       DevSphereFilter f;
       std::memset(&f, 0, sizeof f);
       f.c[0] = o.a[0]; f.c[1] = o.a[1]; f.c[2] = o.a[2];
       f.r2 = static_cast<float>(double(o.radius) * double(o.radius));
-      f.ktol = 1e-5f; f.bit = bit;
-      if (!std::isfinite(f.r2)) { fp.always_mask |= bit; continue; }
+      f.ktol = 1e-5f;
+      if (!std::isfinite(f.r2)) { always_index.push_back(idx); continue; }
       fp.spheres.push_back(f);
+      sphere_index.push_back(idx);
     } else {
-      fp.always_mask |= bit;                         // disk, cylinder: always tested exactly
+      always_index.push_back(idx);                   // disk, cylinder: always tested exactly
     }
   }
   for (const Group& g : groups) {
-    if (g.tris.empty()) continue;
     DevPlane p;
     std::memset(&p, 0, sizeof p);
     for (int k = 0; k < 3; k++) p.n[k] = static_cast<float>(g.n[k]);
-    p.d0 = static_cast<float>(g.d0); p.kt = static_cast<float>(g.kt);
-    p.first_tri = static_cast<uint32_t>(fp.tris.size()); p.n_tris = static_cast<uint32_t>(g.tris.size());
+    p.d0 = static_cast<float>(g.d0); p.kt = static_cast<float>(g.kt * 1.0001); p.ktol = static_cast<float>(g.ktol * 1.0001);
+    p.n_tris = static_cast<uint32_t>(g.tris.size());
     fp.planes.push_back(p);
     fp.tris.insert(fp.tris.end(), g.tris.begin(), g.tris.end());
+    fp.order.insert(fp.order.end(), g.index.begin(), g.index.end());
   }
+  fp.n_prog_tris = static_cast<uint32_t>(fp.order.size());
+  fp.order.insert(fp.order.end(), sphere_index.begin(), sphere_index.end());
+  for (uint32_t idx : always_index) { fp.always_mask |= 1u << fp.order.size(); fp.order.push_back(idx); }
 }
 
 int ValidateScene(const AmberFlatScene* s, const AmberSensor* sensor) {
@@ -523,6 +530,12 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMalloc(&h->d_sphere_filters, (fprog.spheres.size() + 1) * sizeof(DevSphereFilter)));
   if (!fprog.planes.empty()) HIP_TRY_H(hipMemcpy(h->d_planes, fprog.planes.data(), fprog.planes.size() * sizeof(DevPlane), hipMemcpyHostToDevice));
   if (!fprog.tris.empty()) HIP_TRY_H(hipMemcpy(h->d_tri_filters, fprog.tris.data(), fprog.tris.size() * sizeof(DevTriFilter), hipMemcpyHostToDevice));
+  {
+    std::vector<DevObject> prog(fprog.order.size());
+    for (size_t k = 0; k < prog.size(); k++) { prog[k] = objs[fprog.order[k]]; prog[k].kind |= fprog.order[k] << 8; }
+    HIP_TRY_H(hipMalloc(&h->d_prog_objects, (prog.size() + 1) * sizeof(DevObject)));
+    if (!prog.empty()) HIP_TRY_H(hipMemcpy(h->d_prog_objects, prog.data(), prog.size() * sizeof(DevObject), hipMemcpyHostToDevice));
+  }
   if (!fprog.spheres.empty()) HIP_TRY_H(hipMemcpy(h->d_sphere_filters, fprog.spheres.data(), fprog.spheres.size() * sizeof(DevSphereFilter), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_objects, objs.data(), objs.size() * sizeof(DevObject), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
@@ -543,7 +556,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades;
   sc.planes = h->d_planes; sc.tri_filters = h->d_tri_filters; sc.sphere_filters = h->d_sphere_filters;
   sc.n_planes = static_cast<uint32_t>(fprog.planes.size()); sc.n_sphere_filters = static_cast<uint32_t>(fprog.spheres.size());
-  sc.tri_mask = fprog.tri_mask; sc.always_mask = fprog.always_mask;
+  sc.n_prog_tris = fprog.n_prog_tris; sc.always_mask = fprog.always_mask; sc.prog_objects = h->d_prog_objects;
   sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;
   h->n_materials = s->n_materials;
   std::memcpy(sc.lens.origin, L.origin, sizeof L.origin);
@@ -699,6 +712,7 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_planes) (void)hipFree(h->d_planes);
   if (h->d_tri_filters) (void)hipFree(h->d_tri_filters);
   if (h->d_sphere_filters) (void)hipFree(h->d_sphere_filters);
+  if (h->d_prog_objects) (void)hipFree(h->d_prog_objects);
   if (h->d_fb) (void)hipFree(h->d_fb);
   if (h->d_rays) (void)hipFree(h->d_rays);
   if (h->d_next) (void)hipFree(h->d_next);

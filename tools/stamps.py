@@ -15,5 +15,10 @@ for eng, name in ((A.ENGINE_TWO_PHASE, "two_phase"), (A.ENGINE_LIST, "list")):
     v = list(out); tot = sum(v)
     names = ["0 acquire", "1 regenerate", "2 closest-hit phase A (list: n/a)", "3 closest-hit phase B (list: whole scan)", "4 resolve+material+Le", "5 sample+pow/sincos", "6 RR/update/loop", "7 -"]
     print(name, "rays", pt.ray_count())
-    for n, x in zip(names, v):
+    trips, tests = v[7] & 0xffffffff, v[7] >> 32   # NOTE: 32-bit halves overflow on long runs; fine at 64 spp
+    tot -= v[7]
+    for n, x in zip(names[:7], v[:7]):
         print("   %-42s %6.2f %%" % (n, 100.0 * x / tot))
+    if trips:
+        rays = pt.ray_count()
+        print("   phase B triangle loop: %.2f exact tests per ray, %.1f lanes busy per trip" % (tests / rays, tests / trips))
