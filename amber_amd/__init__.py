@@ -7,6 +7,7 @@ contains no rendering code of its own and has no CPU fallback.
 """
 from .api import (  # noqa: F401
     ENGINE_AUTO,
+    ENGINE_BVH,
     ENGINE_LIST,
     ENGINE_TWO_PHASE,
     AmberError,

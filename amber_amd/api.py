@@ -59,7 +59,7 @@ class HostStats(C.Structure):
 
 PRIM_TRIANGLE, PRIM_SPHERE, PRIM_DISK, PRIM_CYLINDER = 0, 1, 2, 3
 MAT_LAMBERTIAN, MAT_PHONG, MAT_SPECULAR, MAT_REFRACTION, MAT_DIFFUSE_LIGHT, MAT_EYE = 0, 1, 2, 3, 4, 5
-ENGINE_AUTO, ENGINE_LIST, ENGINE_TWO_PHASE = 0, 1, 2
+ENGINE_AUTO, ENGINE_LIST, ENGINE_TWO_PHASE, ENGINE_BVH = 0, 1, 2, 3
 
 # every symbol include/amber_hip.h and include/amber_host.h declare
 ABI_SYMBOLS = [
@@ -171,6 +171,25 @@ class HostScene:
         t = (C.c_float * 16)(*[float(x) for x in transform])
         return cls(load_library().amber_host_scene_create(objs, len(objects), mats, len(materials), t, focal_length,
                                                           focus_distance, radius, n_blades, accel))
+
+    @classmethod
+    def create_arrays(cls, kinds, material_index, params, materials, transform, focal_length, focus_distance, radius, n_blades,
+                      accel: int = 0) -> "HostScene":
+        """Bulk form of create(): kinds (n,) u32, material_index (n,) u32, params (n,12) f32 as numpy arrays."""
+        n = len(kinds)
+        dt = np.dtype([("kind", np.uint32), ("material", np.uint32), ("p", np.float32, (12,))])
+        arr = np.zeros(n, dt)
+        arr["kind"], arr["material"] = kinds, material_index
+        arr["p"][:, : np.asarray(params).shape[1]] = params
+        assert arr.itemsize == C.sizeof(FlatObject)
+        mats = (FlatMaterial * max(1, len(materials)))()
+        for i, (kind, rho, param) in enumerate(materials):
+            mats[i].kind, mats[i].param = kind, param
+            for j in range(3):
+                mats[i].rho[j] = rho[j]
+        t = (C.c_float * 16)(*[float(x) for x in transform])
+        return cls(load_library().amber_host_scene_create(arr.ctypes.data_as(C.POINTER(FlatObject)), n, mats, len(materials), t,
+                                                          focal_length, focus_distance, radius, n_blades, accel))
 
     def flatten(self):
         lib = load_library()

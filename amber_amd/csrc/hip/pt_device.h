@@ -68,6 +68,14 @@ struct alignas(16) DevSphereFilter { // 32 B
   float c[3]; float r2;
   float ktol; uint32_t pad[3];
 };
+// Flattened 2-wide BVH node (engine BVH, bvh_build.h): both children's (padded) boxes live in the parent.
+// Child reference: >= 0 inner node index; < 0 leaf: -(ref+1) = first*8 + count into prim_index (count <= 7).
+struct alignas(16) DevBvhNode {   // 64 B
+  float lmin[3]; int32_t left;
+  float lmax[3]; int32_t pad0;
+  float rmin[3]; int32_t right;
+  float rmax[3]; int32_t pad1;
+};
 struct DevLens {
   float origin[3];
   float global_[9];
@@ -94,6 +102,9 @@ struct DevScene {
   uint32_t always_mask;        // program slots that are always candidates (disks, cylinders, degenerate triangles)
   uint32_t n_prog_tris;        // program slots [0, n_prog_tris) are filtered triangles, then spheres, then the rest
   const DevObject* __restrict__ prog_objects;   // objects in program order, kind |= scene index << 8 (staged to LDS)
+  const DevBvhNode* __restrict__ bvh_nodes;     // engine BVH
+  const uint32_t* __restrict__ bvh_prims;       // leaf order -> object index
+  int32_t bvh_root;                             // child reference of the whole scene
   uint32_t n_objects;
   uint32_t max_depth;
   DevLens lens;
@@ -421,9 +432,73 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
   }
 }
 
-template <bool kTwoPhase>
-__device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* lds_objects, V3 o, V3 d, HitRec& best AMBER_STAMP_PARAM) {
-  if (kTwoPhase) ClosestHitTwoPhase(sc, lds_objects, o, d, best AMBER_STAMP_ARG);
+// Engine BVH: per-lane traversal of the flattened 2-wide BVH, near child first, far child pushed on a per-lane
+// stack held in LDS (layout [level][thread]: conflict-free for ds_read/write_b32).  Boxes are padded on the host
+// and the slab test ignores NaN axes (v_min/v_max return the non-NaN operand), so culling is conservative;
+// every object of a visited leaf gets the exact reference test with the (t, index) tie rule.  Result = List.
+#define AMBER_BVH_STACK 32
+__device__ __forceinline__ void SlabTest(const float* mn, const float* mx, V3 o, V3 inv, float t_best, bool& hit, float& t_in) {
+  const float x0 = (mn[0] - o.x) * inv.x, x1 = (mx[0] - o.x) * inv.x;
+  const float y0 = (mn[1] - o.y) * inv.y, y1 = (mx[1] - o.y) * inv.y;
+  const float z0 = (mn[2] - o.z) * inv.z, z1 = (mx[2] - o.z) * inv.z;
+  float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
+  float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+  // widen by a few ulps of the larger parameter: the slab arithmetic itself rounds
+  const float slack = 4.76837158203125e-07f * __builtin_fmaxf(Abs(tn), Abs(tf));
+  tn -= slack; tf += slack;
+  t_in = tn;
+  hit = !(tn > tf) && !(tn > t_best);        // NaN anywhere -> treated as a hit
+}
+
+__device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, HitRec& best) {
+  best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;
+  const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  int32_t* stack = lds_stack + threadIdx.x;          // element k at stack[k * blockDim.x]
+  const uint32_t stride = blockDim.x;
+  int sp = 0;
+  bool overflow = false;
+  int32_t cur = sc.bvh_root;
+  for (;;) {
+    if (cur >= 0) {
+      const DevBvhNode* nd = sc.bvh_nodes + cur;
+      const float4 a = *reinterpret_cast<const float4*>(nd->lmin), b = *reinterpret_cast<const float4*>(nd->lmax);
+      const float4 c = *reinterpret_cast<const float4*>(nd->rmin), e = *reinterpret_cast<const float4*>(nd->rmax);
+      const float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {b.x, b.y, b.z}, rmn[3] = {c.x, c.y, c.z}, rmx[3] = {e.x, e.y, e.z};
+      const int32_t left = __float_as_int(a.w), right = __float_as_int(c.w);
+      bool hl, hr; float tl, tr;
+      SlabTest(lmn, lmx, o, inv, best.t, hl, tl);
+      SlabTest(rmn, rmx, o, inv, best.t, hr, tr);
+      if (hl && hr) {
+        const bool left_first = !(tr < tl);
+        const int32_t near_ = left_first ? left : right, far_ = left_first ? right : left;
+        if (sp < AMBER_BVH_STACK) { stack[sp * stride] = far_; ++sp; cur = near_; continue; }
+        overflow = true;                               // cannot happen with the builder's depth cap; stay correct anyway
+        break;
+      }
+      if (hl) { cur = left; continue; }
+      if (hr) { cur = right; continue; }
+    } else {
+      const uint32_t ref = static_cast<uint32_t>(-(cur + 1));
+      const uint32_t first = ref >> 3, count = ref & 7u;
+      for (uint32_t k = 0; k < count; ++k) {
+        const uint32_t oi = sc.bvh_prims[first + k];
+        const DevObject& ob = sc.objects[oi];
+        IntersectObject<true>(ob, ob.kind, static_cast<int>(oi), static_cast<int>(oi), o, d, best);
+      }
+    }
+    if (sp == 0) break;
+    --sp;
+    cur = stack[sp * stride];
+  }
+  if (__any(overflow)) { if (overflow) ClosestHitList(sc, o, d, best); }
+}
+
+enum { ENGINE_LIST = 1, ENGINE_TWO_PHASE = 2, ENGINE_BVH = 3 };
+
+template <int kEngine>
+__device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3 o, V3 d, HitRec& best AMBER_STAMP_PARAM) {
+  if (kEngine == ENGINE_TWO_PHASE) ClosestHitTwoPhase(sc, lds_objects, o, d, best AMBER_STAMP_ARG);
+  else if (kEngine == ENGINE_BVH) ClosestHitBvh(sc, lds_stack, o, d, best);
   else ClosestHitList(sc, o, d, best);
   AMBER_STAMP(3);
 }
@@ -579,18 +654,18 @@ __device__ __forceinline__ void GenerateEyeRay(const DevScene& sc, uint32_t px, 
 // ---------------------------------------------------------------------------------------------
 struct Bounce { int object; float t; V3 pos; V3 weight_before; };
 
-template <bool kTrace, bool kTwoPhase>
-__device__ __forceinline__ bool PathStep(const DevScene& sc, const DevObject* lds_objects, V3& o, V3& d, V3& weight, V3& measurement,
+template <bool kTrace, int kEngine>
+__device__ __forceinline__ bool PathStep(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3& o, V3& d, V3& weight, V3& measurement,
                                          uint64_t& rng, uint32_t& casts, Bounce* trace AMBER_STAMP_PARAM) {
   HitRec h;
-  ClosestHit<kTwoPhase>(sc, lds_objects, o, d, h AMBER_STAMP_ARG);
+  ClosestHit<kEngine>(sc, lds_objects, lds_stack, o, d, h AMBER_STAMP_ARG);
   casts++;
   if (h.idx < 0) {
     if (kTrace) { trace->object = -1; trace->t = __builtin_nanf(""); trace->pos = v3(0, 0, 0); trace->weight_before = v3(0, 0, 0); }
     return false;
   }
   V3 pos, normal; uint32_t mat;
-  ResolveHit(kTwoPhase ? lds_objects : sc.objects, h, o, d, pos, normal, mat);
+  ResolveHit(kEngine == ENGINE_TWO_PHASE ? lds_objects : sc.objects, h, o, d, pos, normal, mat);
   const DevMaterial m = sc.materials[mat];
   const V3 dir_out = -d;
   if (kTrace) { trace->object = h.idx; trace->t = h.t; trace->pos = pos; trace->weight_before = weight; }

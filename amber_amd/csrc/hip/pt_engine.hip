@@ -19,6 +19,7 @@
 
 #include "../../../include/amber_hip.h"
 #include "pt_device.h"
+#include "bvh_build.h"
 
 using namespace amber_dev;
 
@@ -57,11 +58,13 @@ struct RenderArgs {
 // empty.  A lane walks the samples of its item in order (sum += measurement), regenerating the eye ray in
 // place when a path ends, and stores the item's sum to partial[chunk][pixel]; reduce_partials_kernel adds the
 // chunks to the framebuffer in chunk order.  The summation order is therefore fixed.
-template <bool kTwoPhase>
+template <int kEngine>
 __global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
+  constexpr bool kTwoPhase = kEngine == ENGINE_TWO_PHASE;
   __shared__ DevObject lds_objects[kTwoPhase ? AMBER_MAX_LDS_OBJECTS : 1];
+  __shared__ int32_t lds_stack[kEngine == ENGINE_BVH ? AMBER_BVH_STACK * 256 : 1];
   if (kTwoPhase) StageObjects(sc, lds_objects);
 
   uint32_t pool_next = 0, pool_end = 0;      // wave-uniform: items claimed by this wave, not yet handed out
@@ -135,7 +138,7 @@ __global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
     }
     AMBER_STAMP(1);
     if (alive) {
-      alive = PathStep<false, kTwoPhase>(sc, lds_objects, o, d, w, meas, rng, casts, nullptr AMBER_STAMP_ARG);
+      alive = PathStep<false, kEngine>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, nullptr AMBER_STAMP_ARG);
       ++rays;
       if (!alive) sum = sum + meas;                         // sequential sum over the item's samples
     }
@@ -162,19 +165,21 @@ __global__ void reduce_partials_kernel(float* __restrict__ fb, const float* __re
 // ------------------------------------------------------------------------------------------------
 // known-answer kernels (same device functions)
 // ------------------------------------------------------------------------------------------------
-template <bool kTwoPhase>
+template <int kEngine>
 __global__ void kat_cast_kernel(const DevScene sc, uint32_t n, const float* org, const float* dir,
                                 int32_t* out_obj, float* out_t, float* out_pos, float* out_n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t k = i < n ? i : n - 1;      // keep the object loop wave-uniform for every lane
+  constexpr bool kTwoPhase = kEngine == ENGINE_TWO_PHASE;
   __shared__ DevObject lds_objects[kTwoPhase ? AMBER_MAX_LDS_OBJECTS : 1];
+  __shared__ int32_t lds_stack[kEngine == ENGINE_BVH ? AMBER_BVH_STACK * 256 : 1];
   if (kTwoPhase) StageObjects(sc, lds_objects);
   const V3 o = ld3(org + 3 * k), d = ld3(dir + 3 * k);
   HitRec h;
 #ifdef AMBER_STAMPS
   StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
 #endif
-  ClosestHit<kTwoPhase>(sc, lds_objects, o, d, h AMBER_STAMP_ARG);
+  ClosestHit<kEngine>(sc, lds_objects, lds_stack, o, d, h AMBER_STAMP_ARG);
   if (i >= n) return;
   out_obj[i] = h.idx;
   if (h.idx < 0) {
@@ -183,7 +188,7 @@ __global__ void kat_cast_kernel(const DevScene sc, uint32_t n, const float* org,
     return;
   }
   V3 pos, nrm; uint32_t mat;
-  ResolveHit(kTwoPhase ? lds_objects : sc.objects, h, o, d, pos, nrm, mat);
+  ResolveHit(kEngine == ENGINE_TWO_PHASE ? lds_objects : sc.objects, h, o, d, pos, nrm, mat);
   out_t[i] = h.t;
   out_pos[3 * i] = pos.x; out_pos[3 * i + 1] = pos.y; out_pos[3 * i + 2] = pos.z;
   out_n[3 * i] = nrm.x; out_n[3 * i + 1] = nrm.y; out_n[3 * i + 2] = nrm.z;
@@ -213,12 +218,14 @@ __global__ void kat_eye_kernel(const DevScene sc, uint64_t hashed_seed, uint32_t
   p[0] = o.x; p[1] = o.y; p[2] = o.z; p[3] = d.x; p[4] = d.y; p[5] = d.z; p[6] = w;
 }
 
-template <bool kTwoPhase>
+template <int kEngine>
 __global__ void kat_trace_kernel(const DevScene sc, uint64_t hashed_seed, uint32_t n, const uint32_t* pixel,
                                  const uint32_t* sample, uint32_t max_bounces, uint32_t* out_records, uint32_t* out_casts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t k = i < n ? i : n - 1;
+  constexpr bool kTwoPhase = kEngine == ENGINE_TWO_PHASE;
   __shared__ DevObject lds_objects[kTwoPhase ? AMBER_MAX_LDS_OBJECTS : 1];
+  __shared__ int32_t lds_stack[kEngine == ENGINE_BVH ? AMBER_BVH_STACK * 256 : 1];
   if (kTwoPhase) StageObjects(sc, lds_objects);
   uint64_t rng = XorShiftSeed(hashed_seed, pixel[k], sample[k]);
   V3 o, d; float ew;
@@ -233,7 +240,7 @@ __global__ void kat_trace_kernel(const DevScene sc, uint64_t hashed_seed, uint32
 #ifdef AMBER_STAMPS
       StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
 #endif
-      alive = PathStep<true, kTwoPhase>(sc, lds_objects, o, d, w, meas, rng, casts, &b AMBER_STAMP_ARG);
+      alive = PathStep<true, kEngine>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, &b AMBER_STAMP_ARG);
       if (i < n && casts <= max_bounces) {
         uint32_t* r = out_records + (static_cast<size_t>(i) * max_bounces + (casts - 1)) * 11u;
         r[0] = static_cast<uint32_t>(b.object);
@@ -271,6 +278,8 @@ struct amber_hip_pt {
   DevTriFilter* d_tri_filters = nullptr;
   DevSphereFilter* d_sphere_filters = nullptr;
   DevObject* d_prog_objects = nullptr;
+  DevBvhNode* d_bvh_nodes = nullptr;
+  uint32_t* d_bvh_prims = nullptr;
   bool two_phase = false;
   float* d_fb = nullptr;
   unsigned long long* d_rays = nullptr;
@@ -459,8 +468,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     const uint32_t q = (re - rb) / params->stripe_period, rem = (re - rb) % params->stripe_period;
     local_rows = q * params->stripe_rows + (rem < params->stripe_rows ? rem : params->stripe_rows);
   }
-  if (params->engine != AMBER_ENGINE_AUTO && params->engine != AMBER_ENGINE_LIST && params->engine != AMBER_ENGINE_TWO_PHASE)
-    return Fail(AMBER_EINVAL, "engine not available in this build");
+  if (params->engine > AMBER_ENGINE_BVH) return Fail(AMBER_EINVAL, "unknown engine");
   if (params->engine == AMBER_ENGINE_TWO_PHASE && s->n_objects > AMBER_MAX_LDS_OBJECTS)
     return Fail(AMBER_EINVAL, "AMBER_ENGINE_TWO_PHASE supports at most 32 objects");
 
@@ -513,8 +521,14 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     for (int c = 0; c < 3; c++) { blades[i].v0[c] = f.p[c]; blades[i].v1[c] = f.p[3 + c]; blades[i].v2[c] = f.p[6 + c]; blades[i].n[c] = f.p[9 + c]; }
   }
 
-  h->two_phase = params->engine == AMBER_ENGINE_TWO_PHASE || (params->engine == AMBER_ENGINE_AUTO && s->n_objects <= AMBER_MAX_LDS_OBJECTS);
-  h->engine = h->two_phase ? AMBER_ENGINE_TWO_PHASE : AMBER_ENGINE_LIST;
+  h->engine = params->engine != AMBER_ENGINE_AUTO ? params->engine
+              : (s->n_objects <= AMBER_MAX_LDS_OBJECTS ? AMBER_ENGINE_TWO_PHASE : AMBER_ENGINE_BVH);
+  h->two_phase = h->engine == AMBER_ENGINE_TWO_PHASE;
+  amber_bvh::FlatBvh bvh;
+  if (h->engine == AMBER_ENGINE_BVH) {
+    bvh = amber_bvh::BuildBvh(objs);
+    if (bvh.depth > static_cast<uint32_t>(amber_bvh::kMaxDepth)) { delete h; return Fail(AMBER_EINVAL, "BVH deeper than the device stack"); }
+  }
   FilterProgram fprog;
   if (h->two_phase) BuildFilterProgram(objs, fprog);
 
@@ -536,6 +550,10 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     HIP_TRY_H(hipMalloc(&h->d_prog_objects, (prog.size() + 1) * sizeof(DevObject)));
     if (!prog.empty()) HIP_TRY_H(hipMemcpy(h->d_prog_objects, prog.data(), prog.size() * sizeof(DevObject), hipMemcpyHostToDevice));
   }
+  HIP_TRY_H(hipMalloc(&h->d_bvh_nodes, (bvh.nodes.size() + 1) * sizeof(DevBvhNode)));
+  HIP_TRY_H(hipMalloc(&h->d_bvh_prims, (bvh.prim_index.size() + 1) * sizeof(uint32_t)));
+  if (!bvh.nodes.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(DevBvhNode), hipMemcpyHostToDevice));
+  if (!bvh.prim_index.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_prims, bvh.prim_index.data(), bvh.prim_index.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   if (!fprog.spheres.empty()) HIP_TRY_H(hipMemcpy(h->d_sphere_filters, fprog.spheres.data(), fprog.spheres.size() * sizeof(DevSphereFilter), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_objects, objs.data(), objs.size() * sizeof(DevObject), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
@@ -556,6 +574,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades;
   sc.planes = h->d_planes; sc.tri_filters = h->d_tri_filters; sc.sphere_filters = h->d_sphere_filters;
   sc.n_planes = static_cast<uint32_t>(fprog.planes.size()); sc.n_sphere_filters = static_cast<uint32_t>(fprog.spheres.size());
+  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_prims = h->d_bvh_prims; sc.bvh_root = bvh.root_ref;
   sc.n_prog_tris = fprog.n_prog_tris; sc.always_mask = fprog.always_mask; sc.prog_objects = h->d_prog_objects;
   sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;
   h->n_materials = s->n_materials;
@@ -623,8 +642,9 @@ int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
     }
     auto& ev = h->events[h->events_used++];
     HIP_TRY(hipEventRecord(ev.first, h->stream));
-    if (h->two_phase) hipLaunchKernelGGL(pt_megakernel<true>, dim3(n_blocks), dim3(256), 0, h->stream, a);
-    else hipLaunchKernelGGL(pt_megakernel<false>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    if (h->engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(pt_megakernel<ENGINE_TWO_PHASE>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else if (h->engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(pt_megakernel<ENGINE_BVH>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL(pt_megakernel<ENGINE_LIST>, dim3(n_blocks), dim3(256), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, h->stream));
     const uint32_t n_elems = n_pixels * 3u;
@@ -713,6 +733,8 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_tri_filters) (void)hipFree(h->d_tri_filters);
   if (h->d_sphere_filters) (void)hipFree(h->d_sphere_filters);
   if (h->d_prog_objects) (void)hipFree(h->d_prog_objects);
+  if (h->d_bvh_nodes) (void)hipFree(h->d_bvh_nodes);
+  if (h->d_bvh_prims) (void)hipFree(h->d_bvh_prims);
   if (h->d_fb) (void)hipFree(h->d_fb);
   if (h->d_rays) (void)hipFree(h->d_rays);
   if (h->d_next) (void)hipFree(h->d_next);
@@ -732,8 +754,9 @@ int amber_hip_kat_cast(amber_hip_pt* h, uint32_t n, const float* origins, const 
   HIP_TRY(d_o.alloc(3 * n)); HIP_TRY(d_d.alloc(3 * n)); HIP_TRY(d_t.alloc(n)); HIP_TRY(d_p.alloc(3 * n)); HIP_TRY(d_n.alloc(3 * n)); HIP_TRY(d_i.alloc(n));
   HIP_TRY(hipMemcpy(d_o.p, origins, 3ull * n * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_d.p, dirs, 3ull * n * 4, hipMemcpyHostToDevice));
-  if (h->two_phase) hipLaunchKernelGGL(kat_cast_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
-  else hipLaunchKernelGGL(kat_cast_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
+  if (h->engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(kat_cast_kernel<ENGINE_TWO_PHASE>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
+  else if (h->engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(kat_cast_kernel<ENGINE_BVH>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
+  else hipLaunchKernelGGL(kat_cast_kernel<ENGINE_LIST>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out_object, d_i.p, 4ull * n, hipMemcpyDeviceToHost));
@@ -795,8 +818,9 @@ int amber_hip_kat_trace(amber_hip_pt* h, uint32_t n, const uint32_t* pixel, cons
   HIP_TRY(hipMemcpy(d_p.p, pixel, 4ull * n, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_s.p, sample, 4ull * n, hipMemcpyHostToDevice));
   HIP_TRY(hipMemsetAsync(d_r.p, 0, nrec * 4, h->stream));
-  if (h->two_phase) hipLaunchKernelGGL(kat_trace_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
-  else hipLaunchKernelGGL(kat_trace_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
+  if (h->engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(kat_trace_kernel<ENGINE_TWO_PHASE>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
+  else if (h->engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(kat_trace_kernel<ENGINE_BVH>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
+  else hipLaunchKernelGGL(kat_trace_kernel<ENGINE_LIST>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out_records, d_r.p, nrec * 4, hipMemcpyDeviceToHost));

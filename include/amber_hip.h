@@ -113,11 +113,13 @@ typedef struct {
   uint32_t reserved;    /* row_begin = r*S, row_end = height, stripe_period = N*S).  Local rows are compact. */
 } AmberPtParams;
 
-/* Both engines are the same persistent work-queue kernel; they differ in how a lane finds its closest hit. */
+/* All engines are the same persistent work-queue kernel; they differ in how a lane finds its closest hit.
+ * Every engine returns the List-semantics answer (closest finite hit, ties to the lower object index). */
 enum {
-  AMBER_ENGINE_AUTO = 0,       /* TWO_PHASE when the scene has <= 32 objects, LIST otherwise */
+  AMBER_ENGINE_AUTO = 0,       /* TWO_PHASE when the scene has <= 32 objects, BVH otherwise */
   AMBER_ENGINE_LIST = 1,       /* exact test of every object, wave-uniform scan (object data in SGPRs) */
-  AMBER_ENGINE_TWO_PHASE = 2   /* conservative wave-uniform candidate filter, then exact tests of the candidates only */
+  AMBER_ENGINE_TWO_PHASE = 2,  /* conservative wave-uniform candidate filter, then exact tests of the candidates only */
+  AMBER_ENGINE_BVH = 3         /* host-built flattened 2-wide BVH, per-lane traversal with an LDS stack, exact leaf tests */
 };
 
 typedef struct amber_hip_pt amber_hip_pt;
