@@ -42,7 +42,7 @@ def cpu_baseline(width: int, seed: int, budget_s: float = 15.0):
     t0 = time.perf_counter()
     _, cnt = sc.render_xorshift(width, width, seed, 0, 1, math=O.MATH_LIBM, threads=cores)
     dt1 = time.perf_counter() - t0
-    spp = max(1, min(64, int(budget_s / max(dt1, 1e-3))))
+    spp = max(1, min(512, int(budget_s / max(dt1, 1e-3))))
     t0 = time.perf_counter()
     _, cnt = sc.render_xorshift(width, width, seed, 1, spp, math=O.MATH_LIBM, threads=cores)
     dt = time.perf_counter() - t0
@@ -147,16 +147,17 @@ def main():
             "config": {"workload": f"Cornell box (etude::CornelBox(0.050,0.050,6)) {W}x{H} @ {args.spp} spp, RR-only path tracing, "
                                    f"per-(pixel,sample) XorShift seed {args.seed}", "rays_per_step": rays // args.steps,
                        "paths_per_step": W * H * args.spp, "wall_s_per_step": round(dt_max / args.steps, 4),
-                       "parallelism": f"stripes{world}x8rows", "launches_per_step": len(launches), "engine": "megakernel"},
+                       "parallelism": f"stripes{world}x8rows", "launches_per_step": len(launches), "engine": "work-queue megakernel, two-phase closest hit"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel": "pt_megakernel", "kernel_ms": round(kern_ms, 3),
                          "note": "achieved = rays per launch (rank 0) x 96 B algorithmic ray-state bytes / mean launch duration (hipEvents)"},
         }
-        prof = ROOT / "profiles" / "r01_hbm_traffic.json"
-        if prof.exists():
+        profs = sorted((ROOT / "profiles").glob("r*_hbm_traffic.json"))      # latest committed rocprofv3 PMC summary
+        if profs:
             try:
-                out["roofline"]["traffic"] = json.loads(prof.read_text()).get("hbm_bytes_per_launch")
+                out["roofline"]["traffic"] = json.loads(profs[-1].read_text()).get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = f"profiles/{profs[-1].name}"
             except Exception:
                 pass
         if not args.no_cpu_baseline:

