@@ -10,6 +10,7 @@ from .api import (  # noqa: F401
     ENGINE_BVH,
     ENGINE_LIST,
     ENGINE_TWO_PHASE,
+    ENGINE_WAVEFRONT,
     AmberError,
     FlatMaterial,
     FlatObject,

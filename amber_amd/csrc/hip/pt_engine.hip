@@ -162,6 +162,8 @@ __global__ void reduce_partials_kernel(float* __restrict__ fb, const float* __re
   fb[e] = v;
 }
 
+#include "wavefront.inc"
+
 // ------------------------------------------------------------------------------------------------
 // known-answer kernels (same device functions)
 // ------------------------------------------------------------------------------------------------
@@ -290,7 +292,9 @@ struct amber_hip_pt {
   int n_cus = 256;
   uint32_t row_begin = 0, row_end = 0, stripe_rows = 0, stripe_period = 0, local_rows = 0;
   uint64_t seed = 0, hashed_seed = 0;
-  uint32_t engine = AMBER_ENGINE_LIST;
+  uint32_t engine = AMBER_ENGINE_LIST;      // as requested / resolved: LIST, TWO_PHASE, BVH or WAVEFRONT
+  uint32_t hit_engine = AMBER_ENGINE_LIST;  // closest-hit engine the kernels are instantiated with
+  float* d_wf = nullptr; size_t wf_bytes = 0;   // WAVEFRONT: queues + meas + counts in one allocation
   uint32_t n_materials = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per timed launch
   size_t events_used = 0;
@@ -468,7 +472,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     const uint32_t q = (re - rb) / params->stripe_period, rem = (re - rb) % params->stripe_period;
     local_rows = q * params->stripe_rows + (rem < params->stripe_rows ? rem : params->stripe_rows);
   }
-  if (params->engine > AMBER_ENGINE_BVH) return Fail(AMBER_EINVAL, "unknown engine");
+  if (params->engine > AMBER_ENGINE_WAVEFRONT) return Fail(AMBER_EINVAL, "unknown engine");
   if (params->engine == AMBER_ENGINE_TWO_PHASE && s->n_objects > AMBER_MAX_LDS_OBJECTS)
     return Fail(AMBER_EINVAL, "AMBER_ENGINE_TWO_PHASE supports at most 32 objects");
 
@@ -521,11 +525,12 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     for (int c = 0; c < 3; c++) { blades[i].v0[c] = f.p[c]; blades[i].v1[c] = f.p[3 + c]; blades[i].v2[c] = f.p[6 + c]; blades[i].n[c] = f.p[9 + c]; }
   }
 
-  h->engine = params->engine != AMBER_ENGINE_AUTO ? params->engine
-              : (s->n_objects <= AMBER_MAX_LDS_OBJECTS ? AMBER_ENGINE_TWO_PHASE : AMBER_ENGINE_BVH);
-  h->two_phase = h->engine == AMBER_ENGINE_TWO_PHASE;
+  const uint32_t auto_hit = s->n_objects <= AMBER_MAX_LDS_OBJECTS ? AMBER_ENGINE_TWO_PHASE : AMBER_ENGINE_BVH;
+  h->engine = params->engine != AMBER_ENGINE_AUTO ? params->engine : auto_hit;
+  h->hit_engine = h->engine == AMBER_ENGINE_WAVEFRONT ? auto_hit : h->engine;
+  h->two_phase = h->hit_engine == AMBER_ENGINE_TWO_PHASE;
   amber_bvh::FlatBvh bvh;
-  if (h->engine == AMBER_ENGINE_BVH) {
+  if (h->hit_engine == AMBER_ENGINE_BVH) {
     bvh = amber_bvh::BuildBvh(objs);
     if (bvh.depth > static_cast<uint32_t>(amber_bvh::kMaxDepth)) { delete h; return Fail(AMBER_EINVAL, "BVH deeper than the device stack"); }
   }
@@ -599,11 +604,93 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   return AMBER_OK;
 }
 
-int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples) {
+namespace {
+
+// Engine WAVEFRONT host loop: batches of <= max_chunks accumulation chunks; per batch generate, then bounce launches
+// until the live-ray count read back from the device is zero, then the ordered reduction into the framebuffer.
+int RenderPassWavefront(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples) {
+  const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
+  const uint64_t kMaxPaths = 1ull << 28;                       // 268 M paths: 2 x 14 GB of queues + 3.2 GB of measurements
+  uint64_t max_chunks = kMaxPaths / (static_cast<uint64_t>(n_pixels) * AMBER_ACCUM_CHUNK);
+  if (max_chunks == 0) return Fail(AMBER_EINVAL, "band too large for the wavefront engine");
+  const uint32_t kMaxBounces = 4096;
+  uint32_t done = 0;
+  while (done < n_samples) {
+    uint32_t n = n_samples - done;
+    if (n > max_chunks * AMBER_ACCUM_CHUNK) n = static_cast<uint32_t>(max_chunks * AMBER_ACCUM_CHUNK);
+    const uint32_t n_chunks = (n + AMBER_ACCUM_CHUNK - 1) / AMBER_ACCUM_CHUNK;
+    const size_t n_paths = static_cast<size_t>(n_chunks) * n_pixels * AMBER_ACCUM_CHUNK;
+    // every queue array holds AMBER_WF_SHARDS shards of shard_capacity rays
+    const size_t shard_capacity = ((n_paths + AMBER_WF_SHARDS - 1) / AMBER_WF_SHARDS + 63) / 64 * 64 + 64;
+    const size_t q_len = shard_capacity * AMBER_WF_SHARDS;
+    const size_t n_counts = static_cast<size_t>(kMaxBounces + 2) * AMBER_WF_SHARDS;
+    const size_t bytes = (26 * q_len + 3 * n_paths) * 4 + n_counts * sizeof(unsigned int);
+    if (bytes > h->wf_bytes) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (h->d_wf) { HIP_TRY(hipFree(h->d_wf)); h->d_wf = nullptr; h->wf_bytes = 0; }
+      hipError_t e = hipMalloc(&h->d_wf, bytes);
+      if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(wavefront queues): ") + hipGetErrorString(e));
+      h->wf_bytes = bytes;
+    }
+    float* base = h->d_wf;
+    WfQueue q[2];
+    for (int k = 0; k < 2; k++) {
+      for (int c = 0; c < 9; c++) q[k].f[c] = base + (static_cast<size_t>(k) * 13 + c) * q_len;
+      for (int c = 0; c < 4; c++) q[k].u[c] = reinterpret_cast<uint32_t*>(base + (static_cast<size_t>(k) * 13 + 9 + c) * q_len);
+    }
+    float* meas = base + 26 * q_len;
+    unsigned int* counts = reinterpret_cast<unsigned int*>(meas + 3 * n_paths);
+    HIP_TRY(hipMemsetAsync(counts, 0, n_counts * sizeof(unsigned int), h->stream));
+    WfArgs a;
+    a.scene = h->scene; a.meas = meas; a.counts = counts; a.ray_count = h->d_rays; a.hashed_seed = h->hashed_seed;
+    a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels;
+    a.first_sample = first_sample + done; a.n_samples = n; a.n_paths = static_cast<uint32_t>(n_paths); a.bounce = 0; a.shard_capacity = static_cast<uint32_t>(shard_capacity);
+    const uint32_t n_blocks = 2048u;                          // 8192 waves = 32 per shard
+    if (h->events_used == h->events.size()) {
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+      h->events.emplace_back(e0, e1);
+    }
+    auto& ev = h->events[h->events_used++];
+    HIP_TRY(hipEventRecord(ev.first, h->stream));
+    a.out = q[0]; a.in = q[1];
+    hipLaunchKernelGGL(wf_generate_kernel, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    uint32_t bounce = 0;
+    for (;;) {
+      const uint32_t burst = bounce < 16 ? 8 : 16;            // launches enqueued before the live count is read back
+      for (uint32_t k = 0; k < burst && bounce < kMaxBounces; k++, bounce++) {
+        a.bounce = bounce; a.in = q[bounce & 1]; a.out = q[(bounce + 1) & 1];
+        if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(wf_bounce_kernel<ENGINE_TWO_PHASE>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+        else if (h->hit_engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(wf_bounce_kernel<ENGINE_BVH>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+        else hipLaunchKernelGGL(wf_bounce_kernel<ENGINE_LIST>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+        HIP_TRY(hipGetLastError());
+      }
+      unsigned int shard_live[AMBER_WF_SHARDS];
+      HIP_TRY(hipMemcpyAsync(shard_live, counts + static_cast<size_t>(bounce) * AMBER_WF_SHARDS, sizeof shard_live, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      unsigned long long live = 0;
+      for (unsigned int v : shard_live) live += v;
+      if (live == 0) break;
+      if (bounce >= kMaxBounces) return Fail(AMBER_EHIP, "wavefront engine: path longer than 4096 bounces");
+    }
+    HIP_TRY(hipEventRecord(ev.second, h->stream));
+    const uint32_t n_elems = n_pixels * 3u;
+    hipLaunchKernelGGL(wf_reduce_kernel, dim3((n_elems + 255u) / 256u), dim3(256), 0, h->stream, h->d_fb, meas, n_pixels, n_chunks);
+    HIP_TRY(hipGetLastError());
+    done += n;
+  }
+  return AMBER_OK;
+}
+
+}  // namespace
+
+extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples) {
   if (!h) return Fail(AMBER_EINVAL, "null handle");
   if (n_samples == 0) return AMBER_OK;
   if (static_cast<uint64_t>(first_sample) + n_samples > 0xffffffffull) return Fail(AMBER_EINVAL, "sample index overflow");
   HIP_TRY(hipSetDevice(h->device));
+  if (h->engine == AMBER_ENGINE_WAVEFRONT) return RenderPassWavefront(h, first_sample, n_samples);
   const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
   // a launch covers at most kMaxPartialFloats of per-item sums and < 2^31 items; longer passes are split on
   // chunk boundaries, which leaves the summation order (chunks in order) unchanged
@@ -642,8 +729,8 @@ int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
     }
     auto& ev = h->events[h->events_used++];
     HIP_TRY(hipEventRecord(ev.first, h->stream));
-    if (h->engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(pt_megakernel<ENGINE_TWO_PHASE>, dim3(n_blocks), dim3(256), 0, h->stream, a);
-    else if (h->engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(pt_megakernel<ENGINE_BVH>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(pt_megakernel<ENGINE_TWO_PHASE>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else if (h->hit_engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(pt_megakernel<ENGINE_BVH>, dim3(n_blocks), dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL(pt_megakernel<ENGINE_LIST>, dim3(n_blocks), dim3(256), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, h->stream));
@@ -735,6 +822,7 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_prog_objects) (void)hipFree(h->d_prog_objects);
   if (h->d_bvh_nodes) (void)hipFree(h->d_bvh_nodes);
   if (h->d_bvh_prims) (void)hipFree(h->d_bvh_prims);
+  if (h->d_wf) (void)hipFree(h->d_wf);
   if (h->d_fb) (void)hipFree(h->d_fb);
   if (h->d_rays) (void)hipFree(h->d_rays);
   if (h->d_next) (void)hipFree(h->d_next);
@@ -754,8 +842,8 @@ int amber_hip_kat_cast(amber_hip_pt* h, uint32_t n, const float* origins, const 
   HIP_TRY(d_o.alloc(3 * n)); HIP_TRY(d_d.alloc(3 * n)); HIP_TRY(d_t.alloc(n)); HIP_TRY(d_p.alloc(3 * n)); HIP_TRY(d_n.alloc(3 * n)); HIP_TRY(d_i.alloc(n));
   HIP_TRY(hipMemcpy(d_o.p, origins, 3ull * n * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_d.p, dirs, 3ull * n * 4, hipMemcpyHostToDevice));
-  if (h->engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(kat_cast_kernel<ENGINE_TWO_PHASE>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
-  else if (h->engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(kat_cast_kernel<ENGINE_BVH>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
+  if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(kat_cast_kernel<ENGINE_TWO_PHASE>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
+  else if (h->hit_engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(kat_cast_kernel<ENGINE_BVH>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
   else hipLaunchKernelGGL(kat_cast_kernel<ENGINE_LIST>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, n, d_o.p, d_d.p, d_i.p, d_t.p, d_p.p, d_n.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -818,8 +906,8 @@ int amber_hip_kat_trace(amber_hip_pt* h, uint32_t n, const uint32_t* pixel, cons
   HIP_TRY(hipMemcpy(d_p.p, pixel, 4ull * n, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_s.p, sample, 4ull * n, hipMemcpyHostToDevice));
   HIP_TRY(hipMemsetAsync(d_r.p, 0, nrec * 4, h->stream));
-  if (h->engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(kat_trace_kernel<ENGINE_TWO_PHASE>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
-  else if (h->engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(kat_trace_kernel<ENGINE_BVH>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
+  if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(kat_trace_kernel<ENGINE_TWO_PHASE>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
+  else if (h->hit_engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(kat_trace_kernel<ENGINE_BVH>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
   else hipLaunchKernelGGL(kat_trace_kernel<ENGINE_LIST>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, d_p.p, d_s.p, max_bounces, d_r.p, d_c.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));

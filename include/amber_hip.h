@@ -119,7 +119,9 @@ enum {
   AMBER_ENGINE_AUTO = 0,       /* TWO_PHASE when the scene has <= 32 objects, BVH otherwise */
   AMBER_ENGINE_LIST = 1,       /* exact test of every object, wave-uniform scan (object data in SGPRs) */
   AMBER_ENGINE_TWO_PHASE = 2,  /* conservative wave-uniform candidate filter, then exact tests of the candidates only */
-  AMBER_ENGINE_BVH = 3         /* host-built flattened 2-wide BVH, per-lane traversal with an LDS stack, exact leaf tests */
+  AMBER_ENGINE_BVH = 3,        /* host-built flattened 2-wide BVH, per-lane traversal with an LDS stack, exact leaf tests */
+  AMBER_ENGINE_WAVEFRONT = 4   /* streaming formulation: SoA ray queues in HBM, one launch per bounce, ballot/prefix-sum
+                                  compaction; closest hit as AUTO.  Same results; kept to measure that design. */
 };
 
 typedef struct amber_hip_pt amber_hip_pt;

@@ -443,3 +443,24 @@ def test_million_spheres_bvh_properties(amber):
     rpp = rays / (W * H * spp)
     assert 1.5 < rpp < 12
     print(f"\\n1M spheres: scene+BVH build {t_build:.1f} s, {W}x{H}@{spp}: {ms:.1f} ms, {rays / ms / 1e3:.1f} Mrays/s, {rpp:.2f} rays/path")
+
+
+def test_wavefront_engine_is_bit_identical(amber, cornell, generic):
+    """Engine WAVEFRONT (SoA ray queues in HBM, one launch per bounce, ballot/prefix-sum compaction) == default engine."""
+    for (hs, osc), (W, H, passes) in ((cornell, (96, 80, [(0, 40), (40, 7)])), (generic, (64, 64, [(5, 33)]))):
+        sn = amber.Sensor.default(W, H)
+        a = amber.PathTracer(hs, sn, seed=17, engine=amber.ENGINE_WAVEFRONT)
+        b = amber.PathTracer(hs, sn, seed=17)
+        ref = np.zeros((H, W, 3), np.float32); casts = 0
+        for first, n in passes:
+            a.render_pass(first, n); b.render_pass(first, n)
+            _, c = osc.render_xorshift(W, H, 17, first, n, out=ref); casts += c.casts
+        (ia, ra), (ib, rb) = a.download(), b.download()
+        assert ra == rb == casts
+        assert np.array_equal(bits(ia), bits(ib)) and np.array_equal(bits(ia), bits(ref))
+    hs, _ = cornell
+    sn = amber.Sensor.default(512, 512)
+    a = amber.PathTracer(hs, sn, seed=2, engine=amber.ENGINE_WAVEFRONT, rows=(8, 512), stripe=(8, 16)); a.render_pass(0, 64)
+    b = amber.PathTracer(hs, sn, seed=2, rows=(8, 512), stripe=(8, 16)); b.render_pass(0, 64)
+    (ia, ra), (ib, rb) = a.download(), b.download()
+    assert ra == rb and np.array_equal(bits(ia), bits(ib))
