@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--spp-per-launch", type=int, default=1024)
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--engine", default="auto", choices=["auto", "list", "two_phase", "bvh", "wavefront"],
+                    help="closest-hit / scheduling engine (default: auto = the fastest valid one; others for comparison)")
     args = ap.parse_args()
 
     import numpy as np
@@ -90,7 +92,7 @@ def main():
     mine = parts[rank]
     stream = torch.cuda.current_stream().cuda_stream              # launch on torch's stream: ordered with the gather
     tracer = amber_amd.PathTracer(scene, sensor, seed=args.seed, device=local_rank, rows=mine["rows"], stripe=mine["stripe"],
-                                  stream=stream)
+                                  stream=stream, engine={"auto": 0, "list": 1, "two_phase": 2, "bvh": 3, "wavefront": 4}[args.engine])
     fb = band_tensor(tracer, f"cuda:{local_rank}")
     launches = [(s, min(args.spp_per_launch, args.spp - s)) for s in range(0, args.spp, args.spp_per_launch)]
 
@@ -147,10 +149,10 @@ def main():
             "config": {"workload": f"Cornell box (etude::CornelBox(0.050,0.050,6)) {W}x{H} @ {args.spp} spp, RR-only path tracing, "
                                    f"per-(pixel,sample) XorShift seed {args.seed}", "rays_per_step": rays // args.steps,
                        "paths_per_step": W * H * args.spp, "wall_s_per_step": round(dt_max / args.steps, 4),
-                       "parallelism": f"stripes{world}x8rows", "launches_per_step": len(launches), "engine": "work-queue megakernel, two-phase closest hit"},
+                       "parallelism": f"stripes{world}x8rows", "launches_per_step": len(launches), "engine": "work-queue megakernel, two-phase closest hit" if args.engine == "auto" else args.engine},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "pt_megakernel", "kernel_ms": round(kern_ms, 3),
+                         "kernel": "pt_megakernel" if args.engine != "wavefront" else "wf_generate + wf_bounce launches of one batch", "kernel_ms": round(kern_ms, 3),
                          "note": "achieved = rays per launch (rank 0) x 96 B algorithmic ray-state bytes / mean launch duration (hipEvents)"},
         }
         profs = sorted((ROOT / "profiles").glob("r*_hbm_traffic.json"))      # latest committed rocprofv3 PMC summary
