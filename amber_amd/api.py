@@ -29,7 +29,7 @@ class FlatMaterial(C.Structure):
 class FlatThinLens(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("global_", C.c_float * 9), ("local_", C.c_float * 9),
                 ("focus_distance", C.c_float), ("sensor_distance", C.c_float), ("p_area", C.c_float),
-                ("n_blades", C.c_uint32), ("first_blade_object", C.c_uint32)]
+                ("n_blades", C.c_uint32), ("first_blade_object", C.c_uint32), ("kind", C.c_uint32)]
 
 
 class FlatSceneC(C.Structure):
@@ -114,7 +114,7 @@ def load_library() -> C.CDLL:
     lib.amber_host_cornell_box.argtypes = [C.c_float, C.c_float, u32]
     lib.amber_host_scene_create.restype = vp
     lib.amber_host_scene_create.argtypes = [C.POINTER(FlatObject), u32, C.POINTER(FlatMaterial), u32, C.POINTER(C.c_float),
-                                            C.c_float, C.c_float, C.c_float, u32, C.c_int]
+                                            C.c_float, C.c_float, C.c_float, u32, C.c_int]   # n_blades == 0 selects the pinhole lens
     lib.amber_host_scene_destroy.argtypes = [vp]
     lib.amber_host_scene_destroy.restype = None
     lib.amber_host_scene_flatten.argtypes = [vp, C.POINTER(FlatObject), C.POINTER(u32), C.POINTER(FlatMaterial), C.POINTER(u32),

@@ -166,6 +166,7 @@ class ThinLens : public Lens {
     std::memcpy(L.local_, local_.e, sizeof L.local_);
     L.focus_distance = focus_distance_; L.sensor_distance = sensor_distance_; L.p_area = p_area_;
     L.n_blades = static_cast<uint32_t>(primitives_.size());
+    L.kind = AMBER_LENS_THIN;
   }
 
  private:
@@ -177,7 +178,37 @@ class ThinLens : public Lens {
   std::vector<Object> objects_;
 };
 
+// ---- pinhole lens (lens_pinhole.cc:31-106): a degenerate aperture triangle origin/origin/origin with the Eye
+// material is part of the scene exactly as in the reference (it can never be hit: its determinant is 0).
+class PinholeLens : public Lens {
+ public:
+  PinholeLens(const Matrix4& transform, real_type sensor_distance)
+      : origin_(transform(Vector3())), global_(static_cast<Matrix3>(transform)), local_(global_.Inverse()),
+        sensor_distance_(sensor_distance), eye_(MakeEye()), pinhole_(MakeTriangle(origin_, origin_, origin_)),
+        object_(pinhole_.get(), eye_.get()) {}
+  std::vector<const Object*> ApertureObjects() const noexcept override { return {&object_}; }
+  void Flatten(AmberFlatThinLens& L) const noexcept override {
+    Put3(L.origin, origin_);
+    std::memcpy(L.global_, global_.e, sizeof L.global_);
+    std::memcpy(L.local_, local_.e, sizeof L.local_);
+    L.focus_distance = 0; L.sensor_distance = sensor_distance_; L.p_area = 1;
+    L.n_blades = 1; L.kind = AMBER_LENS_PINHOLE;
+  }
+
+ private:
+  Vector3 origin_;
+  Matrix3 global_, local_;
+  real_type sensor_distance_;
+  std::unique_ptr<Material> eye_;
+  std::unique_ptr<Primitive> pinhole_;
+  Object object_;
+};
+
 }  // namespace
+
+std::unique_ptr<Lens> MakePinholeLens(const Matrix4& transform, real_type sensor_distance) {
+  return std::make_unique<PinholeLens>(transform, sensor_distance);
+}
 
 std::unique_ptr<Primitive> MakeSphere(const Vector3& c, real_type r) noexcept { return std::make_unique<Sphere>(c, r); }
 std::unique_ptr<Primitive> MakeTriangle(const Vector3& a, const Vector3& b, const Vector3& c) noexcept { return std::make_unique<Triangle>(a, b, c); }

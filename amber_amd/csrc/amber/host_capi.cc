@@ -40,8 +40,9 @@ amber_host_scene* amber_host_scene_create(const AmberFlatObject* objects, uint32
     std::vector<std::unique_ptr<Primitive>> primitives;
     std::vector<std::unique_ptr<RGBMaterial>> mats;
     std::vector<RGBObject> objs;
-    auto lens = MakeThinLens(Matrix4(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15]),
-                             focal_length, focus_distance, radius, n_blades);
+    const Matrix4 tm(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15]);
+    // n_blades == 0 selects MakePinholeLens(transform, sensor_distance = focal_length)
+    auto lens = n_blades ? MakeThinLens(tm, focal_length, focus_distance, radius, n_blades) : MakePinholeLens(tm, focal_length);
     for (const auto& o : lens->ApertureObjects()) objs.emplace_back(*o);
     for (uint32_t i = 0; i < n_materials; i++) {
       const AmberFlatMaterial& m = materials[i];

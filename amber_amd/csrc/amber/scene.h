@@ -97,6 +97,8 @@ class Lens {
 };
 std::unique_ptr<Lens> MakeThinLens(const Matrix4& transform, real_type focal_length, real_type focus_distance,
                                    real_type radius, std::size_t n_blades);
+/** scene/lens_pinhole.h:32-38 */
+std::unique_ptr<Lens> MakePinholeLens(const Matrix4& transform, real_type sensor_distance);
 
 // ---- acceleration tags (raytracer/forward.h) ------------------------------------------------------
 // The reference selects its acceleration structure with a template argument of Scene::Create.

@@ -86,6 +86,8 @@ struct DevLens {
   double sd2;                 // std::pow(sensor_distance_, 2) in double (lens_thin.cc:146)
   uint32_t n_blades;
   float n_blades_f;
+  uint32_t kind;              // 0 thin lens, 1 pinhole
+  float inv_scene_area;       // 1 / sensor.SceneArea() (lens_pinhole.cc:101)
 };
 struct DevSensor {
   uint32_t w, h;
@@ -625,6 +627,22 @@ __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 
 __device__ __forceinline__ void GenerateEyeRay(const DevScene& sc, uint32_t px, uint32_t py, uint64_t& rng,
                                                V3& origin, V3& dir, float& weight) {
   const DevLens& L = sc.lens;
+  if (L.kind == 1u) {                                      // BasicPinhole::GenerateRay lens_pinhole.cc:48-68
+    const float jy = Uniform(rng);
+    const float jx = Uniform(rng);
+    const float uvx = (static_cast<float>(px) + jx) / sc.sensor.wf;
+    const float uvy = (static_cast<float>(py) + jy) / sc.sensor.hf;
+    const V3 sensor_point = v3((uvx - 0.5f) * sc.sensor.sw, (uvy - 0.5f) * sc.sensor.sh, L.sensor_distance);
+    const V3 ray_dir = Normalize(MatMul(L.global_, -sensor_point));
+    // PDFDirection lens_pinhole.cc:93-106 (binary32 throughout; no sensor.Size() factor, unlike the thin lens)
+    const V3 dl = MatMul(L.local_, ray_dir);
+    const V3 point = (L.sensor_distance / dl.z) * dl;
+    const float geometry_factor = dl.z * dl.z / SquaredLength(point);
+    const float pdf_dir = L.inv_scene_area / geometry_factor;
+    origin = ld3(L.origin); dir = ray_dir;
+    weight = 1.0f / 1.0f / pdf_dir;                        // 1 / PDFArea (= kDiracDelta) / PDFDirection
+    return;
+  }
   const float fpos = __builtin_floorf(Uniform(rng) * L.n_blades_f);
   uint32_t pos = static_cast<uint32_t>(fpos);
   if (pos > L.n_blades - 1) pos = L.n_blades - 1;

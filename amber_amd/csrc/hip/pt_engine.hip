@@ -436,6 +436,7 @@ int ValidateScene(const AmberFlatScene* s, const AmberSensor* sensor) {
     if (s->materials[i].kind > AMBER_MAT_EYE) return Fail(AMBER_EINVAL, "material " + std::to_string(i) + ": unknown kind");
   const AmberFlatThinLens& L = s->lens;
   if (L.n_blades == 0) return Fail(AMBER_EINVAL, "lens has no aperture blades");
+  if (L.kind > AMBER_LENS_PINHOLE) return Fail(AMBER_EINVAL, "unknown lens kind");
   if (static_cast<uint64_t>(L.first_blade_object) + L.n_blades > s->n_objects) return Fail(AMBER_EINVAL, "aperture blade objects out of range");
   for (uint32_t i = 0; i < L.n_blades; i++)
     if (s->objects[L.first_blade_object + i].kind != AMBER_PRIM_TRIANGLE) return Fail(AMBER_EINVAL, "aperture blade is not a triangle");
@@ -597,6 +598,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   }
   sc.lens.sd2 = static_cast<double>(L.sensor_distance) * static_cast<double>(L.sensor_distance);
   sc.lens.n_blades = L.n_blades; sc.lens.n_blades_f = static_cast<float>(L.n_blades);
+  sc.lens.kind = L.kind;
+  { volatile float area = sensor->scene_width * sensor->scene_height; volatile float inv = 1.0f / area; sc.lens.inv_scene_area = inv; }
   sc.sensor.w = sensor->width; sc.sensor.h = sensor->height;
   sc.sensor.wf = static_cast<float>(sensor->width); sc.sensor.hf = static_cast<float>(sensor->height);
   sc.sensor.sw = sensor->scene_width; sc.sensor.sh = sensor->scene_height;

@@ -74,7 +74,12 @@ typedef struct {
   float    r0;
 } AmberFlatMaterial;
 
-/* thin lens, lens_thin.cc:32-57 (all derived values computed by the host object model) */
+/* lens (all derived values computed by the host object model).
+ * kind AMBER_LENS_THIN:    lens_thin.cc:32-57.
+ * kind AMBER_LENS_PINHOLE: lens_pinhole.cc:31-106; sensor_distance as given, n_blades = 1 (the degenerate aperture
+ *                          triangle origin/origin/origin that the reference inserts into the scene), focus_distance and
+ *                          p_area unused. */
+enum { AMBER_LENS_THIN = 0, AMBER_LENS_PINHOLE = 1 };
 typedef struct {
   float    origin[3];
   float    global_[9];         /* Matrix3, row-major */
@@ -84,6 +89,7 @@ typedef struct {
   float    p_area;             /* 1 / (blade area * n_blades) */
   uint32_t n_blades;
   uint32_t first_blade_object; /* objects[first_blade_object + i] is aperture blade i */
+  uint32_t kind;               /* AMBER_LENS_* */
 } AmberFlatThinLens;
 
 typedef struct {

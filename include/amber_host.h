@@ -25,6 +25,7 @@ amber_host_scene* amber_host_cornell_box(float focal_length, float aperture_radi
 /* Generic scene through the Make* factories.  objects[i].p uses the AmberFlatObject layout WITHOUT
  * the triangle normal (the model computes it); materials[i].r0 is ignored (the model computes it).
  * The lens' aperture blades are inserted first, as cornel_box.cc:62-64 does.  accel: 0 = BVH, 1 = List.
+ * n_blades == 0 builds MakePinholeLens(transform, sensor_distance = focal_length) instead of the thin lens.
  * Returns NULL on error (amber_host_last_error()). */
 amber_host_scene* amber_host_scene_create(const AmberFlatObject* objects, uint32_t n_objects,
                                           const AmberFlatMaterial* materials, uint32_t n_materials,

@@ -592,6 +592,7 @@ struct M3 {
   }
 };
 struct ThinLens {
+  int kind = 0;                     // 0 thin (lens_thin.cc), 1 pinhole (lens_pinhole.cc)
   V3 origin; M3 global_, local_;
   std::vector<Object> blades;       // lens-owned aperture triangles (lens_thin.cc:46-55)
   float focus_distance, sensor_distance, p_area;
@@ -630,6 +631,24 @@ struct EyeRay { V3 origin, normal, dir; float weight; uint32_t blade; };
 // unspecified by C++; the reference's recorded outputs come from g++ 11.4 which evaluates the
 // SECOND argument (Y) first.  The oracle fixes that order: draw#4 -> Y, draw#5 -> X.
 EyeRay GenerateEyeRay(const ThinLens& L, const Sensor& S, uint64_t px, uint64_t py, Sampler& smp, const Math& M) {
+  if (L.kind == 1) {                                                     // BasicPinhole::GenerateRay lens_pinhole.cc:48-68
+    const float jy = UniformF(smp);
+    const float jx = UniformF(smp);
+    const float uvx = (px + jx) / S.w;
+    const float uvy = (py + jy) / S.h;
+    const V3 sensor_point = v3((uvx - 0.5f) * S.sw, (uvy - 0.5f) * S.sh, L.sensor_distance);
+    const V3 ray_dir = Normalize(L.global_(-sensor_point));              // Ray(origin, Vector3) normalises
+    // PDFDirection lens_pinhole.cc:93-106
+    const V3 direction = L.local_(ray_dir);
+    const V3 point = L.sensor_distance / direction.z * direction;
+    const float p_area = 1 / (S.sw * S.sh);
+    const float geometry_factor = direction.z * direction.z / SquaredLength(point);
+    const float pdf_dir = p_area / geometry_factor;
+    EyeRay e;
+    e.origin = L.origin; e.normal = Normalize(L.global_(v3(0, 0, -1))); e.dir = ray_dir; e.blade = 0;
+    e.weight = 1 / static_cast<float>(1.0L) / pdf_dir;                   // 1 / PDFArea(kDiracDelta -> real_type) / PDFDirection
+    return e;
+  }
   const std::size_t nb = L.blades.size();
   const std::size_t pos = std::min<std::size_t>(nb - 1, std::floor(UniformF(static_cast<float>(nb), smp)));
   const Object& tri = L.blades[pos];
@@ -756,7 +775,21 @@ oracle_scene* oracle_scene_create(const oracle_object* objects, uint32_t n_objec
   Material eye; eye.kind = ORACLE_MAT_EYE; eye.rho = splat(1);
   sc->materials.push_back(eye);
   const uint32_t eye_id = static_cast<uint32_t>(sc->materials.size() - 1);
-  sc->lens = MakeThinLens(lens->transform, lens->focal_length, lens->focus_distance, lens->radius, lens->n_blades, eye_id, M);
+  if (lens->n_blades == 0) {   // MakePinholeLens(transform, sensor_distance = focal_length), lens_pinhole.cc:31-46
+    const float* t = lens->transform;
+    ThinLens L;
+    L.kind = 1;
+    L.origin = v3(t[0] * 0.0f + t[1] * 0.0f + t[2] * 0.0f + t[3], t[4] * 0.0f + t[5] * 0.0f + t[6] * 0.0f + t[7],
+                  t[8] * 0.0f + t[9] * 0.0f + t[10] * 0.0f + t[11]);
+    const float g[9] = {t[0], t[1], t[2], t[4], t[5], t[6], t[8], t[9], t[10]};
+    std::memcpy(L.global_.e, g, sizeof g);
+    L.local_ = L.global_.Inverse();
+    L.focus_distance = 0; L.sensor_distance = lens->focal_length; L.p_area = 1;
+    L.blades.push_back(MakeTriangle(L.origin, L.origin, L.origin, eye_id));
+    sc->lens = L;
+  } else {
+    sc->lens = MakeThinLens(lens->transform, lens->focal_length, lens->focus_distance, lens->radius, lens->n_blades, eye_id, M);
+  }
   for (const Object& b : sc->lens.blades) sc->objects.push_back(b);     // cornel_box.cc:62-64
   for (uint32_t i = 0; i < n_objects; i++) {
     Object o; o.kind = objects[i].kind; o.material = objects[i].material;

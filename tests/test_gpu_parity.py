@@ -464,3 +464,24 @@ def test_wavefront_engine_is_bit_identical(amber, cornell, generic):
     b = amber.PathTracer(hs, sn, seed=2, rows=(8, 512), stripe=(8, 16)); b.render_pass(0, 64)
     (ia, ra), (ib, rb) = a.download(), b.download()
     assert ra == rb and np.array_equal(bits(ia), bits(ib))
+
+
+def test_pinhole_lens(amber):
+    """MakePinholeLens (lens_pinhole.cc:31-106): eye rays, path traces and an image against the oracle."""
+    pin = dict(SCENE, n_blades=0, focal_length=0.045)          # n_blades = 0 selects the pinhole; focal_length = sensor distance
+    hs, osc = amber.HostScene.create(**pin), O.Scene.create(**pin)
+    objs, mats, lens = hs.flatten()
+    assert lens.kind == 1 and lens.n_blades == 1 and np.float32(lens.sensor_distance) == np.float32(0.045)
+    W, H = 56, 40
+    pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=6)
+    px = np.arange(0, W * H, 3, dtype=np.uint32); sm = (px % 7).astype(np.uint32)
+    eye = pt.kat_eye(px, sm)
+    for i in range(0, len(px), 9):
+        _, _, e = osc.trace(W, H, 6, int(px[i] % W), int(px[i] // W), int(sm[i]), max_bounces=1)
+        assert np.array_equal(bits(eye[i]), bits(e))
+    assert np.all(eye[:, :3] == np.array(lens.origin[:], np.float32))   # every ray leaves the pinhole itself
+    _compare_traces(pt, osc, W, H, 6, px[:400], sm[:400])
+    pt.render_pass(0, 48)
+    img, rays = pt.download()
+    ref, cnt = osc.render_xorshift(W, H, 6, 0, 48)
+    assert rays == cnt.casts and np.array_equal(bits(img), bits(ref)) and (img > 0).any()

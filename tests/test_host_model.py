@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(amber):
 def test_struct_layouts_match_the_header(amber):
     from amber_amd import api
     assert C.sizeof(api.FlatObject) == 56 and C.sizeof(api.FlatMaterial) == 24
-    assert C.sizeof(api.FlatThinLens) == 4 * (3 + 9 + 9 + 3 + 2)
+    assert C.sizeof(api.FlatThinLens) == 4 * (3 + 9 + 9 + 3 + 3)
     assert C.sizeof(api.Sensor) == 16 and C.sizeof(api.PtParams) == 48
 
 
