@@ -21,7 +21,9 @@ from .api import (  # noqa: F401
     Sensor,
     build_library,
     device_count,
+    export,
     kat_math,
     library_path,
     load_library,
+    tonemap,
 )

@@ -68,7 +68,7 @@ ABI_SYMBOLS = [
     "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_device_count",
     "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math",
     "amber_host_cornell_box", "amber_host_scene_create", "amber_host_scene_destroy", "amber_host_scene_flatten",
-    "amber_host_pt_create", "amber_host_render", "amber_host_last_error",
+    "amber_host_pt_create", "amber_host_render", "amber_host_last_error", "amber_host_tonemap", "amber_host_export",
 ]
 
 
@@ -121,6 +121,8 @@ def load_library() -> C.CDLL:
                                              C.POINTER(FlatThinLens)]
     lib.amber_host_pt_create.argtypes = [vp, C.POINTER(Sensor), C.POINTER(PtParams), C.POINTER(vp)]
     lib.amber_host_render.argtypes = [vp, C.c_char_p, C.POINTER(Sensor), u32, u64, u32, C.c_int, u32, vp, C.POINTER(HostStats)]
+    lib.amber_host_tonemap.argtypes = [vp, u32, u32, vp]
+    lib.amber_host_export.argtypes = [vp, u32, u32, C.c_char_p, C.c_char_p]
     _lib = lib
     return lib
 
@@ -327,3 +329,20 @@ def kat_math(mode: int, x, device: int = 0) -> np.ndarray:
     out = np.empty((n, 2) if mode == 0 else (n,), np.float32)
     _check(load_library().amber_hip_kat_math(device, mode, n, x.ctypes.data, out.ctypes.data))
     return out
+
+
+def tonemap(image) -> np.ndarray:
+    """Filmic -> Gamma 2.2 -> 8-bit (postprocess/filmic.cc, gamma.cc), image (H, W, 3) float32."""
+    img = _f32(image)
+    h, w, _ = img.shape
+    out = np.empty((h, w, 3), np.uint8)
+    _check(load_library().amber_host_tonemap(img.ctypes.data, w, h, out.ctypes.data), host=True)
+    return out
+
+
+def export(image, png_path=None, exr_path=None) -> None:
+    """cli::ExportPNG (tone-mapped) / cli::ExportEXR (raw), x-mirrored as the reference writes them."""
+    img = _f32(image)
+    h, w, _ = img.shape
+    _check(load_library().amber_host_export(img.ctypes.data, w, h, png_path.encode() if png_path else None,
+                                            exr_path.encode() if exr_path else None), host=True)

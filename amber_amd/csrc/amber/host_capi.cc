@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../../../include/amber_host.h"
+#include "postprocess.h"
 #include "rendering.h"
 #include "scene.h"
 
@@ -129,6 +130,35 @@ int amber_host_render(const amber_host_scene* s, const char* algorithm, const Am
     return AMBER_OK;
   } catch (const cli::UnknownAlgorithmError& e) { return Fail(AMBER_EINVAL, e.what()); }
   catch (const std::exception& e) { return Fail(AMBER_EHIP, e.what()); }
+}
+
+extern "C++" {
+namespace {
+postprocess::HDRImage ToImage(const float* rgb, uint32_t w, uint32_t h) {
+  postprocess::HDRImage img(w, h);
+  std::memcpy(img.Data(), rgb, static_cast<size_t>(w) * h * 3 * sizeof(float));
+  return img;
+}
+}  // namespace
+}  // extern "C++"
+
+int amber_host_tonemap(const float* rgb, uint32_t width, uint32_t height, uint8_t* out_rgb8) {
+  if (!rgb || !out_rgb8 || !width || !height) return Fail(AMBER_EINVAL, "bad argument");
+  try {
+    const auto ldr = postprocess::Gamma()(postprocess::Filmic()(ToImage(rgb, width, height)));
+    std::memcpy(out_rgb8, ldr.rgb.data(), ldr.rgb.size());
+    return AMBER_OK;
+  } catch (const std::exception& e) { return Fail(AMBER_EINVAL, e.what()); }
+}
+
+int amber_host_export(const float* rgb, uint32_t width, uint32_t height, const char* png_path, const char* exr_path) {
+  if (!rgb || !width || !height) return Fail(AMBER_EINVAL, "bad argument");
+  try {
+    const auto img = ToImage(rgb, width, height);
+    if (png_path) cli::ExportPNG(postprocess::Gamma()(postprocess::Filmic()(img)), png_path);
+    if (exr_path) cli::ExportEXR(img, exr_path);
+    return AMBER_OK;
+  } catch (const std::exception& e) { return Fail(AMBER_EINVAL, e.what()); }
 }
 
 }  // extern "C"

@@ -47,6 +47,11 @@ int amber_host_render(const amber_host_scene*, const char* algorithm, const Ambe
                       uint64_t seed, uint32_t max_depth, int device, uint32_t samples_per_launch,
                       float* out_rgb, AmberHostStats* stats);
 
+/* Output stage (application.cc:98-115): Filmic -> Gamma -> 8-bit RGB (out_rgb8: w*h*3, Image layout, NOT mirrored). */
+int amber_host_tonemap(const float* rgb, uint32_t width, uint32_t height, uint8_t* out_rgb8);
+/* cli::ExportPNG / cli::ExportEXR (cli/image.cc:45-71): x-mirrored files.  rgb: float image; png is tone-mapped first. */
+int amber_host_export(const float* rgb, uint32_t width, uint32_t height, const char* png_path, const char* exr_path);
+
 const char* amber_host_last_error(void);
 
 #ifdef __cplusplus
