@@ -485,3 +485,35 @@ def test_pinhole_lens(amber):
     img, rays = pt.download()
     ref, cnt = osc.render_xorshift(W, H, 6, 0, 48)
     assert rays == cnt.casts and np.array_equal(bits(img), bits(ref)) and (img > 0).any()
+
+
+def test_baseline_configs_4_and_5_geometry(amber, cornell):
+    """BASELINE configs 4 (2048x2048, 4-GPU shard) and 5 (3840x2160, max depth 16, 8-GPU shard) at a reduced sample
+    count: one rank's stripe set rendered alone equals the same rows of the full frame, ray counts add up over ranks,
+    max_depth truncation never exceeds 16 casts per path and only lowers the ray count."""
+    from amber_amd.distributed import stripe_partition
+    hs, osc = cornell
+    for (W, H, world, depth, spp) in ((2048, 2048, 4, 0, 4), (3840, 2160, 8, 16, 2)):
+        sn = amber.Sensor.default(W, H)
+        full = amber.PathTracer(hs, sn, seed=4, max_depth=depth)
+        full.render_pass(0, spp)
+        img, rays = full.download()
+        full.close()
+        assert np.isfinite(img).all()
+        parts = stripe_partition(H, world)
+        tot = 0
+        for r in (0, world - 1):
+            pt = amber.PathTracer(hs, sn, seed=4, max_depth=depth, rows=parts[r]["rows"], stripe=parts[r]["stripe"])
+            pt.render_pass(0, spp)
+            b, rr = pt.download(); pt.close()
+            assert np.array_equal(bits(b), bits(img[parts[r]["index"]]))
+            tot += rr
+        assert 0 < tot < rays
+        if depth:
+            free = amber.PathTracer(hs, sn, seed=4); free.render_pass(0, spp)
+            rays_free = free.ray_count(); free.close()
+            assert rays < rays_free                                             # truncation only removes tails
+            px = np.arange(0, W * H, 9973, dtype=np.uint32); sm = (px % spp).astype(np.uint32)
+            pt = amber.PathTracer(hs, sn, seed=4, max_depth=depth)
+            _, casts = pt.kat_trace(px, sm, depth)
+            assert casts.max() <= depth
