@@ -575,15 +575,31 @@ __device__ __forceinline__ V3 Radiance(const DevMaterial& m, V3 normal, V3 dir_o
 __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 dir_out, uint64_t& rng, V3& dir_in, V3& weight) {
   const V3 rho = ld3(m.rho);
   const uint32_t kind = m.kind;
-  if (kind == MAT_LAMBERTIAN) {                          // material_lambertian.cc:61-70
-    const V3 w = Dot(dir_out, normal) > 0.0f ? normal : -normal;
-    dir_in = HemispherePSA(w, rng);
-    weight = 1.0f * rho;
-  } else if (kind == MAT_PHONG) {                        // material_phong.cc:81-106
+  if (kind == MAT_LAMBERTIAN || kind == MAT_PHONG) {
+    // Lambertian (material_lambertian.cc:61-70, HemispherePSA sampling.h:234-265) and Phong (material_phong.cc:81-106,
+    // CosinePower sampling.h:267-300) share the lobe construction -- orthonormal basis, two uniforms, sin/cos of phi,
+    // the three-term combination -- and differ only in the lobe axis and in cos(theta).  One code path serves both,
+    // so a wave with lanes on both materials pays for the shared part once; each lane still executes exactly the
+    // operations of its own material (Phong re-samples until the direction is on the side of dir_out).
+    const bool phong = kind == MAT_PHONG;
     const float signed_cos_o = Dot(dir_out, normal);
-    const V3 refl = PerfectReflection(dir_out, normal, signed_cos_o);
+    const V3 w = phong ? PerfectReflection(dir_out, normal, signed_cos_o) : (signed_cos_o > 0.0f ? normal : -normal);
+    V3 u, v; OrthonormalBasis(w, u, v);                  // CosinePower rebuilds the same basis on every attempt
     for (;;) {
-      const V3 di = CosinePower(refl, m.param, rng);
+      const float r0 = Uniform(rng);
+      const float r1 = Uniform(rng);
+      float cos_theta, sin_theta;
+      if (phong) {
+        cos_theta = Pow(r0, 1.0f / (m.param + 1.0f));
+        sin_theta = Sqrt(1.0f - cos_theta * cos_theta);
+      } else {
+        cos_theta = Sqrt(r0);
+        sin_theta = Sqrt(1.0f - r0);
+      }
+      const float phi = 2.0f * 3.14159274f * r1;
+      float sp, cp; SinCos(phi, sp, cp);
+      const V3 di = u * sin_theta * cp + v * sin_theta * sp + w * cos_theta;
+      if (!phong) { dir_in = di; weight = 1.0f * rho; break; }
       const float signed_cos_i = Dot(di, normal);
       if (signed_cos_o * signed_cos_i <= 0.0f) continue;
       dir_in = di;
