@@ -49,8 +49,10 @@ struct alignas(16) DevMaterial {  // 32 B
   uint32_t kind; float rho[3];
   float param; float r0; float pad[2];
 };
-struct alignas(16) DevBlade {     // 48 B: aperture triangle with explicit vertices (SampleSurfacePoint)
+struct alignas(16) DevBlade {     // 64 B: aperture triangle with explicit vertices (SampleSurfacePoint)
   float v0[3], v1[3], v2[3], n[3];
+  int32_t slot;                   // the blade's slot in the two-phase filter program (-1 if it is not a filtered triangle)
+  int32_t pad[3];
 };
 // Phase-A program of the two-phase closest hit (conservative candidate filter): coplanar
 // triangles share one plane record, so the plane hit point is computed once per plane.  All wave-uniform, scalar-loaded.
@@ -367,7 +369,7 @@ __device__ __forceinline__ void ClosestHitList(const DevScene& sc, V3 o, V3 d, H
 //  only, object records gathered from the LDS copy; the (t, index) tie rule makes the visiting order irrelevant.
 //  The result is identical to ClosestHitList (tests: full-image and per-ray equality of both engines).
 #define AMBER_GRAZING 1e-3f
-__device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const DevObject* lds_objects, V3 o, V3 d, HitRec& best AMBER_STAMP_PARAM) {
+__device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const DevObject* lds_objects, V3 o, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM) {
   best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;
   uint32_t cand = sc.always_mask;
   {
@@ -409,6 +411,23 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
     }
   }
   AMBER_STAMP(2);
+  // Self trip.  A ray that leaves a triangle always re-selects that triangle in Phase A (t' ~ 0), and the exact test
+  // then rejects it at its LAST step, t < kEPS (primitive_triangle.cc:122-125), after two wasted divisions.  All lanes
+  // that carry such a self candidate evaluate just t -- the same operations the full test performs -- in one
+  // common trip; "t <= kEPS" means the full test would reject whatever u and v are, so the bit is cleared.
+  // Otherwise (t above kEPS, or NaN) the bit stays and the full exact test decides below.
+  {
+    const bool has_self = origin_slot >= 0 && ((cand >> (origin_slot & 31)) & 1u) != 0u;
+    if (__any(has_self)) {
+      if (has_self) {
+        const DevObject& ob = lds_objects[origin_slot];
+        const V3 A = ld3(ob.a), E1 = ld3(ob.e1), E2 = ld3(ob.e2);
+        const float det = Dot(Cross(d, E2), E1);
+        const float t = Dot(Cross(o - A, E1), E2) / det;
+        if (t <= AMBER_KEPS) cand &= ~(1u << origin_slot);
+      }
+    }
+  }
   // Phase B: filtered triangles first, then everything else (keeps the per-lane kind branch out of the hot loop)
   const uint32_t tri_bits = sc.n_prog_tris >= 32u ? 0xffffffffu : ((1u << sc.n_prog_tris) - 1u);
   uint32_t mt = cand & tri_bits;
@@ -498,8 +517,8 @@ __device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_s
 enum { ENGINE_LIST = 1, ENGINE_TWO_PHASE = 2, ENGINE_BVH = 3 };
 
 template <int kEngine>
-__device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3 o, V3 d, HitRec& best AMBER_STAMP_PARAM) {
-  if (kEngine == ENGINE_TWO_PHASE) ClosestHitTwoPhase(sc, lds_objects, o, d, best AMBER_STAMP_ARG);
+__device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3 o, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM) {
+  if (kEngine == ENGINE_TWO_PHASE) ClosestHitTwoPhase(sc, lds_objects, o, d, origin_slot, best AMBER_STAMP_ARG);
   else if (kEngine == ENGINE_BVH) ClosestHitBvh(sc, lds_stack, o, d, best);
   else ClosestHitList(sc, o, d, best);
   AMBER_STAMP(3);
@@ -641,7 +660,7 @@ __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 
 // (sensor.cc:111-120, jitter draw order Y then X -- the g++ order the reference outputs were made with)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void GenerateEyeRay(const DevScene& sc, uint32_t px, uint32_t py, uint64_t& rng,
-                                               V3& origin, V3& dir, float& weight) {
+                                               V3& origin, V3& dir, float& weight, int& origin_slot) {
   const DevLens& L = sc.lens;
   if (L.kind == 1u) {                                      // BasicPinhole::GenerateRay lens_pinhole.cc:48-68
     const float jy = Uniform(rng);
@@ -657,6 +676,7 @@ __device__ __forceinline__ void GenerateEyeRay(const DevScene& sc, uint32_t px, 
     const float pdf_dir = L.inv_scene_area / geometry_factor;
     origin = ld3(L.origin); dir = ray_dir;
     weight = 1.0f / 1.0f / pdf_dir;                        // 1 / PDFArea (= kDiracDelta) / PDFDirection
+    origin_slot = -1;
     return;
   }
   const float fpos = __builtin_floorf(Uniform(rng) * L.n_blades_f);
@@ -679,6 +699,7 @@ __device__ __forceinline__ void GenerateEyeRay(const DevScene& sc, uint32_t px, 
   const V3 dloc = MatMul(L.local_, ray_dir);
   const float pdf_dir = static_cast<float>(static_cast<double>(L.size_over_area) * L.sd2 / Pow4(dloc.z));
   origin = ap_origin; dir = ray_dir;
+  origin_slot = bl->slot;                                  // the eye ray starts ON this aperture triangle
   weight = static_cast<float>(factor / static_cast<double>(L.p_area) / static_cast<double>(pdf_dir));
 }
 
@@ -690,9 +711,9 @@ struct Bounce { int object; float t; V3 pos; V3 weight_before; };
 
 template <bool kTrace, int kEngine>
 __device__ __forceinline__ bool PathStep(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3& o, V3& d, V3& weight, V3& measurement,
-                                         uint64_t& rng, uint32_t& casts, Bounce* trace AMBER_STAMP_PARAM) {
+                                         uint64_t& rng, uint32_t& casts, int& origin_slot, Bounce* trace AMBER_STAMP_PARAM) {
   HitRec h;
-  ClosestHit<kEngine>(sc, lds_objects, lds_stack, o, d, h AMBER_STAMP_ARG);
+  ClosestHit<kEngine>(sc, lds_objects, lds_stack, o, d, origin_slot, h AMBER_STAMP_ARG);
   casts++;
   if (h.idx < 0) {
     if (kTrace) { trace->object = -1; trace->t = __builtin_nanf(""); trace->pos = v3(0, 0, 0); trace->weight_before = v3(0, 0, 0); }
@@ -714,6 +735,7 @@ __device__ __forceinline__ bool PathStep(const DevScene& sc, const DevObject* ld
   if (Uniform(rng) >= p_rr) return false;                                    // :151-153
   if (sc.max_depth && casts >= sc.max_depth) return false;                   // build-side extension (BASELINE config 5)
   o = pos; d = dir_in;                                                       // :155 Ray(pos, UnitVector3) -- no renormalisation
+  origin_slot = (kEngine == ENGINE_TWO_PHASE && static_cast<uint32_t>(h.slot) < sc.n_prog_tris) ? h.slot : -1;
   weight = weight * (sw / p_rr);                                             // :156
   return true;
 }

@@ -58,8 +58,11 @@ struct RenderArgs {
 // empty.  A lane walks the samples of its item in order (sum += measurement), regenerating the eye ray in
 // place when a path ends, and stores the item's sum to partial[chunk][pixel]; reduce_partials_kernel adds the
 // chunks to the framebuffer in chunk order.  The summation order is therefore fixed.
+#ifndef AMBER_MEGAKERNEL_WAVES_PER_SIMD
+#define AMBER_MEGAKERNEL_WAVES_PER_SIMD 1   // no register cap: 93 VGPRs -> 5 waves/SIMD (6 would spill 8 dwords; measured slower/faster: DESIGN.md)
+#endif
 template <int kEngine>
-__global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
+__global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megakernel(const RenderArgs a) {
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
   constexpr bool kTwoPhase = kEngine == ENGINE_TWO_PHASE;
@@ -75,6 +78,7 @@ __global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
   V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), w = v3(0.f, 0.f, 0.f);
   uint64_t rng = 1;
   uint32_t casts = 0, rays = 0;
+  int origin_slot = -1;                      // filter-program slot of the triangle the current ray starts on
 #ifdef AMBER_STAMPS
   StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
   stamp_ctx->last = __builtin_amdgcn_s_memtime();
@@ -129,7 +133,7 @@ __global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
     if (!alive && !lane_done) {                             // regenerate: next sample of the item
       rng = XorShiftSeed(a.hashed_seed, pixel, s);
       float ew;
-      GenerateEyeRay(sc, px, py, rng, o, d, ew);
+      GenerateEyeRay(sc, px, py, rng, o, d, ew, origin_slot);
       w = v3(ew, ew, ew);                                   // Leading<RGB>(.., Radiant(weight)) lens_basic.h:139-144
       meas = v3(0.f, 0.f, 0.f);
       casts = 0;
@@ -138,7 +142,7 @@ __global__ void __launch_bounds__(256) pt_megakernel(const RenderArgs a) {
     }
     AMBER_STAMP(1);
     if (alive) {
-      alive = PathStep<false, kEngine>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, nullptr AMBER_STAMP_ARG);
+      alive = PathStep<false, kEngine>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG);
       ++rays;
       if (!alive) sum = sum + meas;                         // sequential sum over the item's samples
     }
@@ -181,7 +185,7 @@ __global__ void kat_cast_kernel(const DevScene sc, uint32_t n, const float* org,
 #ifdef AMBER_STAMPS
   StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
 #endif
-  ClosestHit<kEngine>(sc, lds_objects, lds_stack, o, d, h AMBER_STAMP_ARG);
+  ClosestHit<kEngine>(sc, lds_objects, lds_stack, o, d, -1, h AMBER_STAMP_ARG);
   if (i >= n) return;
   out_obj[i] = h.idx;
   if (h.idx < 0) {
@@ -214,8 +218,8 @@ __global__ void kat_eye_kernel(const DevScene sc, uint64_t hashed_seed, uint32_t
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t rng = XorShiftSeed(hashed_seed, pixel[i], sample[i]);
-  V3 o, d; float w;
-  GenerateEyeRay(sc, pixel[i] % sc.sensor.w, pixel[i] / sc.sensor.w, rng, o, d, w);
+  V3 o, d; float w; int origin_slot;
+  GenerateEyeRay(sc, pixel[i] % sc.sensor.w, pixel[i] / sc.sensor.w, rng, o, d, w, origin_slot);
   float* p = out7 + 7 * i;
   p[0] = o.x; p[1] = o.y; p[2] = o.z; p[3] = d.x; p[4] = d.y; p[5] = d.z; p[6] = w;
 }
@@ -230,8 +234,8 @@ __global__ void kat_trace_kernel(const DevScene sc, uint64_t hashed_seed, uint32
   __shared__ int32_t lds_stack[kEngine == ENGINE_BVH ? AMBER_BVH_STACK * 256 : 1];
   if (kTwoPhase) StageObjects(sc, lds_objects);
   uint64_t rng = XorShiftSeed(hashed_seed, pixel[k], sample[k]);
-  V3 o, d; float ew;
-  GenerateEyeRay(sc, pixel[k] % sc.sensor.w, pixel[k] / sc.sensor.w, rng, o, d, ew);
+  V3 o, d; float ew; int origin_slot;
+  GenerateEyeRay(sc, pixel[k] % sc.sensor.w, pixel[k] / sc.sensor.w, rng, o, d, ew, origin_slot);
   V3 w = v3(ew, ew, ew), meas = v3(0.f, 0.f, 0.f);
   uint32_t casts = 0;
   bool alive = true;
@@ -242,7 +246,7 @@ __global__ void kat_trace_kernel(const DevScene sc, uint64_t hashed_seed, uint32
 #ifdef AMBER_STAMPS
       StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
 #endif
-      alive = PathStep<true, kEngine>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, &b AMBER_STAMP_ARG);
+      alive = PathStep<true, kEngine>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, origin_slot, &b AMBER_STAMP_ARG);
       if (i < n && casts <= max_bounces) {
         uint32_t* r = out_records + (static_cast<size_t>(i) * max_bounces + (casts - 1)) * 11u;
         r[0] = static_cast<uint32_t>(b.object);
@@ -296,8 +300,10 @@ struct amber_hip_pt {
   uint32_t hit_engine = AMBER_ENGINE_LIST;  // closest-hit engine the kernels are instantiated with
   float* d_wf = nullptr; size_t wf_bytes = 0;   // WAVEFRONT: queues + meas + counts in one allocation
   uint32_t n_materials = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per timed launch
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // pool of event pairs, one per timed launch in flight
   size_t events_used = 0;
+  uint32_t timed_launches = 0;     // launches already folded into timed_ms
+  double timed_ms = 0;
 };
 
 namespace {
@@ -524,6 +530,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   for (uint32_t i = 0; i < L.n_blades; i++) {
     const AmberFlatObject& f = s->objects[L.first_blade_object + i];
     for (int c = 0; c < 3; c++) { blades[i].v0[c] = f.p[c]; blades[i].v1[c] = f.p[3 + c]; blades[i].v2[c] = f.p[6 + c]; blades[i].n[c] = f.p[9 + c]; }
+    blades[i].slot = -1; blades[i].pad[0] = blades[i].pad[1] = blades[i].pad[2] = 0;
   }
 
   const uint32_t auto_hit = s->n_objects <= AMBER_MAX_LDS_OBJECTS ? AMBER_ENGINE_TWO_PHASE : AMBER_ENGINE_BVH;
@@ -537,6 +544,9 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   }
   FilterProgram fprog;
   if (h->two_phase) BuildFilterProgram(objs, fprog);
+  for (uint32_t i = 0; i < L.n_blades; i++)            // filter-program slot of every aperture blade (self-candidate trip)
+    for (uint32_t k = 0; k < fprog.n_prog_tris; k++)
+      if (fprog.order[k] == L.first_blade_object + i) blades[i].slot = static_cast<int32_t>(k);
 
   auto cleanup = [&](int code, const std::string& msg) { amber_hip_pt_destroy(h); return Fail(code, msg); };
 #define HIP_TRY_H(expr)                                                                            \
@@ -608,6 +618,30 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
 }
 
 namespace {
+// Hands out the next event pair; when the pool of 64 is used up the finished launches are folded into the running
+// totals (one stream synchronisation every 64 launches), so long renders (--spp 0 until expiry) do not grow the pool.
+int AcquireEventPair(amber_hip_pt* h, std::pair<hipEvent_t, hipEvent_t>** out) {
+  if (h->events_used == 64) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->events_used; i++) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second));
+      h->timed_ms += ms;
+    }
+    h->timed_launches += static_cast<uint32_t>(h->events_used);
+    h->events_used = 0;
+  }
+  if (h->events_used == h->events.size()) {
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    h->events.emplace_back(e0, e1);
+  }
+  *out = &h->events[h->events_used++];
+  return AMBER_OK;
+}
+}  // namespace
+
+namespace {
 
 // Engine WAVEFRONT host loop: batches of <= max_chunks accumulation chunks; per batch generate, then bounce launches
 // until the live-ray count read back from the device is zero, then the ordered reduction into the framebuffer.
@@ -649,12 +683,9 @@ int RenderPassWavefront(amber_hip_pt* h, uint32_t first_sample, uint32_t n_sampl
     a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels;
     a.first_sample = first_sample + done; a.n_samples = n; a.n_paths = static_cast<uint32_t>(n_paths); a.bounce = 0; a.shard_capacity = static_cast<uint32_t>(shard_capacity);
     const uint32_t n_blocks = 2048u;                          // 8192 waves = 32 per shard
-    if (h->events_used == h->events.size()) {
-      hipEvent_t e0, e1;
-      HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-      h->events.emplace_back(e0, e1);
-    }
-    auto& ev = h->events[h->events_used++];
+    std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
+    { const int rc = AcquireEventPair(h, &evp); if (rc != AMBER_OK) return rc; }
+    auto& ev = *evp;
     HIP_TRY(hipEventRecord(ev.first, h->stream));
     a.out = q[0]; a.in = q[1];
     hipLaunchKernelGGL(wf_generate_kernel, dim3(n_blocks), dim3(256), 0, h->stream, a);
@@ -725,12 +756,9 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
     const uint32_t by_work = (a.n_items + 255u) / 256u;
     if (by_work < n_blocks) n_blocks = by_work;
     HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
-    if (h->events_used == h->events.size()) {
-      hipEvent_t e0, e1;
-      HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-      h->events.emplace_back(e0, e1);
-    }
-    auto& ev = h->events[h->events_used++];
+    std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
+    { const int rc = AcquireEventPair(h, &evp); if (rc != AMBER_OK) return rc; }
+    auto& ev = *evp;
     HIP_TRY(hipEventRecord(ev.first, h->stream));
     if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(pt_megakernel<ENGINE_TWO_PHASE>, dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (h->hit_engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(pt_megakernel<ENGINE_BVH>, dim3(n_blocks), dim3(256), 0, h->stream, a);
@@ -752,7 +780,7 @@ int amber_hip_pt_clear(amber_hip_pt* h) {
   HIP_TRY(hipMemsetAsync(h->d_fb, 0, fb_floats * sizeof(float), h->stream));
   HIP_TRY(hipMemsetAsync(h->d_rays, 0, sizeof(unsigned long long), h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  h->events_used = 0;
+  h->events_used = 0; h->timed_launches = 0; h->timed_ms = 0;
   return AMBER_OK;
 }
 
@@ -792,13 +820,13 @@ int amber_hip_pt_kernel_time(amber_hip_pt* h, uint32_t* n_launches, double* tota
   if (!h) return Fail(AMBER_EINVAL, "null handle");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  double tot = 0;
+  double tot = h->timed_ms;
   for (size_t i = 0; i < h->events_used; i++) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second));
     tot += ms;
   }
-  if (n_launches) *n_launches = static_cast<uint32_t>(h->events_used);
+  if (n_launches) *n_launches = h->timed_launches + static_cast<uint32_t>(h->events_used);
   if (total_ms) *total_ms = tot;
   return AMBER_OK;
 }

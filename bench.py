@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--spp-per-launch", type=int, default=1024)
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a single GPU: every rank uses device 0 and the gather runs over gloo on host copies")
     ap.add_argument("--engine", default="auto", choices=["auto", "list", "two_phase", "bvh", "wavefront"],
                     help="closest-hit / scheduling engine (default: auto = the fastest valid one; others for comparison)")
     args = ap.parse_args()
@@ -78,12 +80,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: amber_amd has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     W = H = args.width
     sensor = amber_amd.Sensor.default(W, H)
@@ -100,6 +107,9 @@ def main():
         tracer.clear()
         for first, n in launches:
             tracer.render_pass(first, n)
+        if args.rehearse_on_one_gpu and world > 1:
+            torch.cuda.synchronize()
+            return gather_rows(fb.cpu(), parts, W, rank, world)    # gloo: host tensors
         return gather_rows(fb, parts, W, rank, world)              # the single collective of the job
 
     def fence():
@@ -123,15 +133,18 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
-    t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-    r = torch.tensor([total_rays_local], dtype=torch.int64, device=f"cuda:{local_rank}")
-    k = torch.tensor([kernel_ms / max(n_launch, 1)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    red_dev = "cpu" if args.rehearse_on_one_gpu else f"cuda:{local_rank}"
+    t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    r = torch.tensor([total_rays_local], dtype=torch.int64, device=red_dev)
+    k = torch.tensor([kernel_ms / max(n_launch, 1)], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
     dt_max, rays, kern_ms = float(t.item()), int(r.item()), float(k.item())
 
+    if rank == 0 and os.environ.get("AMBER_BENCH_SAVE_IMAGE"):
+        np.save(os.environ["AMBER_BENCH_SAVE_IMAGE"], img.detach().cpu().numpy())
     if rank == 0:
         rays_per_launch_local = total_rays_local / max(n_launch, 1)
         achieved = rays_per_launch_local * BYTES_PER_RAY / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0

@@ -1,0 +1,21 @@
+"""A/B of two builds of the library on config 2 in ONE process, interleaved rounds (cdna guide rule 24)."""
+import ctypes as C, os, sys, time, statistics
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import numpy as np
+libs = sys.argv[1:3]; spp = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+import amber_amd.api as api
+res = {}
+handles = {}
+for path in libs:
+    api._lib = None; api._LIB_PATH = api._ROOT / "lib" / path
+    import amber_amd as A
+    lib = A.load_library()
+    sc = A.HostScene.cornell_box(); pt = A.PathTracer(sc, A.Sensor.default(1024, 1024))
+    handles[path] = (lib, sc, pt)
+for rnd in range(5):
+    for path in libs:
+        lib, sc, pt = handles[path]; api._lib = lib
+        pt.clear(); pt.render_pass(0, spp); pt.sync(); n, ms = pt.kernel_time()
+        res.setdefault(path, []).append(ms)
+for path in libs:
+    print("%-28s median %.2f ms  min %.2f  (%s)" % (path, statistics.median(res[path]), min(res[path]), " ".join("%.1f" % x for x in res[path])))
