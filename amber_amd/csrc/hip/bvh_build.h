@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -43,7 +44,12 @@ struct Box {
 };
 
 // Bounds of one object (same shapes as Primitive::BoundingBox, primitive_*.cc), widened outward.
-inline Box ObjectBox(const DevObject& o) {
+// sphere_slack2: the reference's sphere test (primitive_sphere.cc:75-107, algebra.h:31-52) evaluates the discriminant
+// b*b - 4*c in binary32 with b ~ 2D and c ~ D^2 for a ray origin at distance D, so it ACCEPTS rays whose impact
+// parameter p satisfies p^2 <= r^2 + ~12 eps D^2 -- for a small distant sphere noticeably outside the geometric
+// sphere (r = 0.005, D = 6: 3.5e-3).  Those accepted hits must stay inside the leaf's box, so spheres are bounded
+// with r' = sqrt(r^2 + 16 eps D_scene^2) (found when the 1M-sphere scene lost 7 paths in 1.4e9 to tighter boxes).
+inline Box ObjectBox(const DevObject& o, double sphere_slack2 = 0.0) {
   Box b; b.reset();
   const uint32_t kind = o.kind & 0xffu;
   if (kind == 0) {            // triangle: v0, v0+E1, v0+E2
@@ -54,7 +60,8 @@ inline Box ObjectBox(const DevObject& o) {
     for (int c = 0; c < 3; c++) p[c] = o.a[c] + o.e2[c];
     b.grow(p);
   } else if (kind == 1) {     // sphere
-    for (int c = 0; c < 3; c++) { b.mn[c] = o.a[c] - std::fabs(o.radius); b.mx[c] = o.a[c] + std::fabs(o.radius); }
+    const float r = static_cast<float>(std::sqrt(double(o.radius) * o.radius + sphere_slack2) * 1.000001);
+    for (int c = 0; c < 3; c++) { b.mn[c] = o.a[c] - r; b.mx[c] = o.a[c] + r; }
   } else {                    // disk / cylinder: bounding sphere of the swept disk (normal is not guaranteed unit)
     double nl = std::sqrt(double(o.e1[0]) * o.e1[0] + double(o.e1[1]) * o.e1[1] + double(o.e1[2]) * o.e1[2]);
     const double h = kind == 3 ? std::fabs(double(o.height)) * nl : 0.0;
@@ -170,8 +177,14 @@ inline FlatBvh BuildBvh(const std::vector<DevObject>& objs) {
   const uint32_t n = static_cast<uint32_t>(objs.size());
   b.boxes.resize(n); b.cent.resize(3 * size_t(n)); b.index.resize(n);
   Box all; all.reset();
+  for (uint32_t i = 0; i < n; i++) all.grow(ObjectBox(objs[i]));
+  const double dx = double(all.mx[0]) - all.mn[0], dy = double(all.mx[1]) - all.mn[1], dz = double(all.mx[2]) - all.mn[2];
+  double slack_factor = 16.0;
+  if (const char* env = std::getenv("AMBER_BVH_SPHERE_SLACK")) slack_factor = std::atof(env);   // test hook: the image must not depend on it
+  const double sphere_slack2 = slack_factor * 5.9604644775390625e-08 * (dx * dx + dy * dy + dz * dz);   // 16 eps D^2
+  all.reset();
   for (uint32_t i = 0; i < n; i++) {
-    b.boxes[i] = ObjectBox(objs[i]);
+    b.boxes[i] = ObjectBox(objs[i], sphere_slack2);
     for (int c = 0; c < 3; c++) b.cent[3 * size_t(i) + c] = 0.5f * (b.boxes[i].mn[c] + b.boxes[i].mx[c]);
     b.index[i] = i;
     all.grow(b.boxes[i]);

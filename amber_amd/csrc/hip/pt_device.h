@@ -458,14 +458,26 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
 // and the slab test ignores NaN axes (v_min/v_max return the non-NaN operand), so culling is conservative;
 // every object of a visited leaf gets the exact reference test with the (t, index) tie rule.  Result = List.
 #define AMBER_BVH_STACK 32
-__device__ __forceinline__ void SlabTest(const float* mn, const float* mx, V3 o, V3 inv, float t_best, bool& hit, float& t_in) {
-  const float x0 = (mn[0] - o.x) * inv.x, x1 = (mx[0] - o.x) * inv.x;
-  const float y0 = (mn[1] - o.y) * inv.y, y1 = (mx[1] - o.y) * inv.y;
-  const float z0 = (mn[2] - o.z) * inv.z, z1 = (mx[2] - o.z) * inv.z;
+__device__ __forceinline__ void SlabTest(const float* mn, const float* mx, V3 inv, V3 oi, V3 oo, float t_best, bool& hit, float& t_in) {
+  // (plane - o) / d as one FMA per plane: plane * inv - o * inv (oi = o * inv, once per ray).  Culling only has to be
+  // conservative; the extra rounding of this form is covered by the slack below and the padded boxes.
+#ifndef AMBER_SLAB_SUBMUL
+  const float x0 = __builtin_fmaf(mn[0], inv.x, -oi.x), x1 = __builtin_fmaf(mx[0], inv.x, -oi.x);
+  const float y0 = __builtin_fmaf(mn[1], inv.y, -oi.y), y1 = __builtin_fmaf(mx[1], inv.y, -oi.y);
+  const float z0 = __builtin_fmaf(mn[2], inv.z, -oi.z), z1 = __builtin_fmaf(mx[2], inv.z, -oi.z);
+#else
+  const float x0 = (mn[0] - oo.x) * inv.x, x1 = (mx[0] - oo.x) * inv.x;
+  const float y0 = (mn[1] - oo.y) * inv.y, y1 = (mx[1] - oo.y) * inv.y;
+  const float z0 = (mn[2] - oo.z) * inv.z, z1 = (mx[2] - oo.z) * inv.z;
+#endif
   float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
   float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-  // widen by a few ulps of the larger parameter: the slab arithmetic itself rounds
+  // widen by a few ulps of the magnitudes involved: the slab arithmetic itself rounds
+#ifdef AMBER_SLAB_OLD_SLACK
   const float slack = 4.76837158203125e-07f * __builtin_fmaxf(Abs(tn), Abs(tf));
+#else
+  const float slack = 9.5367431640625e-07f * (__builtin_fmaxf(Abs(tn), Abs(tf)) + __builtin_fmaxf(__builtin_fmaxf(Abs(oi.x), Abs(oi.y)), Abs(oi.z)));
+#endif
   tn -= slack; tf += slack;
   t_in = tn;
   hit = !(tn > tf) && !(tn > t_best);        // NaN anywhere -> treated as a hit
@@ -474,31 +486,44 @@ __device__ __forceinline__ void SlabTest(const float* mn, const float* mx, V3 o,
 __device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, HitRec& best) {
   best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;
   const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const V3 oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);   // inf * 0 = NaN on axis-parallel rays: that axis is then ignored (conservative)
   int32_t* stack = lds_stack + threadIdx.x;          // element k at stack[k * blockDim.x]
   const uint32_t stride = blockDim.x;
   int sp = 0;
   bool overflow = false;
+  // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (or runs out of
+  // work), then all lanes of the wave test their leaves together -- the expensive exact tests run with as many lanes
+  // as possible instead of being interleaved with other lanes' box tests.
+  const int32_t kDone = 0x7fffffff;
   int32_t cur = sc.bvh_root;
   for (;;) {
-    if (cur >= 0) {
+    while (cur >= 0 && cur != kDone) {
       const DevBvhNode* nd = sc.bvh_nodes + cur;
       const float4 a = *reinterpret_cast<const float4*>(nd->lmin), b = *reinterpret_cast<const float4*>(nd->lmax);
       const float4 c = *reinterpret_cast<const float4*>(nd->rmin), e = *reinterpret_cast<const float4*>(nd->rmax);
       const float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {b.x, b.y, b.z}, rmn[3] = {c.x, c.y, c.z}, rmx[3] = {e.x, e.y, e.z};
       const int32_t left = __float_as_int(a.w), right = __float_as_int(c.w);
       bool hl, hr; float tl, tr;
-      SlabTest(lmn, lmx, o, inv, best.t, hl, tl);
-      SlabTest(rmn, rmx, o, inv, best.t, hr, tr);
+      SlabTest(lmn, lmx, inv, oi, o, best.t, hl, tl);
+      SlabTest(rmn, rmx, inv, oi, o, best.t, hr, tr);
       if (hl && hr) {
         const bool left_first = !(tr < tl);
         const int32_t near_ = left_first ? left : right, far_ = left_first ? right : left;
-        if (sp < AMBER_BVH_STACK) { stack[sp * stride] = far_; ++sp; cur = near_; continue; }
-        overflow = true;                               // cannot happen with the builder's depth cap; stay correct anyway
-        break;
+        if (sp < AMBER_BVH_STACK) { stack[sp * stride] = far_; ++sp; }
+        else overflow = true;                          // cannot happen with the builder's depth cap; stay correct anyway
+        cur = near_;
+      } else if (hl) {
+        cur = left;
+      } else if (hr) {
+        cur = right;
+      } else if (sp > 0) {
+        --sp; cur = stack[sp * stride];
+      } else {
+        cur = kDone;
       }
-      if (hl) { cur = left; continue; }
-      if (hr) { cur = right; continue; }
-    } else {
+    }
+    if (cur == kDone) break;
+    {                                                  // cur < 0: a leaf
       const uint32_t ref = static_cast<uint32_t>(-(cur + 1));
       const uint32_t first = ref >> 3, count = ref & 7u;
       for (uint32_t k = 0; k < count; ++k) {
@@ -507,9 +532,7 @@ __device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_s
         IntersectObject<true>(ob, ob.kind, static_cast<int>(oi), static_cast<int>(oi), o, d, best);
       }
     }
-    if (sp == 0) break;
-    --sp;
-    cur = stack[sp * stride];
+    if (sp > 0) { --sp; cur = stack[sp * stride]; } else break;
   }
   if (__any(overflow)) { if (overflow) ClosestHitList(sc, o, d, best); }
 }

@@ -517,3 +517,28 @@ def test_baseline_configs_4_and_5_geometry(amber, cornell):
             pt = amber.PathTracer(hs, sn, seed=4, max_depth=depth)
             _, casts = pt.kat_trace(px, sm, depth)
             assert casts.max() <= depth
+
+
+def test_bvh_bounds_are_conservative_enough(amber, cornell):
+    """The BVH may only cull what the exact tests would reject.  (1) Cornell 1024x1024@64 through engine BVH equals the
+    default engine on all 1.4e8 rays.  (2) On the 1M-sphere scene the image must not change when the sphere bounds are
+    made 16x more conservative (AMBER_BVH_SPHERE_SLACK test hook): the reference's binary32 discriminant accepts rays
+    that miss a small distant sphere geometrically, and bounds derived from the geometry alone lose those hits."""
+    import os
+    from amber_amd import scenes
+    hs, _ = cornell
+    sn = amber.Sensor.default(1024, 1024)
+    res = []
+    for eng in (amber.ENGINE_AUTO, amber.ENGINE_BVH):
+        pt = amber.PathTracer(hs, sn, seed=6, engine=eng); pt.render_pass(0, 64); res.append(pt.download()); pt.close()
+    assert res[0][1] == res[1][1] and np.array_equal(bits(res[0][0]), bits(res[1][0]))
+    k = scenes.random_spheres(1_000_000, 7)
+    out = []
+    for slack in (None, "256"):
+        if slack: os.environ["AMBER_BVH_SPHERE_SLACK"] = slack
+        try:
+            hb = amber.HostScene.create_arrays(**k)
+            pt = amber.PathTracer(hb, amber.Sensor.default(960, 540), seed=1); pt.render_pass(0, 64); out.append(pt.download()); pt.close()
+        finally:
+            os.environ.pop("AMBER_BVH_SPHERE_SLACK", None)
+    assert out[0][1] == out[1][1] and np.array_equal(bits(out[0][0]), bits(out[1][0]))
