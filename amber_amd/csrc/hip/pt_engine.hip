@@ -728,7 +728,7 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
   const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
   // a launch covers at most kMaxPartialFloats of per-item sums and < 2^31 items; longer passes are split on
   // chunk boundaries, which leaves the summation order (chunks in order) unchanged
-  const uint64_t kMaxPartialFloats = 384ull << 20;    // 1.5 GiB
+  const uint64_t kMaxPartialFloats = 768ull << 20;    // 3 GiB
   uint64_t max_chunks = kMaxPartialFloats / (static_cast<uint64_t>(n_pixels) * 3u);
   const uint64_t by_items = 0x7fffffffull / n_pixels;
   if (by_items < max_chunks) max_chunks = by_items;

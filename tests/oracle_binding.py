@@ -14,7 +14,7 @@ ROOT = Path(__file__).resolve().parent.parent
 LIB = ROOT / "oracle" / "liboracle.so"
 
 ACCEL_BVH, ACCEL_LIST = 0, 1
-ACCUM_CHUNK = 32   # include/amber_hip.h AMBER_ACCUM_CHUNK
+ACCUM_CHUNK = 8    # include/amber_hip.h AMBER_ACCUM_CHUNK
 MATH_LIBM, MATH_PORTABLE = 0, 1
 
 
