@@ -458,26 +458,16 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
 // and the slab test ignores NaN axes (v_min/v_max return the non-NaN operand), so culling is conservative;
 // every object of a visited leaf gets the exact reference test with the (t, index) tie rule.  Result = List.
 #define AMBER_BVH_STACK 32
-__device__ __forceinline__ void SlabTest(const float* mn, const float* mx, V3 inv, V3 oi, V3 oo, float t_best, bool& hit, float& t_in) {
+__device__ __forceinline__ void SlabTest(const float* mn, const float* mx, V3 inv, V3 oi, float t_best, bool& hit, float& t_in) {
   // (plane - o) / d as one FMA per plane: plane * inv - o * inv (oi = o * inv, once per ray).  Culling only has to be
   // conservative; the extra rounding of this form is covered by the slack below and the padded boxes.
-#ifndef AMBER_SLAB_SUBMUL
   const float x0 = __builtin_fmaf(mn[0], inv.x, -oi.x), x1 = __builtin_fmaf(mx[0], inv.x, -oi.x);
   const float y0 = __builtin_fmaf(mn[1], inv.y, -oi.y), y1 = __builtin_fmaf(mx[1], inv.y, -oi.y);
   const float z0 = __builtin_fmaf(mn[2], inv.z, -oi.z), z1 = __builtin_fmaf(mx[2], inv.z, -oi.z);
-#else
-  const float x0 = (mn[0] - oo.x) * inv.x, x1 = (mx[0] - oo.x) * inv.x;
-  const float y0 = (mn[1] - oo.y) * inv.y, y1 = (mx[1] - oo.y) * inv.y;
-  const float z0 = (mn[2] - oo.z) * inv.z, z1 = (mx[2] - oo.z) * inv.z;
-#endif
   float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
   float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
   // widen by a few ulps of the magnitudes involved: the slab arithmetic itself rounds
-#ifdef AMBER_SLAB_OLD_SLACK
-  const float slack = 4.76837158203125e-07f * __builtin_fmaxf(Abs(tn), Abs(tf));
-#else
   const float slack = 9.5367431640625e-07f * (__builtin_fmaxf(Abs(tn), Abs(tf)) + __builtin_fmaxf(__builtin_fmaxf(Abs(oi.x), Abs(oi.y)), Abs(oi.z)));
-#endif
   tn -= slack; tf += slack;
   t_in = tn;
   hit = !(tn > tf) && !(tn > t_best);        // NaN anywhere -> treated as a hit
@@ -504,8 +494,8 @@ __device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_s
       const float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {b.x, b.y, b.z}, rmn[3] = {c.x, c.y, c.z}, rmx[3] = {e.x, e.y, e.z};
       const int32_t left = __float_as_int(a.w), right = __float_as_int(c.w);
       bool hl, hr; float tl, tr;
-      SlabTest(lmn, lmx, inv, oi, o, best.t, hl, tl);
-      SlabTest(rmn, rmx, inv, oi, o, best.t, hr, tr);
+      SlabTest(lmn, lmx, inv, oi, best.t, hl, tl);
+      SlabTest(rmn, rmx, inv, oi, best.t, hr, tr);
       if (hl && hr) {
         const bool left_first = !(tr < tl);
         const int32_t near_ = left_first ? left : right, far_ = left_first ? right : left;

@@ -542,3 +542,47 @@ def test_bvh_bounds_are_conservative_enough(amber, cornell):
         finally:
             os.environ.pop("AMBER_BVH_SPHERE_SLACK", None)
     assert out[0][1] == out[1][1] and np.array_equal(bits(out[0][0]), bits(out[1][0]))
+
+
+def test_edge_sizes_and_engine_thresholds(amber, cornell):
+    """Ragged and minimal inputs: 1x1 and 1xN frames, zero samples, sample offsets near 2^32, a band of one row,
+    scenes of exactly 32 objects (last two-phase size) and 33 objects (first BVH size), an all-miss scene."""
+    hs, osc = cornell
+    for (W, H) in ((1, 1), (1, 9), (13, 1), (9, 9)):
+        pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=3)
+        pt.render_pass(0, 0)                                              # no samples: a no-op
+        z, r0 = pt.download()
+        assert r0 == 0 and not z.any()
+        first = 2 ** 32 - 21
+        pt.render_pass(first, 20)                                         # highest legal sample indices
+        img, rays = pt.download()
+        ref, cnt = osc.render_xorshift(W, H, 3, first, 20)
+        assert rays == cnt.casts and np.array_equal(bits(img), bits(ref))
+        with pytest.raises(amber.AmberError, match="overflow"):
+            pt.render_pass(2 ** 32 - 5, 10)
+    pt = amber.PathTracer(hs, amber.Sensor.default(40, 30), seed=3, rows=(17, 18))     # a one-row band
+    pt.render_pass(0, 24)
+    b, r = pt.download()
+    ref, cnt = osc.render_xorshift(40, 30, 3, 0, 24, rows=(17, 18))
+    assert b.shape == (1, 40, 3) and r == cnt.casts and np.array_equal(bits(b[0]), bits(ref[17]))
+    with pytest.raises(amber.AmberError, match="bad row band"):
+        amber.PathTracer(hs, amber.Sensor.default(40, 30), rows=(10, 31))
+    # 32 vs 33 objects: 6 blades + n spheres in a row
+    base = dict(materials=[(4, (5.0, 5.0, 5.0), 0.0), (0, (0.6, 0.6, 0.6), 0.0)], transform=[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 5, 0, 0, 0, 1],
+                focal_length=0.05, focus_distance=5.0, radius=0.02, n_blades=6)
+    for n_sph, engine_is_bvh in ((26, False), (27, True)):
+        objs = [(1, i % 2, [-1.3 + 0.1 * i, 0.1 * np.sin(i), 0.0, 0.045]) for i in range(n_sph)]
+        sc = dict(base, objects=objs)
+        h2, o2 = amber.HostScene.create(**sc), O.Scene.create(**sc)
+        assert len(h2.flatten()[0]) == 6 + n_sph
+        pt = amber.PathTracer(h2, amber.Sensor.default(48, 32), seed=1)
+        pt.render_pass(0, 16)
+        img, rays = pt.download()
+        ref, cnt = o2.render_xorshift(48, 32, 1, 0, 16)
+        assert rays == cnt.casts and np.array_equal(bits(img), bits(ref)) and (img > 0).any()
+    # nothing in front of the camera: every path is one cast and a miss
+    sc = dict(base, objects=[(1, 1, [0.0, 0.0, 50.0, 1.0])])
+    h3 = amber.HostScene.create(**sc)
+    pt = amber.PathTracer(h3, amber.Sensor.default(16, 16), seed=1); pt.render_pass(0, 8)
+    img, rays = pt.download()
+    assert rays == 16 * 16 * 8 and not img.any()
