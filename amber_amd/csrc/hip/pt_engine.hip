@@ -116,8 +116,8 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
         pixel = px + py * sc.sensor.w;                      // Image index x + y*W (image.h:116-124)
         slot = chunk * a.n_pixels + plocal;
         s = a.first_sample + chunk * AMBER_ACCUM_CHUNK;
-        const uint32_t e = s + AMBER_ACCUM_CHUNK, last = a.first_sample + a.n_samples;
-        s_end = e < last ? e : last;
+        const uint32_t left = a.first_sample + a.n_samples - s;            // >= 1; no 32-bit wrap near the top of the range
+        s_end = s + (left < AMBER_ACCUM_CHUNK ? left : AMBER_ACCUM_CHUNK);
         sum = v3(0.f, 0.f, 0.f);
         have_item = true;
         need = false;
