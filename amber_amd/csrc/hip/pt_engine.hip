@@ -20,6 +20,7 @@
 #include "../../../include/amber_hip.h"
 #include "pt_device.h"
 #include "bvh_build.h"
+#include "filter_build.h"
 
 using namespace amber_dev;
 
@@ -322,112 +323,6 @@ struct DevBuf {
   hipError_t alloc(size_t n) { return hipMalloc(&p, (n ? n : 1) * sizeof(T)); }
 };
 
-// Phase-A program of the two-phase closest hit.  Everything here only has to be CONSERVATIVE: a candidate that
-// the filter keeps is decided by the exact reference-arithmetic test, so these values are computed in double and
-// rounded once.  Tolerances: the reference's binary32 Moeller-Trumbore has an absolute error of at most
-// ~6 eps (|o - v0| + 1.5 |E|) / |cos| in world units along the triangle's plane; with eps = 2^-24 and a safety
-// factor the bound used is  c / |n.d|,  c = 32 eps (scene diameter + 1.5 max edge), turned into barycentric units
-// with the gradient magnitudes of the affine barycentric maps.  Coplanar triangles (all vertices within 4 eps of
-// the scene diameter of the first triangle's plane) share a plane record; their distance to it joins the tolerance.
-struct FilterProgram {
-  std::vector<DevPlane> planes;
-  std::vector<DevTriFilter> tris;
-  std::vector<DevSphereFilter> spheres;
-  std::vector<uint32_t> order;          // program slot -> scene object index
-  uint32_t n_prog_tris = 0, always_mask = 0;
-};
-
-void BuildFilterProgram(const std::vector<DevObject>& objs, FilterProgram& fp) {
-  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, e_max = 0;
-  auto grow = [&](double x, double y, double z) {
-    const double p[3] = {x, y, z};
-    for (int c = 0; c < 3; c++) { if (p[c] < lo[c]) lo[c] = p[c]; if (p[c] > hi[c]) hi[c] = p[c]; }
-  };
-  auto len3 = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
-  for (const DevObject& o : objs) {
-    if (o.kind == AMBER_PRIM_TRIANGLE) {
-      grow(o.a[0], o.a[1], o.a[2]);
-      grow(double(o.a[0]) + o.e1[0], double(o.a[1]) + o.e1[1], double(o.a[2]) + o.e1[2]);
-      grow(double(o.a[0]) + o.e2[0], double(o.a[1]) + o.e2[1], double(o.a[2]) + o.e2[2]);
-      const double E1[3] = {o.e1[0], o.e1[1], o.e1[2]}, E2[3] = {o.e2[0], o.e2[1], o.e2[2]};
-      e_max = std::max(e_max, std::max(len3(E1), len3(E2)));
-    } else {
-      const double r = std::fabs(double(o.radius)) + std::fabs(double(o.height));
-      grow(o.a[0] - r, o.a[1] - r, o.a[2] - r); grow(o.a[0] + r, o.a[1] + r, o.a[2] + r);
-    }
-  }
-  const double diam = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
-  const double eps = 5.9604644775390625e-08;
-  const double c = 32.0 * eps * (diam + 1.5 * e_max);
-  struct Group { double n[3], d0, kt, ktol; std::vector<DevTriFilter> tris; std::vector<uint32_t> index; };
-  std::vector<Group> groups;
-  std::vector<uint32_t> sphere_index, always_index;
-  for (size_t i = 0; i < objs.size() && i < 32; i++) {
-    const DevObject& o = objs[i];
-    const uint32_t idx = static_cast<uint32_t>(i);
-    if (o.kind == AMBER_PRIM_TRIANGLE) {
-      const double v0[3] = {o.a[0], o.a[1], o.a[2]}, E1[3] = {o.e1[0], o.e1[1], o.e1[2]}, E2[3] = {o.e2[0], o.e2[1], o.e2[2]};
-      const double nr[3] = {E1[1] * E2[2] - E1[2] * E2[1], E1[2] * E2[0] - E1[0] * E2[2], E1[0] * E2[1] - E1[1] * E2[0]};
-      const double n2 = nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2];
-      if (!(n2 > 1e-60) || !std::isfinite(n2)) { always_index.push_back(idx); continue; }
-      const double nl = std::sqrt(n2);
-      const double n[3] = {nr[0] / nl, nr[1] / nl, nr[2] / nl};
-      const double d0 = n[0] * v0[0] + n[1] * v0[1] + n[2] * v0[2];
-      // u = A.(P - v0), A = (E2 x nr)/|nr|^2 ; v = B.(P - v0), B = (nr x E1)/|nr|^2
-      const double A[3] = {(E2[1] * nr[2] - E2[2] * nr[1]) / n2, (E2[2] * nr[0] - E2[0] * nr[2]) / n2, (E2[0] * nr[1] - E2[1] * nr[0]) / n2};
-      const double B[3] = {(nr[1] * E1[2] - nr[2] * E1[1]) / n2, (nr[2] * E1[0] - nr[0] * E1[2]) / n2, (nr[0] * E1[1] - nr[1] * E1[0]) / n2};
-      const double AB[3] = {A[0] + B[0], A[1] + B[1], A[2] + B[2]};
-      const double g = std::max(len3(A), std::max(len3(B), len3(AB)));
-      const double inv_sin = len3(E1) * len3(E2) / nl;
-      // find a plane group that contains all three vertices
-      const double verts[3][3] = {{v0[0], v0[1], v0[2]}, {v0[0] + E1[0], v0[1] + E1[1], v0[2] + E1[2]}, {v0[0] + E2[0], v0[1] + E2[1], v0[2] + E2[2]}};
-      Group* grp = nullptr; double dist = 0;
-      for (Group& gq : groups) {
-        double dmax = 0;
-        for (const auto& vtx : verts) dmax = std::max(dmax, std::fabs(gq.n[0] * vtx[0] + gq.n[1] * vtx[1] + gq.n[2] * vtx[2] - gq.d0));
-        if (dmax <= 4.0 * eps * diam) { grp = &gq; dist = dmax; break; }
-      }
-      DevTriFilter f;
-      std::memset(&f, 0, sizeof f);
-      for (int k = 0; k < 3; k++) { f.A[k] = static_cast<float>(A[k]); f.B[k] = static_cast<float>(B[k]); }
-      f.a0 = static_cast<float>(-(A[0] * v0[0] + A[1] * v0[1] + A[2] * v0[2]));
-      f.b0 = static_cast<float>(-(B[0] * v0[0] + B[1] * v0[1] + B[2] * v0[2]));
-      const double ktol = (c + dist) * g * 1.0001 + 1e-7;
-      const double kt = 2.0 * (c + dist) * std::max(1.0, inv_sin) + 1e-7;
-      if (!std::isfinite(ktol) || !std::isfinite(f.a0) || !std::isfinite(f.b0) || !std::isfinite(kt)) { always_index.push_back(idx); continue; }
-      if (!grp) { groups.push_back(Group{{n[0], n[1], n[2]}, d0, 0.0, 0.0, {}, {}}); grp = &groups.back(); }
-      grp->kt = std::max(grp->kt, kt);
-      grp->ktol = std::max(grp->ktol, ktol);
-      grp->tris.push_back(f);
-      grp->index.push_back(idx);
-    } else if (o.kind == AMBER_PRIM_SPHERE) {
-      DevSphereFilter f;
-      std::memset(&f, 0, sizeof f);
-      f.c[0] = o.a[0]; f.c[1] = o.a[1]; f.c[2] = o.a[2];
-      f.r2 = static_cast<float>(double(o.radius) * double(o.radius));
-      f.ktol = 1e-5f;
-      if (!std::isfinite(f.r2)) { always_index.push_back(idx); continue; }
-      fp.spheres.push_back(f);
-      sphere_index.push_back(idx);
-    } else {
-      always_index.push_back(idx);                   // disk, cylinder: always tested exactly
-    }
-  }
-  for (const Group& g : groups) {
-    DevPlane p;
-    std::memset(&p, 0, sizeof p);
-    for (int k = 0; k < 3; k++) p.n[k] = static_cast<float>(g.n[k]);
-    p.d0 = static_cast<float>(g.d0); p.kt = static_cast<float>(g.kt * 1.0001); p.ktol = static_cast<float>(g.ktol * 1.0001);
-    p.n_tris = static_cast<uint32_t>(g.tris.size());
-    fp.planes.push_back(p);
-    fp.tris.insert(fp.tris.end(), g.tris.begin(), g.tris.end());
-    fp.order.insert(fp.order.end(), g.index.begin(), g.index.end());
-  }
-  fp.n_prog_tris = static_cast<uint32_t>(fp.order.size());
-  fp.order.insert(fp.order.end(), sphere_index.begin(), sphere_index.end());
-  for (uint32_t idx : always_index) { fp.always_mask |= 1u << fp.order.size(); fp.order.push_back(idx); }
-}
-
 int ValidateScene(const AmberFlatScene* s, const AmberSensor* sensor) {
   if (!s || !sensor) return Fail(AMBER_EINVAL, "null scene or sensor");
   if (!s->objects || s->n_objects == 0) return Fail(AMBER_EINVAL, "scene has no objects");
@@ -542,8 +437,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     bvh = amber_bvh::BuildBvh(objs);
     if (bvh.depth > static_cast<uint32_t>(amber_bvh::kMaxDepth)) { delete h; return Fail(AMBER_EINVAL, "BVH deeper than the device stack"); }
   }
-  FilterProgram fprog;
-  if (h->two_phase) BuildFilterProgram(objs, fprog);
+  amber_filter::FilterProgram fprog;
+  if (h->two_phase) amber_filter::BuildFilterProgram(objs, fprog);
   for (uint32_t i = 0; i < L.n_blades; i++)            // filter-program slot of every aperture blade (self-candidate trip)
     for (uint32_t k = 0; k < fprog.n_prog_tris; k++)
       if (fprog.order[k] == L.first_blade_object + i) blades[i].slot = static_cast<int32_t>(k);

@@ -1,0 +1,117 @@
+// host_sanitize.hip -- host-only driver built with AddressSanitizer + UBSan (tests/test_host_sanitizers.py):
+// exercises the host code that prepares device data -- object model, Flatten, filter program, BVH build, output
+// writers -- on degenerate and large inputs.  No GPU call is made (GPU sanitizers are not available on this pool).
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#include "../amber_amd/csrc/amber/postprocess.h"
+#include "../amber_amd/csrc/amber/rendering.h"
+#include "../amber_amd/csrc/amber/scene.h"
+#include "../amber_amd/csrc/hip/bvh_build.h"
+#include "../amber_amd/csrc/hip/filter_build.h"
+
+using amber_dev::DevObject;
+
+static std::vector<DevObject> ToDev(const amber::scene::FlatScene& fs) {
+  std::vector<DevObject> objs(fs.objects.size());
+  for (size_t i = 0; i < objs.size(); i++) {
+    const AmberFlatObject& f = fs.objects[i];
+    DevObject& o = objs[i];
+    std::memset(&o, 0, sizeof o);
+    o.kind = f.kind; o.material = f.material;
+    for (int c = 0; c < 3; c++) o.a[c] = f.p[c];
+    if (f.kind == AMBER_PRIM_TRIANGLE) for (int c = 0; c < 3; c++) { o.e1[c] = f.p[3 + c] - f.p[c]; o.e2[c] = f.p[6 + c] - f.p[c]; o.n[c] = f.p[9 + c]; }
+    else if (f.kind == AMBER_PRIM_SPHERE) o.radius = f.p[3];
+    else { for (int c = 0; c < 3; c++) o.e1[c] = f.p[3 + c]; o.radius = f.p[6]; o.height = f.p[7]; }
+  }
+  return objs;
+}
+
+static void CheckBvh(const std::vector<DevObject>& objs, const char* what) {
+  const auto b = amber_bvh::BuildBvh(objs);
+  // every object appears exactly once in the leaves, references are in range, depth within the device stack
+  std::vector<int> seen(objs.size(), 0);
+  size_t leaves = 0;
+  std::vector<int32_t> stack{b.root_ref};
+  while (!stack.empty()) {
+    const int32_t r = stack.back(); stack.pop_back();
+    if (r >= 0) {
+      if (static_cast<size_t>(r) >= b.nodes.size()) { std::printf("FAIL %s: node ref out of range\n", what); std::exit(1); }
+      stack.push_back(b.nodes[r].left); stack.push_back(b.nodes[r].right);
+    } else {
+      const uint32_t ref = static_cast<uint32_t>(-(r + 1)), first = ref >> 3, count = ref & 7u;
+      leaves++;
+      for (uint32_t k = 0; k < count; k++) {
+        if (first + k >= b.prim_index.size()) { std::printf("FAIL %s: leaf range\n", what); std::exit(1); }
+        seen[b.prim_index[first + k]]++;
+      }
+    }
+  }
+  for (int s : seen) if (s != 1) { std::printf("FAIL %s: object referenced %d times\n", what, s); std::exit(1); }
+  if (b.depth > static_cast<uint32_t>(amber_bvh::kMaxDepth)) { std::printf("FAIL %s: depth %u\n", what, b.depth); std::exit(1); }
+  std::printf("ok   bvh %-28s objects %zu nodes %zu leaves %zu depth %u\n", what, objs.size(), b.nodes.size(), leaves, b.depth);
+}
+
+int main() {
+  using namespace amber;
+  // 1. Cornell box: flatten + filter program
+  {
+    const auto scene = etude::CornelBox(0.050f, 0.050f, 6);
+    const auto fs = scene.Flatten();
+    const auto objs = ToDev(fs);
+    amber_filter::FilterProgram fp;
+    amber_filter::BuildFilterProgram(objs, fp);
+    if (fp.order.size() != objs.size() || fp.planes.size() != 9 || fp.tris.size() != 22 || fp.spheres.size() != 3 || fp.always_mask != 0) {
+      std::printf("FAIL filter program: planes %zu tris %zu spheres %zu always %x\n", fp.planes.size(), fp.tris.size(), fp.spheres.size(), fp.always_mask);
+      return 1;
+    }
+    std::printf("ok   filter program: 9 planes, 22 triangles, 3 spheres\n");
+    CheckBvh(objs, "cornell");
+  }
+  // 2. degenerate inputs: pinhole (zero-area triangle), one object, coincident centres, extreme coordinates
+  {
+    std::vector<std::unique_ptr<scene::Primitive>> prims; std::vector<std::unique_ptr<scene::RGBMaterial>> mats; std::vector<scene::RGBObject> objects;
+    auto lens = scene::MakePinholeLens(scene::Matrix4(1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 3, 0, 0, 0, 1), 0.05f);
+    for (const auto& o : lens->ApertureObjects()) objects.emplace_back(*o);
+    mats.emplace_back(scene::MakeLambertian(scene::RGB(0.5f)));
+    prims.emplace_back(scene::MakeDisk(scene::Vector3(0, 0, 0), scene::Vector3(0, 1, 0), 1.0f));
+    objects.emplace_back(prims.back().get(), mats.back().get());
+    prims.emplace_back(scene::MakeCylinder(scene::Vector3(1, 0, 0), scene::Vector3(0, 1, 0), 0.2f, 1.0f));
+    objects.emplace_back(prims.back().get(), mats.back().get());
+    const auto sc = scene::RGBScene::Create<raytracer::List<float, scene::RGBObject>>(std::move(prims), std::move(mats), std::move(objects), std::move(lens));
+    const auto fs = sc.Flatten();
+    const auto objs = ToDev(fs);
+    amber_filter::FilterProgram fp;
+    amber_filter::BuildFilterProgram(objs, fp);
+    if (fp.always_mask != 0x7u || !fp.planes.empty()) { std::printf("FAIL degenerate filter program always=%x\n", fp.always_mask); return 1; }
+    std::printf("ok   degenerate scene: every object is an always-candidate\n");
+    CheckBvh(objs, "pinhole+disk+cylinder");
+  }
+  {
+    std::vector<DevObject> one(1); std::memset(&one[0], 0, sizeof(DevObject)); one[0].kind = 1; one[0].radius = 1;
+    CheckBvh(one, "single sphere");
+    std::vector<DevObject> same(1000, one[0]);
+    CheckBvh(same, "1000 coincident spheres");
+    std::vector<DevObject> far(300, one[0]);
+    for (size_t i = 0; i < far.size(); i++) { far[i].a[0] = (i % 2 ? 1e30f : -1e30f); far[i].a[1] = static_cast<float>(i); far[i].radius = 1e-30f; }
+    CheckBvh(far, "extreme coordinates");
+  }
+  // 3. large random cloud
+  {
+    std::mt19937 rng(3); std::uniform_real_distribution<float> u(-1.f, 1.f);
+    std::vector<DevObject> objs(200000);
+    for (auto& o : objs) { std::memset(&o, 0, sizeof o); o.kind = 1; o.a[0] = u(rng); o.a[1] = u(rng); o.a[2] = u(rng); o.radius = 0.004f; }
+    CheckBvh(objs, "200k random spheres");
+  }
+  // 4. output stage writers
+  {
+    postprocess::HDRImage img(33, 17);
+    for (unsigned y = 0; y < 17; y++) for (unsigned x = 0; x < 33; x++) img[prelude::Pixel(x, y)] = postprocess::HDR(0.001f * x, 0.002f * y, 0.5f);
+    cli::ExportPNG(postprocess::Gamma()(postprocess::Filmic()(img)), "/tmp/amber_sanitize.png");
+    cli::ExportEXR(img, "/tmp/amber_sanitize.exr");
+    std::printf("ok   png/exr writers\n");
+  }
+  std::printf("ALL OK\n");
+  return 0;
+}

@@ -1,0 +1,26 @@
+"""AddressSanitizer + UBSan over the HOST code that prepares device data (GPU sanitizers are not available on
+this pool): object model, Flatten, filter program, BVH build on degenerate and large inputs, PNG/EXR writers."""
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_host_code_under_asan_ubsan(tmp_path):
+    exe = tmp_path / "host_sanitize"
+    srcs = [ROOT / "tests" / "host_sanitize.hip", ROOT / "amber_amd" / "csrc" / "amber" / "amber_host.cc",
+            ROOT / "amber_amd" / "csrc" / "amber" / "postprocess.cc"]
+    # amber_host.cc references the C ABI; the driver never renders, so resolve it against the real library
+    cmd = ["hipcc", "--cuda-host-only", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=undefined", "-o", str(exe)] + [str(s) for s in srcs] + \
+          ["-L" + str(ROOT / "amber_amd" / "lib"), "-lamber_hip", "-Wl,-rpath," + str(ROOT / "amber_amd" / "lib")]
+    subprocess.run(["make", "-C", str(ROOT / "amber_amd" / "csrc")], check=True, capture_output=True)
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600,
+                       env={"ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0", "PATH": "/usr/bin:/bin", "LD_LIBRARY_PATH": "/opt/rocm/lib"})
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout + r.stderr
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
