@@ -175,7 +175,7 @@ def main():
                 out["roofline"]["traffic_source"] = f"profiles/{profs[-1].name}"
             except Exception:
                 pass
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:                    # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(W, args.seed)
         print(json.dumps(out), flush=True)
     if dist is not None:
