@@ -32,9 +32,19 @@ class FlatThinLens(C.Structure):
                 ("n_blades", C.c_uint32), ("first_blade_object", C.c_uint32), ("kind", C.c_uint32)]
 
 
+class FlatLight(C.Structure):
+    _fields_ = [("object", C.c_uint32), ("cum_power", C.c_float), ("pdf_area", C.c_float), ("irradiance", C.c_float * 3)]
+
+
 class FlatSceneC(C.Structure):
     _fields_ = [("objects", C.POINTER(FlatObject)), ("n_objects", C.c_uint32),
-                ("materials", C.POINTER(FlatMaterial)), ("n_materials", C.c_uint32), ("lens", FlatThinLens)]
+                ("materials", C.POINTER(FlatMaterial)), ("n_materials", C.c_uint32), ("lens", FlatThinLens),
+                ("lights", C.POINTER(FlatLight)), ("n_lights", C.c_uint32)]
+
+
+class Splat(C.Structure):
+    _fields_ = [("path", C.c_uint32), ("sample", C.c_uint32), ("bounce", C.c_uint32), ("pixel", C.c_uint32),
+                ("rgb", C.c_float * 3), ("pad", C.c_uint32)]
 
 
 class Sensor(C.Structure):
@@ -65,7 +75,7 @@ ENGINE_AUTO, ENGINE_LIST, ENGINE_TWO_PHASE, ENGINE_BVH, ENGINE_WAVEFRONT = 0, 1,
 ABI_SYMBOLS = [
     "amber_hip_pt_create", "amber_hip_pt_render_pass", "amber_hip_pt_clear", "amber_hip_pt_sync",
     "amber_hip_pt_download", "amber_hip_pt_device_framebuffer", "amber_hip_pt_local_rows", "amber_hip_pt_kernel_time", "amber_hip_pt_destroy",
-    "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_device_count",
+    "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_device_count", "amber_hip_lt_trace",
     "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math",
     "amber_host_cornell_box", "amber_host_scene_create", "amber_host_scene_destroy", "amber_host_scene_flatten",
     "amber_host_pt_create", "amber_host_render", "amber_host_last_error", "amber_host_tonemap", "amber_host_export",
@@ -105,6 +115,7 @@ def load_library() -> C.CDLL:
     lib.amber_hip_pt_kernel_time.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_double)]
     lib.amber_hip_pt_destroy.argtypes = [vp]
     lib.amber_hip_pt_destroy.restype = None
+    lib.amber_hip_lt_trace.argtypes = [vp, u32, u32, vp, u32, C.POINTER(u32), C.POINTER(u64)]
     lib.amber_hip_kat_cast.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     lib.amber_hip_kat_sample.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     lib.amber_hip_kat_eye.argtypes = [vp, u32, vp, vp, vp]
@@ -275,6 +286,20 @@ class PathTracer:
         n, ms = C.c_uint32(), C.c_double()
         _check(load_library().amber_hip_pt_kernel_time(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def lt_trace(self, first_sample: int, n_samples: int, capacity: int = 1 << 16):
+        """Light tracing (algorithm_lt.cc): splats of W*H light paths per pass, sorted (pass, path, bounce).
+        Returns (structured numpy array of records, ray count)."""
+        dt = np.dtype([("path", np.uint32), ("sample", np.uint32), ("bounce", np.uint32), ("pixel", np.uint32), ("rgb", np.float32, (3,)), ("pad", np.uint32)])
+        while True:
+            out = np.zeros(capacity, dt)
+            n, rays = C.c_uint32(), C.c_uint64()
+            rc = load_library().amber_hip_lt_trace(self._h, first_sample, n_samples, out.ctypes.data, capacity, C.byref(n), C.byref(rays))
+            if rc == -4 and n.value > capacity:
+                capacity = n.value
+                continue
+            _check(rc)
+            return out[: n.value], rays.value
 
     # ---- known-answer entry points -----------------------------------------------------------
     def kat_cast(self, origins, dirs):

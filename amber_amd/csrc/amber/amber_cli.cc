@@ -2,7 +2,7 @@
 //
 // Mirrors cli::Application (/root/reference/src/amber/cli/application.cc:49-215) and the flags of
 // cli::ParseCommandLineOption (option.cc:40-100) as far as they concern the path tracer:
-//   --algorithm pt|pt-hip   --spp N (0 = until --time / SIGINT)   --width --height   --time SECONDS
+//   --algorithm pt|lt   --spp N (0 = until --time / SIGINT)   --width --height   --time SECONDS
 //   --output BASENAME (writes BASENAME.png tone-mapped and BASENAME.exr raw)   --threads (accepted, ignored)
 // plus --seed, --device, --max-depth, --engine of this implementation.  The scene is etude::CornelBox(0.050,
 // 0.050, 6) as in application.cc:68-73 (--scene needs assimp in the reference and is not supported here).
@@ -125,9 +125,11 @@ int main(int argc, char** argv) {
     const auto image = future.get();
     done = true;
     if (timer.joinable()) timer.join();
-    const auto* hp = dynamic_cast<rendering::HipPathTracing*>(algorithm.get());
-    if (hp) {
-      const auto& st = hp->Stats();
+    const rendering::HipPathTracingStats* stp = nullptr;
+    if (const auto* hp = dynamic_cast<rendering::HipPathTracing*>(algorithm.get())) stp = &hp->Stats();
+    if (const auto* hl = dynamic_cast<rendering::HipLightTracing*>(algorithm.get())) stp = &hl->Stats();
+    if (stp) {
+      const auto& st = *stp;
       std::cerr << st.passes << " passes, " << st.rays << " rays, kernel " << st.kernel_ms << " ms ("
                 << (st.kernel_ms > 0 ? st.rays / st.kernel_ms / 1e3 : 0.0) << " Mrays/s)" << std::endl;
     }

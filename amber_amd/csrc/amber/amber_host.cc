@@ -4,6 +4,7 @@
 // (primitive_*.cc, material_*.cc, lens_thin.cc); only the Make* factories are exported.
 // Everything computed here is scene DATA for the device; file:line citations are relative to
 // /root/reference.
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 #include <type_traits>
@@ -125,6 +126,9 @@ class FlatMaterial : public Material {
   FlatMaterial(uint32_t kind, rendering::SurfaceType surface, const RGB& rho, real_type param, real_type r0)
       : kind_(kind), surface_(surface), rho_(rho), param_(param), r0_(r0) {}
   rendering::SurfaceType Surface() const noexcept override { return surface_; }
+  const RGB Irradiance() const noexcept override {
+    return kind_ == AMBER_MAT_DIFFUSE_LIGHT ? rho_ * RGB(static_cast<real_type>(kPI)) : RGB();
+  }
   void Flatten(AmberFlatMaterial& m) const noexcept override {
     m.kind = kind_; m.rho[0] = rho_.x; m.rho[1] = rho_.y; m.rho[2] = rho_.z; m.param = param_; m.r0 = r0_;
   }
@@ -273,9 +277,32 @@ FlatScene Scene::Flatten() const {
     if (objects_[first + b].GetPrimitive() != blades[b]->GetPrimitive())
       throw std::runtime_error("Scene::Flatten: aperture objects must be contiguous and in blade order");
   L.first_blade_object = static_cast<uint32_t>(first);
+  // scene::LightSet (light_set.h:61-82, built by Scene::Create scene/scene.h:177-182): Light-surface objects sorted by
+  // Power = Sum(SurfaceArea * Irradiance) (scene/object.h:99-103) with running sums; pdf_area per light_set.h:107-111.
+  {
+    struct Item { uint32_t index; real_type power; RGB irr; };
+    std::vector<Item> items;
+    for (std::size_t i = 0; i < objects_.size(); i++) {
+      if (objects_[i].Surface() != rendering::SurfaceType::Light) continue;
+      const RGB irr = objects_[i].Irradiance();
+      const RGB p = RGB(objects_[i].SurfaceArea()) * irr;
+      items.push_back(Item{static_cast<uint32_t>(i), p.x + p.y + p.z, irr});
+    }
+    std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.power < b.power; });
+    real_type power = 0;
+    for (const Item& it : items) {
+      power += it.power;
+      AmberFlatLight fl{};
+      fl.object = it.index; fl.cum_power = power;
+      fl.irradiance[0] = it.irr.x; fl.irradiance[1] = it.irr.y; fl.irradiance[2] = it.irr.z;
+      fs.lights.push_back(fl);
+    }
+    for (AmberFlatLight& fl : fs.lights) fl.pdf_area = (fl.irradiance[0] + fl.irradiance[1] + fl.irradiance[2]) / power;
+  }
   fs.flat.objects = fs.objects.data(); fs.flat.n_objects = static_cast<uint32_t>(fs.objects.size());
   fs.flat.materials = fs.materials.data(); fs.flat.n_materials = static_cast<uint32_t>(fs.materials.size());
   fs.flat.lens = L;
+  fs.flat.lights = fs.lights.empty() ? nullptr : fs.lights.data(); fs.flat.n_lights = static_cast<uint32_t>(fs.lights.size());
   return fs;
 }
 
@@ -393,6 +420,51 @@ const Image<RGB> HipPathTracing::Render(const Scene<RGB>& scene, const Sensor& s
   return image;
 }
 
+// rendering::LightTracing (algorithm_lt.cc:82-163) on the HIP engine: per claimed pass W*H light paths; their splats come
+// back sorted in the reference's accumulation order and are added to a pass image, pass images to the running sum.
+const Image<RGB> HipLightTracing::Render(const Scene<RGB>& scene, const Sensor& sensor, Context& context) {
+  stats_ = HipPathTracingStats();
+  const scene::FlatScene fs = scene.Flatten();
+  AmberSensor s{static_cast<uint32_t>(sensor.Width()), static_cast<uint32_t>(sensor.Height()), sensor.SceneWidth(), sensor.SceneHeight()};
+  AmberPtParams p{};
+  p.seed = options_.seed; p.max_depth = options_.max_depth; p.device = options_.device; p.engine = options_.engine;
+  Handle handle;
+  Check(amber_hip_pt_create(&fs.flat, &s, &p, &handle.h), "amber_hip_pt_create");
+  auto sum = sensor.CreateImage<RGB>();
+  std::vector<AmberSplat> splats(1u << 16);
+  const uint32_t batch = options_.samples_per_launch ? options_.samples_per_launch : 1;
+  uint32_t first = 0;
+  for (;;) {
+    uint32_t n = 0;
+    while (n < batch && context.Iterate()) n++;
+    if (n == 0) break;
+    uint32_t n_out = 0; uint64_t rays = 0;
+    int rc = amber_hip_lt_trace(handle.h, first, n, splats.data(), static_cast<uint32_t>(splats.size()), &n_out, &rays);
+    if (rc == AMBER_ENOMEM && n_out > splats.size()) {      // grow once and repeat the (deterministic) batch
+      splats.resize(n_out);
+      rc = amber_hip_lt_trace(handle.h, first, n, splats.data(), static_cast<uint32_t>(splats.size()), &n_out, &rays);
+    }
+    Check(rc, "amber_hip_lt_trace");
+    stats_.rays += rays; stats_.launches++;
+    uint32_t k = 0;
+    for (uint32_t pass = first; pass < first + n; pass++) {
+      if (k >= n_out || splats[k].sample != pass) continue;
+      auto image = sensor.CreateImage<RGB>();                // one pass image, algorithm_lt.cc:115-122
+      for (; k < n_out && splats[k].sample == pass; k++)
+        image[Pixel(splats[k].pixel % s.width, splats[k].pixel / s.width)] += RGB(splats[k].rgb[0], splats[k].rgb[1], splats[k].rgb[2]);
+      sum += image;
+    }
+    first += n; stats_.passes += n;
+    if (n < batch) break;
+  }
+  if (stats_.passes) sum /= RGB(static_cast<real_type>(stats_.passes));
+  return sum;
+}
+
+std::unique_ptr<Algorithm<RGB>> MakeRGBHipLightTracing(const HipPathTracingOptions& options) {
+  return std::make_unique<HipLightTracing>(options);
+}
+
 std::unique_ptr<Algorithm<RGB>> MakeRGBHipPathTracing(const HipPathTracingOptions& options) {
   return std::make_unique<HipPathTracing>(options);
 }
@@ -404,6 +476,7 @@ std::unique_ptr<rendering::Algorithm<rendering::RGB>> MakeAlgorithm(const std::s
                                                                    const rendering::HipPathTracingOptions& options) {
   // algorithm_factory.cc:35-79 dispatches on --algorithm; this package provides the path tracer only.
   if (name == "pt" || name == "pt-hip") return rendering::MakeRGBHipPathTracing(options);
+  if (name == "lt" || name == "lt-hip") return rendering::MakeRGBHipLightTracing(options);
   throw UnknownAlgorithmError(name);
 }
 }  // namespace cli

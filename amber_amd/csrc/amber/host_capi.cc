@@ -124,8 +124,10 @@ int amber_host_render(const amber_host_scene* s, const char* algorithm, const Am
     const auto image = algo->Render(s->scene, sn, ctx);
     std::memcpy(out_rgb, image.Data(), static_cast<size_t>(sensor->width) * sensor->height * 3 * sizeof(float));
     if (stats) {
-      const auto* hp = dynamic_cast<rendering::HipPathTracing*>(algo.get());
-      if (hp) { stats->rays = hp->Stats().rays; stats->passes = hp->Stats().passes; stats->launches = hp->Stats().launches; stats->kernel_ms = hp->Stats().kernel_ms; }
+      const rendering::HipPathTracingStats* st = nullptr;
+      if (const auto* hp = dynamic_cast<rendering::HipPathTracing*>(algo.get())) st = &hp->Stats();
+      if (const auto* hl = dynamic_cast<rendering::HipLightTracing*>(algo.get())) st = &hl->Stats();
+      if (st) { stats->rays = st->rays; stats->passes = st->passes; stats->launches = st->launches; stats->kernel_ms = st->kernel_ms; }
     }
     return AMBER_OK;
   } catch (const cli::UnknownAlgorithmError& e) { return Fail(AMBER_EINVAL, e.what()); }

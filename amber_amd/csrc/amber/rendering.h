@@ -93,6 +93,19 @@ class HipPathTracing : public Algorithm<RGB> {
 
 std::unique_ptr<Algorithm<RGB>> MakeRGBHipPathTracing(const HipPathTracingOptions& options = HipPathTracingOptions());
 
+/** Drop-in for MakeRGBLightTracing() (include/amber/rendering/algorithm_lt.h:30-31, algorithm_lt.cc:82-163). */
+class HipLightTracing : public Algorithm<RGB> {
+ public:
+  explicit HipLightTracing(const HipPathTracingOptions& options) : options_(options) {}
+  const Image<RGB> Render(const Scene<RGB>& scene, const Sensor& sensor, Context& context) override;
+  const HipPathTracingStats& Stats() const noexcept { return stats_; }
+
+ private:
+  HipPathTracingOptions options_;
+  HipPathTracingStats stats_;
+};
+std::unique_ptr<Algorithm<RGB>> MakeRGBHipLightTracing(const HipPathTracingOptions& options = HipPathTracingOptions());
+
 }  // namespace rendering
 
 namespace cli {

@@ -57,6 +57,8 @@ class Material {
  public:
   virtual ~Material() {}
   virtual rendering::SurfaceType Surface() const noexcept = 0;
+  /** material.h:93-99: zero except for DiffuseLight (radiance * pi, material_diffuse_light.h:118-125). */
+  virtual const RGB Irradiance() const noexcept { return RGB(); }
   virtual void Flatten(AmberFlatMaterial& out) const noexcept = 0;
 };
 using RGBMaterial = Material;
@@ -76,6 +78,7 @@ class Object {
   const AABB BoundingBox() const noexcept { return primitive_->BoundingBox(); }
   real_type SurfaceArea() const noexcept { return primitive_->SurfaceArea(); }
   rendering::SurfaceType Surface() const noexcept { return material_->Surface(); }
+  const RGB Irradiance() const noexcept { return material_->Irradiance(); }
   const Primitive* GetPrimitive() const noexcept { return primitive_; }
   const Material* GetMaterial() const noexcept { return material_; }
 
@@ -112,6 +115,7 @@ struct List {};   // brute force over all objects in insertion order (accelerati
 struct FlatScene {
   std::vector<AmberFlatObject> objects;
   std::vector<AmberFlatMaterial> materials;
+  std::vector<AmberFlatLight> lights;      // scene::LightSet order (light_set.h:61-82)
   AmberFlatScene flat{};
 };
 

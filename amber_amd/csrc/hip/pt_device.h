@@ -78,12 +78,23 @@ struct alignas(16) DevBvhNode {   // 64 B
   float rmin[3]; int32_t right;
   float rmax[3]; int32_t pad1;
 };
+// Light-tracing source record: one per DiffuseLight object, sorted by power (scene/light_set.h:61-82).
+struct alignas(16) DevLight {     // 96 B
+  uint32_t kind; int32_t slot;      // primitive kind ; filter-program slot of a light triangle (-1 otherwise)
+  float cum_power; float pdf_area;  // cumulative power ; Sum(Irradiance) / total power (light_set.h:107-111)
+  float irr[3]; float pad0;         // Irradiance = radiance * pi (material_diffuse_light.h:118-125)
+  float p[12];                      // triangle v0 v1 v2 normal | sphere centre r | disk centre normal r | cylinder centre normal r h
+  float pad1[4];
+};
+// One splat of a light path onto the sensor (algorithm_lt.cc:141-147)
+struct DevSplat { uint32_t path, sample, bounce, pixel; float rgb[3]; uint32_t pad; };   // 32 B
 struct DevLens {
   float origin[3];
   float global_[9];
   float local_[9];
   float focus_distance, sensor_distance, p_area;
   float neg_fd_over_sd;       // -focus_distance / sensor_distance (lens_thin.cc:87)
+  float neg_sd_over_fd;       // -sensor_distance / focus_distance (lens_thin.cc:118)
   float size_over_area;       // sensor.Size() / sensor.SceneArea() in float (lens_thin.cc:145)
   double sd2;                 // std::pow(sensor_distance_, 2) in double (lens_thin.cc:146)
   uint32_t n_blades;
@@ -94,6 +105,7 @@ struct DevLens {
 struct DevSensor {
   uint32_t w, h;
   float wf, hf, sw, sh;
+  float size_f;               // float(width * height): image.Size() (algorithm_lt.cc:146)
 };
 struct DevScene {
   const DevObject* __restrict__ objects;
@@ -109,6 +121,9 @@ struct DevScene {
   const DevBvhNode* __restrict__ bvh_nodes;     // engine BVH
   const uint32_t* __restrict__ bvh_prims;       // leaf order -> object index
   int32_t bvh_root;                             // child reference of the whole scene
+  const DevLight* __restrict__ lights;          // light tracing
+  uint32_t n_lights;
+  float total_power;
   uint32_t n_objects;
   uint32_t max_depth;
   DevLens lens;
@@ -668,6 +683,95 @@ __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 
   }
 }
 
+// Scene::SampleImportance: identical to SampleLight for the symmetric forwarders, Eye and DiffuseLight
+// (material_basic.h:340-351); BasicRefraction::SampleImportance (material_refraction.cc:222-263) drops the ior^2
+// radiance scaling and uses p = (rho + 0.5) / 2.
+__device__ __forceinline__ void SampleImportance(const DevMaterial& m, V3 normal, V3 dir_out, uint64_t& rng, V3& dir_in, V3& weight) {
+  if (m.kind != MAT_REFRACTION) { SampleLight(m, normal, dir_out, rng, dir_in, weight); return; }
+  const V3 rho = ld3(m.rho);
+  const float signed_cos_alpha = Dot(dir_out, normal);
+  const float ior = signed_cos_alpha > 0.0f ? 1.0f / m.param : m.param;
+  const float squared_cos_beta = 1.0f - (1.0f - signed_cos_alpha * signed_cos_alpha) * (ior * ior);
+  const V3 dir_r = PerfectReflection(dir_out, normal, signed_cos_alpha);
+  if (squared_cos_beta < 0.0f) { dir_in = dir_r; weight = 1.0f * rho; return; }
+  const float cos_alpha = Abs(signed_cos_alpha);
+  const float cos_beta = Sqrt(squared_cos_beta);
+  const V3 dir_t = (-ior) * dir_out + ((signed_cos_alpha < 0.0f ? 1.0f : -1.0f) * cos_beta + ior * signed_cos_alpha) * normal;
+  const float rho_r = static_cast<float>(static_cast<double>(m.r0) + static_cast<double>(1.0f - m.r0) * Pow5(1.0f - cos_alpha));
+  const float rho_t = 1.0f - rho_r;
+  const float p_r = (rho_r + 0.5f) / 2.0f;
+  const float p_t = (rho_t + 0.5f) / 2.0f;
+  if (Uniform(rng) < p_r) { dir_in = dir_r; weight = (rho_r / p_r) * rho; }
+  else { dir_in = dir_t; weight = (rho_t / p_t) * rho; }
+}
+
+// LightSet::GenerateRay (light_set.h:84-104) + Primitive::SampleSurfacePoint (primitive_*.cc) + HemispherePSA.
+__device__ __forceinline__ void GenerateLightRay(const DevScene& sc, uint64_t& rng, V3& origin, V3& dir, V3& weight, int& origin_slot) {
+  const float x = Uniform(rng) * sc.total_power;                       // prelude::Uniform(powers_.back(), sampler)
+  uint32_t pos = 0;
+  while (pos + 1u < sc.n_lights && sc.lights[pos].cum_power < x) ++pos; // std::lower_bound (clamped to the last light)
+  const DevLight* L = sc.lights + pos;
+  const uint32_t kind = L->kind;
+  V3 normal;
+  if (kind == PRIM_TRIANGLE) {                                          // primitive_triangle.cc:136-150
+    float u = Uniform(rng), v = Uniform(rng);
+    if (u + v >= 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+    origin = (1.0f - u - v) * ld3(L->p) + u * ld3(L->p + 3) + v * ld3(L->p + 6);
+    normal = ld3(L->p + 9);
+  } else if (kind == PRIM_SPHERE) {                                     // primitive_sphere.cc:115-122, SphereSA sampling.h:185-199
+    const float r0 = Uniform(rng) * (1.0f - (-1.0f)) + (-1.0f);
+    const float r1 = Uniform(rng);
+    const float sin_theta = Sqrt(1.0f - r0 * r0);
+    float sp, cp; SinCos(2.0f * 3.14159274f * r1, sp, cp);
+    normal = v3(r0 * cp, r0 * sp, sin_theta);
+    origin = ld3(L->p) + L->p[3] * normal;
+  } else if (kind == PRIM_DISK) {                                       // primitive_disk.cc:122-136
+    const float radius = Sqrt(Uniform(rng) * (L->p[6] * L->p[6]));
+    const V3 N = ld3(L->p + 3);
+    V3 u, v; OrthonormalBasis(N, u, v);
+    float ay, ax; SinCos(Uniform(rng) * 6.28318548f, ay, ax);           // Circle: theta = Uniform<T>(2 * kPI, sampler)
+    origin = ld3(L->p) + (u * ax + v * ay) * radius;
+    normal = N;
+  } else {                                                              // primitive_cylinder.cc:150-164
+    const float height = Uniform(rng) * L->p[7];
+    const V3 N = ld3(L->p + 3);
+    V3 u, v; OrthonormalBasis(N, u, v);
+    float ay, ax; SinCos(Uniform(rng) * 6.28318548f, ay, ax);
+    const V3 n = u * ax + v * ay;
+    origin = ld3(L->p) + N * height + n * L->p[6];
+    normal = Normalize(n);
+  }
+  dir = HemispherePSA(normal, rng);
+  weight = ld3(L->irr) / L->pdf_area;                                   // object.Irradiance() / PDFArea(object)
+  origin_slot = L->slot;
+}
+
+// Lens::Response for Ray(position, direction_out) (scene/scene.h:299-307, lens_thin.cc:109-130, lens_pinhole.cc:70-85,
+// Sensor::ResponsePixel sensor.cc:46-59).  Returns false when the ray does not reach the sensor.
+__device__ __forceinline__ bool LensResponse(const DevScene& sc, V3 position, V3 direction_out, uint32_t& pixel, float& value) {
+  const DevLens& L = sc.lens;
+  const V3 direction = MatMul(L.local_, direction_out);
+  float sx, sy;
+  if (L.kind == 1u) {
+    const V3 point = (L.sensor_distance / direction.z) * direction;
+    sx = point.x; sy = point.y; value = 1.0f;
+  } else {
+    if (direction.z >= 0.0f) return false;
+    const V3 aperture_point = MatMul(L.local_, position - ld3(L.origin));
+    const V3 sensor_point = L.neg_sd_over_fd * aperture_point + (L.sensor_distance / direction.z) * direction;
+    sx = sensor_point.x; sy = sensor_point.y;
+    value = static_cast<float>(Pow4(Normalize(sensor_point - aperture_point).z / direction.z));
+  }
+  const float uvx = sx / sc.sensor.sw + 0.5f, uvy = sy / sc.sensor.sh + 0.5f;
+  const float mn = uvy < uvx ? uvy : uvx, mx = uvx < uvy ? uvy : uvx;  // std::min / std::max of (x, y)
+  if (mn < 0.0f || mx >= 1.0f) return false;
+  uint32_t ix = static_cast<uint32_t>(uvx * sc.sensor.wf), iy = static_cast<uint32_t>(uvy * sc.sensor.hf);
+  if (ix > sc.sensor.w - 1u) ix = sc.sensor.w - 1u;
+  if (iy > sc.sensor.h - 1u) iy = sc.sensor.h - 1u;
+  pixel = ix + iy * sc.sensor.w;
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // eye ray: BasicThin::GenerateRay (lens_thin.cc:70-107) + Sensor::PixelBound::Uniform
 // (sensor.cc:111-120, jitter draw order Y then X -- the g++ order the reference outputs were made with)
@@ -722,9 +826,14 @@ __device__ __forceinline__ void GenerateEyeRay(const DevScene& sc, uint32_t px, 
 // ---------------------------------------------------------------------------------------------
 struct Bounce { int object; float t; V3 pos; V3 weight_before; };
 
-template <bool kTrace, int kEngine>
+// kLight = false: PathTracing::Thread::Render (algorithm_pt.cc:137-157).  kLight = true: LightTracing::Thread::Render
+// (algorithm_lt.cc:134-162): a hit on an Eye surface splats weight * response / image.Size() instead of collecting
+// emitted radiance, and the material is sampled with SampleImportance.
+struct SplatSink { DevSplat* records; unsigned int* count; uint32_t capacity; uint32_t path, sample; float size_f; };
+
+template <bool kTrace, int kEngine, bool kLight = false>
 __device__ __forceinline__ bool PathStep(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3& o, V3& d, V3& weight, V3& measurement,
-                                         uint64_t& rng, uint32_t& casts, int& origin_slot, Bounce* trace AMBER_STAMP_PARAM) {
+                                         uint64_t& rng, uint32_t& casts, int& origin_slot, Bounce* trace AMBER_STAMP_PARAM, const SplatSink* sink = nullptr) {
   HitRec h;
   ClosestHit<kEngine>(sc, lds_objects, lds_stack, o, d, origin_slot, h AMBER_STAMP_ARG);
   casts++;
@@ -737,10 +846,27 @@ __device__ __forceinline__ bool PathStep(const DevScene& sc, const DevObject* ld
   const DevMaterial m = sc.materials[mat];
   const V3 dir_out = -d;
   if (kTrace) { trace->object = h.idx; trace->t = h.t; trace->pos = pos; trace->weight_before = weight; }
-  measurement = measurement + weight * Radiance(m, normal, dir_out);        // algorithm_pt.cc:144
-  AMBER_STAMP(4);
   V3 dir_in, sw;
-  SampleLight(m, normal, dir_out, rng, dir_in, sw);                          // :145-146
+  if (kLight) {
+    if (m.kind == MAT_EYE) {                                                 // algorithm_lt.cc:141-147
+      uint32_t pixel; float value;
+      if (LensResponse(sc, pos, dir_out, pixel, value)) {
+        const V3 add = (weight * value) / sink->size_f;
+        const unsigned int k = atomicAdd(sink->count, 1u);
+        if (k < sink->capacity) {
+          DevSplat& r = sink->records[k];
+          r.path = sink->path; r.sample = sink->sample; r.bounce = casts; r.pixel = pixel;
+          r.rgb[0] = add.x; r.rgb[1] = add.y; r.rgb[2] = add.z; r.pad = 0u;
+        }
+      }
+    }
+    AMBER_STAMP(4);
+    SampleImportance(m, normal, dir_out, rng, dir_in, sw);
+  } else {
+    measurement = measurement + weight * Radiance(m, normal, dir_out);      // algorithm_pt.cc:144
+    AMBER_STAMP(4);
+    SampleLight(m, normal, dir_out, rng, dir_in, sw);                        // :145-146
+  }
   AMBER_STAMP(5);
   float p_rr = 0.9375f;                                                      // std::min<real_type>(kRussianRoulette, Max(w)) :148-149
   const float mw = Max3(sw);

@@ -11,6 +11,7 @@
 //           (/root/reference/src/amber/rendering/algorithm_pt.cc:112-160).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -45,6 +46,9 @@ struct RenderArgs {
   unsigned long long* ray_count;
   unsigned int* next_item;   // work-queue head (zeroed before every launch)
   unsigned long long* stamps; // diagnostic build only (AMBER_STAMPS): 8 section sums
+  DevSplat* splats;          // light tracing: splat records, their counter and capacity
+  unsigned int* splat_count;
+  uint32_t splat_capacity;
   uint64_t hashed_seed;      // SplitMix64(global_seed)
   uint32_t row_begin;
   uint32_t stripe_rows, stripe_period;   // 0,0 = contiguous rows
@@ -62,7 +66,9 @@ struct RenderArgs {
 #ifndef AMBER_MEGAKERNEL_WAVES_PER_SIMD
 #define AMBER_MEGAKERNEL_WAVES_PER_SIMD 1   // no register cap: 93 VGPRs -> 5 waves/SIMD (6 would spill 8 dwords; measured slower/faster: DESIGN.md)
 #endif
-template <int kEngine>
+// kLight: the same worker loop traces LIGHT paths (algorithm_lt.cc:112-163): an item is (light path index, chunk of
+// passes), nothing is summed per item, Eye hits append splat records instead.
+template <int kEngine, bool kLight = false>
 __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megakernel(const RenderArgs a) {
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
@@ -89,8 +95,10 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
     AMBER_STAMP(6);
     bool need = !alive && s >= s_end && !lane_done;
     if (need && have_item) {                                // item finished: publish its sum
-      float* p = a.partial + static_cast<size_t>(slot) * 3u;
-      p[0] = sum.x; p[1] = sum.y; p[2] = sum.z;
+      if (!kLight) {
+        float* p = a.partial + static_cast<size_t>(slot) * 3u;
+        p[0] = sum.x; p[1] = sum.y; p[2] = sum.z;
+      }
       have_item = false;
     }
     unsigned long long mask = __ballot(need);
@@ -133,9 +141,13 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
     AMBER_STAMP(0);
     if (!alive && !lane_done) {                             // regenerate: next sample of the item
       rng = XorShiftSeed(a.hashed_seed, pixel, s);
-      float ew;
-      GenerateEyeRay(sc, px, py, rng, o, d, ew, origin_slot);
-      w = v3(ew, ew, ew);                                   // Leading<RGB>(.., Radiant(weight)) lens_basic.h:139-144
+      if (kLight) {
+        GenerateLightRay(sc, rng, o, d, w, origin_slot);
+      } else {
+        float ew;
+        GenerateEyeRay(sc, px, py, rng, o, d, ew, origin_slot);
+        w = v3(ew, ew, ew);                                 // Leading<RGB>(.., Radiant(weight)) lens_basic.h:139-144
+      }
       meas = v3(0.f, 0.f, 0.f);
       casts = 0;
       alive = true;
@@ -143,7 +155,12 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
     }
     AMBER_STAMP(1);
     if (alive) {
-      alive = PathStep<false, kEngine>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG);
+      if (kLight) {
+        const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, pixel, s - 1u, sc.sensor.size_f};
+        alive = PathStep<false, kEngine, true>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, &sink);
+      } else {
+        alive = PathStep<false, kEngine>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG);
+      }
       ++rays;
       if (!alive) sum = sum + meas;                         // sequential sum over the item's samples
     }
@@ -292,6 +309,11 @@ struct amber_hip_pt {
   unsigned long long* d_rays = nullptr;
   unsigned int* d_next = nullptr;
   unsigned long long* d_stamps = nullptr;
+  DevLight* d_lights = nullptr;
+  DevSplat* d_splats = nullptr;
+  unsigned int* d_splat_count = nullptr;
+  uint32_t splat_capacity = 0;
+  uint64_t hashed_seed_lt = 0;
   float* d_partial = nullptr;
   size_t partial_floats = 0;
   int n_cus = 256;
@@ -335,6 +357,9 @@ int ValidateScene(const AmberFlatScene* s, const AmberSensor* sensor) {
   }
   for (uint32_t i = 0; i < s->n_materials; i++)
     if (s->materials[i].kind > AMBER_MAT_EYE) return Fail(AMBER_EINVAL, "material " + std::to_string(i) + ": unknown kind");
+  if (s->n_lights && !s->lights) return Fail(AMBER_EINVAL, "n_lights > 0 but lights is null");
+  for (uint32_t i = 0; i < s->n_lights; i++)
+    if (s->lights[i].object >= s->n_objects) return Fail(AMBER_EINVAL, "light object index out of range");
   const AmberFlatThinLens& L = s->lens;
   if (L.n_blades == 0) return Fail(AMBER_EINVAL, "lens has no aperture blades");
   if (L.kind > AMBER_LENS_PINHOLE) return Fail(AMBER_EINVAL, "unknown lens kind");
@@ -384,6 +409,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   h->row_begin = rb; h->row_end = re; h->local_rows = local_rows;
   h->stripe_rows = params->stripe_rows; h->stripe_period = params->stripe_rows ? params->stripe_period : 0;
   h->seed = params->seed; h->hashed_seed = HostSplitMix64(params->seed);
+  h->hashed_seed_lt = HostSplitMix64(params->seed + 0x6C74ull);     // light paths use streams of their own
   if (params->stream) { h->stream = static_cast<hipStream_t>(params->stream); }
   else {
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -442,6 +468,18 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   for (uint32_t i = 0; i < L.n_blades; i++)            // filter-program slot of every aperture blade (self-candidate trip)
     for (uint32_t k = 0; k < fprog.n_prog_tris; k++)
       if (fprog.order[k] == L.first_blade_object + i) blades[i].slot = static_cast<int32_t>(k);
+  std::vector<DevLight> lights(s->n_lights);
+  for (uint32_t i = 0; i < s->n_lights; i++) {
+    const AmberFlatLight& fl = s->lights[i];
+    const AmberFlatObject& fo = s->objects[fl.object];
+    DevLight& dl = lights[i];
+    std::memset(&dl, 0, sizeof dl);
+    dl.kind = fo.kind; dl.slot = -1; dl.cum_power = fl.cum_power; dl.pdf_area = fl.pdf_area;
+    for (int c = 0; c < 3; c++) dl.irr[c] = fl.irradiance[c];
+    for (int c = 0; c < 12; c++) dl.p[c] = fo.p[c];
+    for (uint32_t k = 0; k < fprog.n_prog_tris; k++)
+      if (fprog.order[k] == fl.object) dl.slot = static_cast<int32_t>(k);
+  }
 
   auto cleanup = [&](int code, const std::string& msg) { amber_hip_pt_destroy(h); return Fail(code, msg); };
 #define HIP_TRY_H(expr)                                                                            \
@@ -461,6 +499,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     HIP_TRY_H(hipMalloc(&h->d_prog_objects, (prog.size() + 1) * sizeof(DevObject)));
     if (!prog.empty()) HIP_TRY_H(hipMemcpy(h->d_prog_objects, prog.data(), prog.size() * sizeof(DevObject), hipMemcpyHostToDevice));
   }
+  HIP_TRY_H(hipMalloc(&h->d_lights, (lights.size() + 1) * sizeof(DevLight)));
+  if (!lights.empty()) HIP_TRY_H(hipMemcpy(h->d_lights, lights.data(), lights.size() * sizeof(DevLight), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMalloc(&h->d_bvh_nodes, (bvh.nodes.size() + 1) * sizeof(DevBvhNode)));
   HIP_TRY_H(hipMalloc(&h->d_bvh_prims, (bvh.prim_index.size() + 1) * sizeof(uint32_t)));
   if (!bvh.nodes.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(DevBvhNode), hipMemcpyHostToDevice));
@@ -486,6 +526,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.planes = h->d_planes; sc.tri_filters = h->d_tri_filters; sc.sphere_filters = h->d_sphere_filters;
   sc.n_planes = static_cast<uint32_t>(fprog.planes.size()); sc.n_sphere_filters = static_cast<uint32_t>(fprog.spheres.size());
   sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_prims = h->d_bvh_prims; sc.bvh_root = bvh.root_ref;
+  sc.lights = h->d_lights; sc.n_lights = s->n_lights; sc.total_power = s->n_lights ? s->lights[s->n_lights - 1].cum_power : 0.0f;
   sc.n_prog_tris = fprog.n_prog_tris; sc.always_mask = fprog.always_mask; sc.prog_objects = h->d_prog_objects;
   sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;
   h->n_materials = s->n_materials;
@@ -508,6 +549,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.sensor.w = sensor->width; sc.sensor.h = sensor->height;
   sc.sensor.wf = static_cast<float>(sensor->width); sc.sensor.hf = static_cast<float>(sensor->height);
   sc.sensor.sw = sensor->scene_width; sc.sensor.sh = sensor->scene_height;
+  sc.sensor.size_f = static_cast<float>(static_cast<uint64_t>(sensor->width) * sensor->height);
+  { volatile float q = -L.sensor_distance / L.focus_distance; sc.lens.neg_sd_over_fd = q; }
   *out = h;
   return AMBER_OK;
 }
@@ -643,7 +686,7 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
       h->partial_floats = need;
     }
     RenderArgs a;
-    a.scene = h->scene; a.partial = h->d_partial; a.ray_count = h->d_rays; a.next_item = h->d_next; a.stamps = h->d_stamps; a.hashed_seed = h->hashed_seed;
+    a.scene = h->scene; a.partial = h->d_partial; a.ray_count = h->d_rays; a.next_item = h->d_next; a.stamps = h->d_stamps; a.splats = nullptr; a.splat_count = nullptr; a.splat_capacity = 0; a.hashed_seed = h->hashed_seed;
     a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first_sample + done; a.n_samples = n;
     a.n_chunks = n_chunks; a.n_items = n_pixels * n_chunks;
     // persistent workers: 5 workgroups of 4 waves per CU (90 VGPRs -> 5 waves/SIMD), fewer if the queue is short
@@ -664,6 +707,61 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_elems + 255u) / 256u), dim3(256), 0, h->stream, h->d_fb, h->d_partial, n_elems, n_chunks);
     HIP_TRY(hipGetLastError());
     done += n;
+  }
+  return AMBER_OK;
+}
+
+int amber_hip_lt_trace(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, AmberSplat* out, uint32_t capacity,
+                       uint32_t* n_out, uint64_t* ray_count) {
+  if (!h || !n_out || (capacity && !out)) return Fail(AMBER_EINVAL, "null argument");
+  *n_out = 0;
+  if (h->engine == AMBER_ENGINE_WAVEFRONT) return Fail(AMBER_EINVAL, "light tracing runs on the work-queue kernel (engine auto, list, two_phase or bvh)");
+  if (static_cast<uint64_t>(first_sample) + n_samples > 0xffffffffull) return Fail(AMBER_EINVAL, "sample index overflow");
+  if (n_samples == 0 || h->scene.n_lights == 0) { if (ray_count) *ray_count = 0; return AMBER_OK; }
+  HIP_TRY(hipSetDevice(h->device));
+  const uint32_t n_paths = h->scene.sensor.w * h->scene.sensor.h;           // image.Size() light paths per pass
+  const uint32_t n_chunks = (n_samples + AMBER_ACCUM_CHUNK - 1) / AMBER_ACCUM_CHUNK;
+  if (static_cast<uint64_t>(n_paths) * n_chunks > 0x7fffffffull) return Fail(AMBER_EINVAL, "too many light paths for one call");
+  const uint32_t dev_capacity = capacity ? capacity : 1u;
+  if (dev_capacity > h->splat_capacity) {
+    if (h->d_splats) { HIP_TRY(hipFree(h->d_splats)); h->d_splats = nullptr; h->splat_capacity = 0; }
+    hipError_t e = hipMalloc(&h->d_splats, static_cast<size_t>(dev_capacity) * sizeof(DevSplat));
+    if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(splats): ") + hipGetErrorString(e));
+    h->splat_capacity = dev_capacity;
+  }
+  if (!h->d_splat_count) HIP_TRY(hipMalloc(&h->d_splat_count, sizeof(unsigned int)));
+  unsigned long long rays_before = 0, rays_after = 0;
+  HIP_TRY(hipMemcpyAsync(&rays_before, h->d_rays, sizeof rays_before, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_splat_count, 0, sizeof(unsigned int), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
+  RenderArgs a;
+  a.scene = h->scene; a.partial = nullptr; a.ray_count = h->d_rays; a.next_item = h->d_next; a.stamps = nullptr;
+  a.splats = h->d_splats; a.splat_count = h->d_splat_count; a.splat_capacity = dev_capacity; a.hashed_seed = h->hashed_seed_lt;
+  a.row_begin = 0; a.stripe_rows = 0; a.stripe_period = 0; a.n_pixels = n_paths; a.first_sample = first_sample; a.n_samples = n_samples;
+  a.n_chunks = n_chunks; a.n_items = n_paths * n_chunks;
+  uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * 5u;
+  const uint32_t by_work = (a.n_items + 255u) / 256u;
+  if (by_work < n_blocks) n_blocks = by_work;
+  if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+  else if (h->hit_engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL((pt_megakernel<ENGINE_BVH, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+  else hipLaunchKernelGGL((pt_megakernel<ENGINE_LIST, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+  HIP_TRY(hipGetLastError());
+  unsigned int produced = 0;
+  HIP_TRY(hipMemcpyAsync(&produced, h->d_splat_count, sizeof produced, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(&rays_after, h->d_rays, sizeof rays_after, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (ray_count) *ray_count = rays_after - rays_before;
+  *n_out = produced;
+  if (produced > capacity) return Fail(AMBER_ENOMEM, "splat buffer too small: " + std::to_string(produced) + " splats produced");
+  if (produced) {
+    static_assert(sizeof(AmberSplat) == sizeof(DevSplat), "splat layouts must agree");
+    HIP_TRY(hipMemcpy(out, h->d_splats, static_cast<size_t>(produced) * sizeof(DevSplat), hipMemcpyDeviceToHost));
+    // the reference adds the splats of pass s in path order (algorithm_lt.cc:112-123): restore that order
+    std::sort(out, out + produced, [](const AmberSplat& x, const AmberSplat& y) {
+      if (x.sample != y.sample) return x.sample < y.sample;
+      if (x.path != y.path) return x.path < y.path;
+      return x.bounce < y.bounce;
+    });
   }
   return AMBER_OK;
 }
@@ -753,6 +851,9 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_rays) (void)hipFree(h->d_rays);
   if (h->d_next) (void)hipFree(h->d_next);
   if (h->d_stamps) (void)hipFree(h->d_stamps);
+  if (h->d_lights) (void)hipFree(h->d_lights);
+  if (h->d_splats) (void)hipFree(h->d_splats);
+  if (h->d_splat_count) (void)hipFree(h->d_splat_count);
   if (h->d_partial) (void)hipFree(h->d_partial);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;

@@ -93,12 +93,23 @@ typedef struct {
   uint32_t kind;               /* AMBER_LENS_* */
 } AmberFlatThinLens;
 
+/* One entry per SurfaceType::Light object, in the order of scene::LightSet (sorted by power, light_set.h:61-82):
+ * cumulative power, pdf_area = Sum(Irradiance) / total power, Irradiance = radiance * pi.  Used by light tracing only. */
+typedef struct {
+  uint32_t object;        /* index into objects */
+  float    cum_power;
+  float    pdf_area;
+  float    irradiance[3];
+} AmberFlatLight;
+
 typedef struct {
   const AmberFlatObject*   objects;
   uint32_t                 n_objects;
   const AmberFlatMaterial* materials;
   uint32_t                 n_materials;
   AmberFlatThinLens        lens;
+  const AmberFlatLight*    lights;      /* may be NULL when n_lights == 0 */
+  uint32_t                 n_lights;
 } AmberFlatScene;
 
 /* rendering::Sensor, sensor.h:34-92 / application.cc:89-94 */
@@ -154,6 +165,15 @@ int  amber_hip_pt_local_rows(amber_hip_pt*, uint32_t* n_rows);
  * number of timed launches since create/clear and their total duration. */
 int  amber_hip_pt_kernel_time(amber_hip_pt*, uint32_t* n_launches, double* total_ms);
 void amber_hip_pt_destroy(amber_hip_pt*);
+
+/* ---- light tracing (rendering::LightTracing, algorithm_lt.cc:112-163) on the same kernels -----------
+ * Traces width*height light paths for every pass in [first_sample, first_sample + n_samples) (path i of pass s is seeded
+ * by (seed, i, s)) and returns the splats they make on the sensor, sorted in the reference's accumulation order
+ * (pass, path, bounce).  value = weight * response / image.Size() is ready to be added to pixel `pixel`.
+ * Synchronous.  AMBER_ENOMEM if more than `capacity` splats were produced (n_out then holds the number needed). */
+typedef struct { uint32_t path, sample, bounce, pixel; float rgb[3]; uint32_t pad; } AmberSplat;
+int amber_hip_lt_trace(amber_hip_pt*, uint32_t first_sample, uint32_t n_samples, AmberSplat* out, uint32_t capacity,
+                       uint32_t* n_out, uint64_t* ray_count);
 
 const char* amber_hip_last_error(void);
 int         amber_hip_abi_version(void);

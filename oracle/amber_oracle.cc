@@ -678,6 +678,111 @@ EyeRay GenerateEyeRay(const ThinLens& L, const Sensor& S, uint64_t px, uint64_t 
   return e;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Light tracing support (src/amber/rendering/algorithm_lt.cc:125-163, scene/light_set.h:61-123,
+// lens_thin.cc:109-130, lens_pinhole.cc:70-85, sensor.cc:46-59, Primitive::SampleSurfacePoint)
+// ------------------------------------------------------------------------------------------
+Scatter SampleImportance(const Material& m, V3 normal, V3 dir_out, Sampler& smp, const Math& M) {
+  if (m.kind != ORACLE_MAT_REFRACTION) return SampleLight(m, normal, dir_out, smp, M);   // symmetric forwarders / Eye / Light
+  Scatter sc;                                                                             // material_refraction.cc:222-263
+  const float signed_cos_alpha = Dot(dir_out, normal);
+  const float ior = signed_cos_alpha > 0 ? 1 / m.param : m.param;
+  const float squared_cos_beta = 1 - (1 - signed_cos_alpha * signed_cos_alpha) * (ior * ior);
+  const V3 dir_r = PerfectReflection(dir_out, normal, signed_cos_alpha);
+  if (squared_cos_beta < 0) { sc.dir = dir_r; sc.weight = 1.0f * m.rho; return sc; }
+  const float cos_alpha = std::abs(signed_cos_alpha);
+  const float cos_beta = std::sqrt(squared_cos_beta);
+  const V3 dir_t = -ior * dir_out + ((signed_cos_alpha < 0 ? 1 : -1) * cos_beta + ior * signed_cos_alpha) * normal;
+  const float rho_r = Schlick(m.r0, cos_alpha, M);
+  const float rho_t = 1 - rho_r;                                       // no radiance scaling for importance transport
+  const float p_r = (rho_r + 0.5f) / 2;
+  const float p_t = (rho_t + 0.5f) / 2;
+  if (UniformF(smp) < p_r) { sc.dir = dir_r; sc.weight = (rho_r / p_r) * m.rho; }
+  else { sc.dir = dir_t; sc.weight = (rho_t / p_t) * m.rho; }
+  return sc;
+}
+
+float SurfaceAreaOf(const Object& o) {
+  switch (o.kind) {
+    case ORACLE_PRIM_TRIANGLE: return TriangleArea(o);
+    case ORACLE_PRIM_SPHERE: return 4 * kPIf * o.radius * o.radius;                 // primitive_sphere.cc:109-113
+    case ORACLE_PRIM_DISK: return kPIf * o.radius * o.radius;                       // primitive_disk.cc:116-120
+    default: return 2 * kPIf * o.radius * o.height;                                 // primitive_cylinder.cc:144-148
+  }
+}
+// sampling.h:176-183: theta = Uniform<T>(2 * kPI, sampler) -- the product is long double, narrowed to T
+inline void Circle(Sampler& smp, const Math& M, float& cx, float& cy) {
+  const float theta = UniformF(static_cast<float>(2 * kPI), smp);
+  float s, c; M.sincos(theta, s, c);
+  cx = c; cy = s;
+}
+// returns origin and direction (the surface normal) of Primitive::SampleSurfacePoint
+void SampleSurfacePoint(const Object& o, Sampler& smp, const Math& M, V3& origin, V3& normal) {
+  switch (o.kind) {
+    case ORACLE_PRIM_TRIANGLE: {                                        // primitive_triangle.cc:136-150
+      float u = UniformF(smp), v = UniformF(smp);
+      if (u + v >= 1) { u = 1 - u; v = 1 - v; }
+      origin = (1 - u - v) * o.a + u * o.b + v * o.c; normal = o.normal; return;
+    }
+    case ORACLE_PRIM_SPHERE: {                                          // primitive_sphere.cc:115-122, SphereSA sampling.h:185-199
+      const float r0 = static_cast<float>(smp()) * (1.0f - (-1.0f)) + (-1.0f);       // Uniform<T>(-1, 1, sampler)
+      const float r1 = UniformF(smp);
+      const float cos_theta = r0;
+      const float sin_theta = std::sqrt(1 - r0 * r0);
+      const float phi = 2 * kPIf * r1;
+      float sp, cp; M.sincos(phi, sp, cp);
+      normal = v3(cos_theta * cp, cos_theta * sp, sin_theta);
+      origin = o.a + o.radius * normal; return;
+    }
+    case ORACLE_PRIM_DISK: {                                            // primitive_disk.cc:122-136
+      const float radius = std::sqrt(UniformF(o.radius * o.radius, smp));
+      V3 u, v; OrthonormalBasis(o.b, u, v);
+      float ax, ay; Circle(smp, M, ax, ay);
+      origin = o.a + (u * ax + v * ay) * radius; normal = o.b; return;
+    }
+    default: {                                                          // primitive_cylinder.cc:150-164
+      const float height = UniformF(o.height, smp);
+      V3 u, v; OrthonormalBasis(o.b, u, v);
+      float ax, ay; Circle(smp, M, ax, ay);
+      const V3 n = u * ax + v * ay;
+      origin = o.a + o.b * height + n * o.radius;
+      normal = Normalize(n);                                            // Ray(origin, Vector3) normalises, ray.h:52-56
+      return;
+    }
+  }
+}
+
+struct Light { uint32_t object; float cum_power; V3 irradiance; };
+struct LightSet {                                                       // scene/light_set.h:61-82
+  std::vector<Light> lights;
+  float total() const { return lights.empty() ? 0.0f : lights.back().cum_power; }
+};
+
+// Sensor::ResponsePixel sensor.cc:46-59 ; returns false when the point is off the sensor
+bool ResponsePixel(const Sensor& S, float px, float py, uint64_t& x, uint64_t& y) {
+  const float uvx = px / S.sw + 0.5f, uvy = py / S.sh + 0.5f;
+  if (std::min(uvx, uvy) < 0 || std::max(uvx, uvy) >= 1) return false;
+  x = std::min<uint64_t>(S.w - 1, uvx * S.w);                           // UVToPixel sensor.cc:86-92 (float -> integer truncation)
+  y = std::min<uint64_t>(S.h - 1, uvy * S.h);
+  return true;
+}
+// Lens::Response for Ray(position, direction_out): scene/scene.h:299-307
+bool LensResponse(const ThinLens& L, const Sensor& S, V3 position, V3 direction_out, const Math& M, uint64_t& x, uint64_t& y, float& value) {
+  const V3 direction = L.local_(direction_out);
+  if (L.kind == 1) {                                                    // lens_pinhole.cc:70-85
+    const V3 point = L.sensor_distance / direction.z * direction;
+    if (!ResponsePixel(S, point.x, point.y, x, y)) return false;
+    value = 1; return true;
+  }
+  if (direction.z >= 0) return false;                                   // lens_thin.cc:111-114
+  const V3 aperture_point = L.local_(position - L.origin);
+  const V3 sensor_point = -L.sensor_distance / L.focus_distance * aperture_point + L.sensor_distance / direction.z * direction;
+  if (!ResponsePixel(S, sensor_point.x, sensor_point.y, x, y)) return false;
+  value = static_cast<float>(M.pow_i(Normalize(sensor_point - aperture_point).z / direction.z, 4));
+  return true;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -688,11 +793,29 @@ struct oracle_scene {
   std::vector<Object> objects;        // insertion order
   std::vector<Material> materials;
   ThinLens lens;
+  LightSet light_set;
   std::unique_ptr<BVH> bvh;
 
   void Finish() {
     for (uint32_t i = 0; i < objects.size(); i++) objects[i].index = i;
+    BuildLightSet();
     if (accel == ORACLE_ACCEL_BVH) bvh = std::make_unique<BVH>(std::vector<Object>(objects));
+  }
+  // Scene::Create collects the SurfaceType::Light objects (scene/scene.h:177-182); LightSet sorts them by power and
+  // accumulates (light_set.h:61-82).  Power = Sum(SurfaceArea * Irradiance) (scene/object.h:99-103), Irradiance = radiance * pi.
+  void BuildLightSet() {
+    struct Item { uint32_t index; float power; V3 irr; V3 irradiance() const { return irr; } };
+    std::vector<Item> items;
+    for (const Object& o : objects) {
+      const Material& m = materials[o.material];
+      if (m.kind != ORACLE_MAT_DIFFUSE_LIGHT) continue;
+      const V3 irr = m.rho * kPIf;
+      const V3 p = SurfaceAreaOf(o) * irr;
+      items.push_back(Item{o.index, p.x + p.y + p.z, irr});
+    }
+    std::sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.power < y.power; });
+    float power = 0;
+    for (const Item& it : items) { power += it.power; light_set.lights.push_back(Light{it.index, power, it.irradiance()}); }
   }
   // Scene::Cast scene/scene.h:236-244 -> Acceleration::Cast(ray, FLT_MAX) acceleration.h:46-51
   bool Cast(const Ray& ray, Hit& hit, const Object*& obj) const {
@@ -754,6 +877,56 @@ PathResult TracePath(const oracle_scene& sc, const Sensor& S, uint64_t px, uint6
   }
   r.measurement = measurement;
   return r;
+}
+
+}  // namespace
+
+
+namespace {
+
+struct SplatRecord { uint32_t path, sample, bounce, pixel; float rgb[3]; };
+
+// LightTracing::Thread::Render algorithm_lt.cc:125-163 for one light path; appends the splats it makes.
+uint32_t TraceLightPath(const oracle_scene& sc, const Sensor& S, uint32_t path, uint32_t sample, Sampler& smp, const Math& M,
+                        uint32_t max_depth, std::vector<SplatRecord>& out) {
+  const LightSet& ls = sc.light_set;
+  if (ls.lights.empty()) return 0;
+  // LightSet::GenerateRay light_set.h:84-104
+  const float x = UniformF(ls.total(), smp);
+  std::size_t pos = 0;
+  while (pos < ls.lights.size() && ls.lights[pos].cum_power < x) pos++;          // std::lower_bound
+  if (pos >= ls.lights.size()) pos = ls.lights.size() - 1;                        // objects_.at(pos) would throw; unreachable for u < 1
+  const Light& light = ls.lights[pos];
+  const Object& lobj = sc.objects[light.object];
+  V3 origin, normal;
+  SampleSurfacePoint(lobj, smp, M, origin, normal);
+  const V3 dir = HemispherePSA(normal, smp, M);
+  const float pdf_area = (light.irradiance.x + light.irradiance.y + light.irradiance.z) / ls.total();   // light_set.h:107-111
+  Ray ray{origin, dir};
+  V3 weight = light.irradiance / splat(pdf_area);
+  const float size_f = static_cast<float>(S.w * S.h);
+  uint32_t casts = 0;
+  for (;;) {
+    Hit hit; const Object* obj = nullptr;
+    sc.Cast(ray, hit, obj);
+    casts++;
+    if (!hit) break;
+    const Material& m = sc.materials[obj->material];
+    if (m.kind == ORACLE_MAT_EYE) {                                       // algorithm_lt.cc:141-147
+      uint64_t px, py; float value;
+      if (LensResponse(sc.lens, S, hit.pos, -ray.d, M, px, py, value)) {
+        const V3 add = (weight * splat(value)) / splat(size_f);           // weight * response.Value() / image.Size()
+        out.push_back(SplatRecord{path, sample, casts, static_cast<uint32_t>(px + py * S.w), {add.x, add.y, add.z}});
+      }
+    }
+    const Scatter scat = SampleImportance(m, hit.n, -ray.d, smp, M);
+    const float p_rr = std::min<float>(static_cast<float>(kRussianRoulette), Max3(scat.weight));
+    if (UniformF(smp) >= p_rr) break;
+    if (max_depth && casts >= max_depth) break;
+    ray = Ray{hit.pos, scat.dir};
+    weight = weight * (scat.weight / splat(p_rr));
+  }
+  return casts;
 }
 
 }  // namespace
@@ -1044,6 +1217,43 @@ void oracle_xorshift_uniforms(uint64_t state, uint32_t n, double* u) { XorShiftS
 
 void oracle_sincos(float phi, int math, float* s, float* c) { Math{math}.sincos(phi, *s, *c); }
 float oracle_pow(float x, float y, int math) { return Math{math}.powf_(x, y); }
+
+// Light tracing in XorShift mode: passes [first_sample, first_sample+n); every pass traces W*H light paths (path i
+// seeded by (lt_seed, i, pass)) and adds their splats to a zeroed pass image in path order; pass images are added to
+// sum_rgb in pass order.  Returns the number of splats; optionally copies the first max_records of them (7 x u32 each:
+// path, sample, bounce, pixel, rgb bits) in accumulation order.
+uint64_t oracle_render_lt_xorshift(const oracle_scene* sc, const oracle_sensor* sensor, uint64_t global_seed, uint32_t first_sample,
+                                   uint32_t n_samples, int math, uint32_t max_depth, float* sum_rgb, oracle_counters* counters,
+                                   uint32_t* records, uint64_t max_records) {
+  const Sensor S{sensor->width, sensor->height, sensor->scene_width, sensor->scene_height};
+  const Math M{math};
+  const uint64_t lt_seed = global_seed + 0x6C74ull;                      // decorrelated from the path tracer's streams
+  const uint32_t n_paths = static_cast<uint32_t>(S.w * S.h);
+  oracle_counters cnt{0, 0, 0};
+  uint64_t n_rec = 0;
+  std::vector<float> pass(static_cast<std::size_t>(n_paths) * 3);
+  for (uint32_t s = first_sample; s < first_sample + n_samples; s++) {
+    std::vector<SplatRecord> recs;
+    for (uint32_t i = 0; i < n_paths; i++) {
+      XorShiftSampler smp(XorShiftSeed(lt_seed, i, s));
+      cnt.casts += TraceLightPath(*sc, S, i, s, smp, M, max_depth, recs);
+      cnt.paths++;
+    }
+    std::fill(pass.begin(), pass.end(), 0.0f);
+    for (const SplatRecord& r : recs) {
+      float* p = &pass[static_cast<std::size_t>(r.pixel) * 3];
+      p[0] += r.rgb[0]; p[1] += r.rgb[1]; p[2] += r.rgb[2];
+      if (records && n_rec < max_records) {
+        uint32_t* q = records + n_rec * 7;
+        q[0] = r.path; q[1] = r.sample; q[2] = r.bounce; q[3] = r.pixel; std::memcpy(q + 4, r.rgb, 12);
+      }
+      n_rec++;
+    }
+    if (!recs.empty()) for (std::size_t k = 0; k < pass.size(); k++) sum_rgb[k] += pass[k];
+  }
+  if (counters) *counters = cnt;
+  return n_rec;
+}
 
 uint64_t oracle_fnv1a64(const void* data, uint64_t n_bytes) {
   const unsigned char* p = static_cast<const unsigned char*>(data);

@@ -106,6 +106,12 @@ void oracle_render_xorshift(const oracle_scene*, const oracle_sensor*, uint64_t 
                             int math, uint32_t max_depth, uint32_t n_threads, uint32_t chunk,
                             float* sum_rgb, oracle_counters* counters);
 
+/* Light tracing (algorithm_lt.cc:112-163) in XorShift mode; see amber_oracle.cc.  No reference output exists for it:
+ * it is pinned only through the functions it shares with the pinned path tracer. */
+uint64_t oracle_render_lt_xorshift(const oracle_scene*, const oracle_sensor*, uint64_t global_seed, uint32_t first_sample,
+                                   uint32_t n_samples, int math, uint32_t max_depth, float* sum_rgb, oracle_counters* counters,
+                                   uint32_t* records, uint64_t max_records);
+
 /* per-path trace in XorShift mode (for path-level parity tests) */
 typedef struct {
   int32_t  object;       /* object index in oracle object order, -1 = miss */

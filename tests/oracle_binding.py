@@ -75,6 +75,8 @@ def load():
     L.oracle_scene_bvh_stats.argtypes = [vp] + [C.POINTER(u32)] * 3
     L.oracle_render_mt.argtypes = [vp, C.POINTER(OSensor), u64, u32, C.c_int, vp, C.POINTER(OCounters)]
     L.oracle_render_xorshift.argtypes = [vp, C.POINTER(OSensor), u64, u32, u32, u32, u32, C.c_int, u32, u32, u32, vp, C.POINTER(OCounters)]
+    L.oracle_render_lt_xorshift.restype = u64
+    L.oracle_render_lt_xorshift.argtypes = [vp, C.POINTER(OSensor), u64, u32, u32, C.c_int, u32, vp, C.POINTER(OCounters), vp, u64]
     L.oracle_trace_path.restype = u32
     L.oracle_trace_path.argtypes = [vp, C.POINTER(OSensor), u64, u32, u32, u32, C.c_int, u32, C.POINTER(OBounce), u32, C.POINTER(f)]
     L.oracle_cast.restype = C.c_int32
@@ -148,6 +150,16 @@ class Scene:
         y0, y1 = rows if rows else (0, h)
         self.L.oracle_render_xorshift(self.h, C.byref(s), seed, first, n, y0, y1, math, max_depth, threads, chunk, img.ctypes.data, C.byref(cnt))
         return img, cnt
+
+    def render_lt(self, w, h, seed, first, n, math=MATH_PORTABLE, max_depth=0, max_records=1 << 16):
+        """Light tracing: returns (sum image, counters, records (k,7) uint32 in accumulation order)."""
+        s = sensor(w, h)
+        img = np.zeros((h, w, 3), np.float32)
+        cnt = OCounters()
+        rec = np.zeros((max_records, 7), np.uint32)
+        k = self.L.oracle_render_lt_xorshift(self.h, C.byref(s), seed, first, n, math, max_depth, img.ctypes.data, C.byref(cnt), rec.ctypes.data, max_records)
+        assert k <= max_records
+        return img, cnt, rec[:k]
 
     def trace(self, w, h, seed, px, py, sample, math=MATH_PORTABLE, max_depth=0, max_bounces=16):
         s = sensor(w, h)

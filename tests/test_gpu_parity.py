@@ -586,3 +586,48 @@ def test_edge_sizes_and_engine_thresholds(amber, cornell):
     pt = amber.PathTracer(h3, amber.Sensor.default(16, 16), seed=1); pt.render_pass(0, 8)
     img, rays = pt.download()
     assert rays == 16 * 16 * 8 and not img.any()
+
+
+def test_light_tracing(amber, cornell):
+    """rendering::LightTracing (algorithm_lt.cc:112-163) on the same kernels: light sampling over all four primitive kinds
+    (LightSet order, SampleSurfacePoint, HemispherePSA), SampleImportance incl. refraction, lens Response and the splat
+    records, bit for bit against the oracle; then the Algorithm::Render adapter (`--algorithm lt`)."""
+    lights = dict(
+        materials=[(4, (30.0, 20.0, 10.0), 0.0), (0, (0.7, 0.6, 0.5), 0.0), (2, (0.8, 0.8, 0.8), 0.0), (3, (1.0, 1.0, 1.0), 1.5), (4, (5.0, 5.0, 9.0), 0.0)],
+        objects=[
+            (2, 0, [0.0, 1.5, 0.0, 0.0, -1.0, 0.0, 0.6]),                      # disk light
+            (0, 4, [-1.0, 1.4, -1.0, -1.0, 1.4, 1.0, -0.5, 1.4, 0.0]),        # triangle light
+            (1, 0, [1.2, 0.8, 0.0, 0.15]),                                     # sphere light
+            (3, 4, [-1.4, -0.5, 0.5, 0.0, 1.0, 0.0, 0.1, 0.6]),               # cylinder light
+            (0, 1, [-3, -1, -3, 3, -1, 3, 3, -1, -3]), (0, 1, [-3, -1, -3, -3, -1, 3, 3, -1, 3]),
+            (1, 2, [0.7, -0.6, -0.3, 0.4]), (1, 3, [0.0, -0.5, 0.8, 0.45]),
+        ],
+        transform=[1, 0, 0, 0, 0, 1, 0, 0.2, 0, 0, 1, 2.6, 0, 0, 0, 1], focal_length=0.05, focus_distance=2.6, radius=0.45, n_blades=5,
+    )
+    hs, osc = amber.HostScene.create(**lights), O.Scene.create(**lights)
+    W, H = 48, 36
+    pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=13)
+    rec, rays = pt.lt_trace(2, 21)
+    ref_img, cnt, oref = osc.render_lt(W, H, 13, 2, 21)
+    assert rays == cnt.casts and len(rec) == len(oref) and len(rec) > 300
+    got = np.stack([rec["path"], rec["sample"], rec["bounce"], rec["pixel"], *[rec["rgb"][:, c].view(np.uint32) for c in range(3)]], 1)
+    assert np.array_equal(got, oref)
+    assert rec["bounce"].max() >= 3 and len(np.unique(rec["pixel"])) > 100
+    # engine BVH and LIST produce the same records (closest hit is engine independent)
+    for eng in (amber.ENGINE_LIST, amber.ENGINE_BVH):
+        r2, rays2 = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=13, engine=eng).lt_trace(2, 21)
+        assert rays2 == rays and np.array_equal(r2, rec)
+    # adapter: mean image over passes, pass images summed in order
+    img, st = hs.render(amber.Sensor.default(W, H), 12, seed=13, samples_per_launch=5, algorithm="lt")
+    oimg, ocnt, _ = osc.render_lt(W, H, 13, 0, 12)
+    assert st["passes"] == 12 and st["rays"] == ocnt.casts
+    assert np.array_equal(bits(img), bits(oimg / np.float32(12))) and (img > 0).any()
+    # the Cornell box: its 5 cm aperture is hit by ~1e-4 of the light paths; whatever arrives must match exactly
+    hc, oc = cornell
+    pt = amber.PathTracer(hc, amber.Sensor.default(64, 64), seed=3)
+    rec, rays = pt.lt_trace(0, 48)
+    _, cnt, oref = oc.render_lt(64, 64, 3, 0, 48)
+    assert rays == cnt.casts and len(rec) == len(oref)
+    if len(rec):
+        got = np.stack([rec["path"], rec["sample"], rec["bounce"], rec["pixel"], *[rec["rgb"][:, c].view(np.uint32) for c in range(3)]], 1)
+        assert np.array_equal(got, oref)
