@@ -607,21 +607,21 @@ def test_light_tracing(amber, cornell):
     hs, osc = amber.HostScene.create(**lights), O.Scene.create(**lights)
     W, H = 48, 36
     pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=13)
-    rec, rays = pt.lt_trace(2, 21)
-    ref_img, cnt, oref = osc.render_lt(W, H, 13, 2, 21)
-    assert rays == cnt.casts and len(rec) == len(oref) and len(rec) > 300
+    rec, rays = pt.lt_trace(2, 400)
+    ref_img, cnt, oref = osc.render_lt(W, H, 13, 2, 400)
+    assert rays == cnt.casts and len(rec) == len(oref) and len(rec) > 30    # only light that lands on the 36 mm sensor counts
     got = np.stack([rec["path"], rec["sample"], rec["bounce"], rec["pixel"], *[rec["rgb"][:, c].view(np.uint32) for c in range(3)]], 1)
     assert np.array_equal(got, oref)
-    assert rec["bounce"].max() >= 3 and len(np.unique(rec["pixel"])) > 100
+    assert rec["bounce"].max() >= 3 and len(np.unique(rec["pixel"])) > 20
     # engine BVH and LIST produce the same records (closest hit is engine independent)
     for eng in (amber.ENGINE_LIST, amber.ENGINE_BVH):
-        r2, rays2 = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=13, engine=eng).lt_trace(2, 21)
+        r2, rays2 = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=13, engine=eng).lt_trace(2, 400)
         assert rays2 == rays and np.array_equal(r2, rec)
     # adapter: mean image over passes, pass images summed in order
-    img, st = hs.render(amber.Sensor.default(W, H), 12, seed=13, samples_per_launch=5, algorithm="lt")
-    oimg, ocnt, _ = osc.render_lt(W, H, 13, 0, 12)
-    assert st["passes"] == 12 and st["rays"] == ocnt.casts
-    assert np.array_equal(bits(img), bits(oimg / np.float32(12))) and (img > 0).any()
+    img, st = hs.render(amber.Sensor.default(W, H), 150, seed=13, samples_per_launch=64, algorithm="lt")
+    oimg, ocnt, _ = osc.render_lt(W, H, 13, 0, 150)
+    assert st["passes"] == 150 and st["rays"] == ocnt.casts
+    assert np.array_equal(bits(img), bits(oimg / np.float32(150))) and (img > 0).any()
     # the Cornell box: its 5 cm aperture is hit by ~1e-4 of the light paths; whatever arrives must match exactly
     hc, oc = cornell
     pt = amber.PathTracer(hc, amber.Sensor.default(64, 64), seed=3)
