@@ -115,7 +115,8 @@ def load_library() -> C.CDLL:
     lib.amber_hip_pt_kernel_time.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_double)]
     lib.amber_hip_pt_destroy.argtypes = [vp]
     lib.amber_hip_pt_destroy.restype = None
-    lib.amber_hip_lt_trace.argtypes = [vp, u32, u32, vp, u32, C.POINTER(u32), C.POINTER(u64)]
+    if hasattr(lib, "amber_hip_lt_trace"):     # absent only in older builds loaded by tools/ab_lib.py
+        lib.amber_hip_lt_trace.argtypes = [vp, u32, u32, vp, u32, C.POINTER(u32), C.POINTER(u64)]
     lib.amber_hip_kat_cast.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     lib.amber_hip_kat_sample.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     lib.amber_hip_kat_eye.argtypes = [vp, u32, vp, vp, vp]

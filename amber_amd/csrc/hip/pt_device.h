@@ -126,7 +126,7 @@ struct DevScene {
   float total_power;
   uint32_t n_objects;
   uint32_t max_depth;
-  DevLens lens;
+  const DevLens* __restrict__ lens;              // device memory, read with LoadLens() where a path starts / ends
   DevSensor sensor;
 };
 
@@ -746,10 +746,22 @@ __device__ __forceinline__ void GenerateLightRay(const DevScene& sc, uint64_t& r
   origin_slot = L->slot;
 }
 
+// The lens record (40 dwords) is needed once per path, not per bounce: it is read from constant memory next to its
+// use.  The empty asm makes the pointer opaque per use, otherwise the compiler hoists the 40 scalar loads out of the
+// persistent loop, keeps them live across the whole bounce loop and spills SGPRs to VGPR lanes in the hot code.
+__device__ __forceinline__ DevLens LoadLens(const DevScene& sc) {
+  ConstWords w = (ConstWords)(sc.lens);
+  asm volatile("" : "+s"(w));
+  union { DevLens lens; uint32_t words[sizeof(DevLens) / 4]; } u;
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(DevLens) / 4; ++k) u.words[k] = w[k];
+  return u.lens;
+}
+
 // Lens::Response for Ray(position, direction_out) (scene/scene.h:299-307, lens_thin.cc:109-130, lens_pinhole.cc:70-85,
 // Sensor::ResponsePixel sensor.cc:46-59).  Returns false when the ray does not reach the sensor.
 __device__ __forceinline__ bool LensResponse(const DevScene& sc, V3 position, V3 direction_out, uint32_t& pixel, float& value) {
-  const DevLens& L = sc.lens;
+  const DevLens L = LoadLens(sc);
   const V3 direction = MatMul(L.local_, direction_out);
   float sx, sy;
   if (L.kind == 1u) {
@@ -778,7 +790,7 @@ __device__ __forceinline__ bool LensResponse(const DevScene& sc, V3 position, V3
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void GenerateEyeRay(const DevScene& sc, uint32_t px, uint32_t py, uint64_t& rng,
                                                V3& origin, V3& dir, float& weight, int& origin_slot) {
-  const DevLens& L = sc.lens;
+  const DevLens L = LoadLens(sc);
   if (L.kind == 1u) {                                      // BasicPinhole::GenerateRay lens_pinhole.cc:48-68
     const float jy = Uniform(rng);
     const float jx = Uniform(rng);

@@ -64,7 +64,7 @@ struct RenderArgs {
 // place when a path ends, and stores the item's sum to partial[chunk][pixel]; reduce_partials_kernel adds the
 // chunks to the framebuffer in chunk order.  The summation order is therefore fixed.
 #ifndef AMBER_MEGAKERNEL_WAVES_PER_SIMD
-#define AMBER_MEGAKERNEL_WAVES_PER_SIMD 1   // no register cap: 93 VGPRs -> 5 waves/SIMD (6 would spill 8 dwords; measured slower/faster: DESIGN.md)
+#define AMBER_MEGAKERNEL_WAVES_PER_SIMD 6   // 80 VGPRs + 8 B scratch; in-process A/B on config 2: 5 waves (87 VGPRs) 48.8 ms, 6: 47.9, 7: 48.2, 8: 49.5
 #endif
 // kLight: the same worker loop traces LIGHT paths (algorithm_lt.cc:112-163): an item is (light path index, chunk of
 // passes), nothing is summed per item, Eye hits append splat records instead.
@@ -310,6 +310,7 @@ struct amber_hip_pt {
   unsigned int* d_next = nullptr;
   unsigned long long* d_stamps = nullptr;
   DevLight* d_lights = nullptr;
+  DevLens* d_lens = nullptr;
   DevSplat* d_splats = nullptr;
   unsigned int* d_splat_count = nullptr;
   uint32_t splat_capacity = 0;
@@ -530,27 +531,31 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.n_prog_tris = fprog.n_prog_tris; sc.always_mask = fprog.always_mask; sc.prog_objects = h->d_prog_objects;
   sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;
   h->n_materials = s->n_materials;
-  std::memcpy(sc.lens.origin, L.origin, sizeof L.origin);
-  std::memcpy(sc.lens.global_, L.global_, sizeof L.global_);
-  std::memcpy(sc.lens.local_, L.local_, sizeof L.local_);
-  sc.lens.focus_distance = L.focus_distance; sc.lens.sensor_distance = L.sensor_distance; sc.lens.p_area = L.p_area;
-  { volatile float q = -L.focus_distance / L.sensor_distance; sc.lens.neg_fd_over_sd = q; }
+  DevLens lens{};
+  std::memcpy(lens.origin, L.origin, sizeof L.origin);
+  std::memcpy(lens.global_, L.global_, sizeof L.global_);
+  std::memcpy(lens.local_, L.local_, sizeof L.local_);
+  lens.focus_distance = L.focus_distance; lens.sensor_distance = L.sensor_distance; lens.p_area = L.p_area;
+  { volatile float q = -L.focus_distance / L.sensor_distance; lens.neg_fd_over_sd = q; }
   {
     // sensor.Size() / sensor.SceneArea(): uint -> float, float*float, float/float (lens_thin.cc:145, sensor.cc:40-50)
     volatile float size_f = static_cast<float>(static_cast<uint64_t>(sensor->width) * sensor->height);
     volatile float area = sensor->scene_width * sensor->scene_height;
     volatile float r = size_f / area;
-    sc.lens.size_over_area = r;
+    lens.size_over_area = r;
   }
-  sc.lens.sd2 = static_cast<double>(L.sensor_distance) * static_cast<double>(L.sensor_distance);
-  sc.lens.n_blades = L.n_blades; sc.lens.n_blades_f = static_cast<float>(L.n_blades);
-  sc.lens.kind = L.kind;
-  { volatile float area = sensor->scene_width * sensor->scene_height; volatile float inv = 1.0f / area; sc.lens.inv_scene_area = inv; }
+  lens.sd2 = static_cast<double>(L.sensor_distance) * static_cast<double>(L.sensor_distance);
+  lens.n_blades = L.n_blades; lens.n_blades_f = static_cast<float>(L.n_blades);
+  lens.kind = L.kind;
+  { volatile float area = sensor->scene_width * sensor->scene_height; volatile float inv = 1.0f / area; lens.inv_scene_area = inv; }
   sc.sensor.w = sensor->width; sc.sensor.h = sensor->height;
   sc.sensor.wf = static_cast<float>(sensor->width); sc.sensor.hf = static_cast<float>(sensor->height);
   sc.sensor.sw = sensor->scene_width; sc.sensor.sh = sensor->scene_height;
   sc.sensor.size_f = static_cast<float>(static_cast<uint64_t>(sensor->width) * sensor->height);
-  { volatile float q = -L.sensor_distance / L.focus_distance; sc.lens.neg_sd_over_fd = q; }
+  { volatile float q = -L.sensor_distance / L.focus_distance; lens.neg_sd_over_fd = q; }
+  HIP_TRY_H(hipMalloc(&h->d_lens, sizeof(DevLens)));
+  HIP_TRY_H(hipMemcpy(h->d_lens, &lens, sizeof(DevLens), hipMemcpyHostToDevice));
+  sc.lens = h->d_lens;
   *out = h;
   return AMBER_OK;
 }
@@ -690,7 +695,7 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
     a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first_sample + done; a.n_samples = n;
     a.n_chunks = n_chunks; a.n_items = n_pixels * n_chunks;
     // persistent workers: 5 workgroups of 4 waves per CU (90 VGPRs -> 5 waves/SIMD), fewer if the queue is short
-    uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * 5u;
+    uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * (AMBER_MEGAKERNEL_WAVES_PER_SIMD > 5 ? AMBER_MEGAKERNEL_WAVES_PER_SIMD : 5u);
     const uint32_t by_work = (a.n_items + 255u) / 256u;
     if (by_work < n_blocks) n_blocks = by_work;
     HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
@@ -739,7 +744,7 @@ int amber_hip_lt_trace(amber_hip_pt* h, uint32_t first_sample, uint32_t n_sample
   a.splats = h->d_splats; a.splat_count = h->d_splat_count; a.splat_capacity = dev_capacity; a.hashed_seed = h->hashed_seed_lt;
   a.row_begin = 0; a.stripe_rows = 0; a.stripe_period = 0; a.n_pixels = n_paths; a.first_sample = first_sample; a.n_samples = n_samples;
   a.n_chunks = n_chunks; a.n_items = n_paths * n_chunks;
-  uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * 5u;
+  uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * (AMBER_MEGAKERNEL_WAVES_PER_SIMD > 5 ? AMBER_MEGAKERNEL_WAVES_PER_SIMD : 5u);
   const uint32_t by_work = (a.n_items + 255u) / 256u;
   if (by_work < n_blocks) n_blocks = by_work;
   if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
@@ -852,6 +857,7 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_next) (void)hipFree(h->d_next);
   if (h->d_stamps) (void)hipFree(h->d_stamps);
   if (h->d_lights) (void)hipFree(h->d_lights);
+  if (h->d_lens) (void)hipFree(h->d_lens);
   if (h->d_splats) (void)hipFree(h->d_splats);
   if (h->d_splat_count) (void)hipFree(h->d_splat_count);
   if (h->d_partial) (void)hipFree(h->d_partial);

@@ -1,8 +1,9 @@
-"""A/B of two builds of the library on config 2 in ONE process, interleaved rounds (cdna guide rule 24)."""
+"""A/B of two or more builds of the library on config 2 in ONE process, interleaved rounds (cdna guide rule 24)."""
 import ctypes as C, os, sys, time, statistics
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
-libs = sys.argv[1:3]; spp = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+libs = [a for a in sys.argv[1:] if a.endswith('.so')]
+spp = next((int(a) for a in sys.argv[1:] if a.isdigit()), 256)
 import amber_amd.api as api
 res = {}
 handles = {}
