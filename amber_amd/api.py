@@ -77,7 +77,7 @@ ABI_SYMBOLS = [
     "amber_hip_pt_download", "amber_hip_pt_device_framebuffer", "amber_hip_pt_local_rows", "amber_hip_pt_kernel_time", "amber_hip_pt_destroy",
     "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_device_count", "amber_hip_lt_trace",
     "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math",
-    "amber_host_cornell_box", "amber_host_scene_create", "amber_host_scene_destroy", "amber_host_scene_flatten",
+    "amber_host_cornell_box", "amber_host_scene_import", "amber_host_scene_create", "amber_host_scene_destroy", "amber_host_scene_flatten",
     "amber_host_pt_create", "amber_host_render", "amber_host_last_error", "amber_host_tonemap", "amber_host_export",
 ]
 
@@ -124,6 +124,8 @@ def load_library() -> C.CDLL:
     lib.amber_hip_kat_math.argtypes = [i32, i32, u32, vp, vp]
     lib.amber_host_cornell_box.restype = vp
     lib.amber_host_cornell_box.argtypes = [C.c_float, C.c_float, u32]
+    lib.amber_host_scene_import.restype = vp
+    lib.amber_host_scene_import.argtypes = [C.c_char_p]
     lib.amber_host_scene_create.restype = vp
     lib.amber_host_scene_create.argtypes = [C.POINTER(FlatObject), u32, C.POINTER(FlatMaterial), u32, C.POINTER(C.c_float),
                                             C.c_float, C.c_float, C.c_float, u32, C.c_int]   # n_blades == 0 selects the pinhole lens
@@ -168,6 +170,11 @@ class HostScene:
     def cornell_box(cls, focal_length: float = 0.050, aperture_radius: float = 0.050, n_blades: int = 6) -> "HostScene":
         """etude::CornelBox(0.050, 0.050, 6) -- application.cc:68-73."""
         return cls(load_library().amber_host_cornell_box(focal_length, aperture_radius, n_blades))
+
+    @classmethod
+    def import_file(cls, filename) -> "HostScene":
+        """cli::ImportScene(filename) + Scene::Create<BVH> (import.cc:49-167, application.cc:74-86); OBJ + MTL subset."""
+        return cls(load_library().amber_host_scene_import(str(filename).encode()))
 
     @classmethod
     def create(cls, objects, materials, transform, focal_length, focus_distance, radius, n_blades, accel: int = 0) -> "HostScene":

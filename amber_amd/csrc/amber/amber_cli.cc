@@ -5,7 +5,8 @@
 //   --algorithm pt|lt   --spp N (0 = until --time / SIGINT)   --width --height   --time SECONDS
 //   --output BASENAME (writes BASENAME.png tone-mapped and BASENAME.exr raw)   --threads (accepted, ignored)
 // plus --seed, --device, --max-depth, --engine of this implementation.  The scene is etude::CornelBox(0.050,
-// 0.050, 6) as in application.cc:68-73 (--scene needs assimp in the reference and is not supported here).
+// 0.050, 6) as in application.cc:68-73, or --scene FILE through cli::ImportScene (import.h: OBJ + MTL subset, the
+// reference reads it through assimp) built with the BVH acceleration (application.cc:74-87).
 // Render runs on a std::async thread while the main thread prints the reference's progress line every 500 ms;
 // SIGINT or the --time limit call Context::Expire(), a second SIGINT aborts (application.cc:132-147).
 #include <atomic>
@@ -21,6 +22,7 @@
 
 #include "postprocess.h"
 #include "rendering.h"
+#include "import.h"
 #include "scene.h"
 
 namespace {
@@ -75,11 +77,10 @@ int main(int argc, char** argv) {
   Option option;
   if (!Parse(argc, argv, option) || option.help) {
     std::cerr << "amber: a global illumination renderer (MI355X path tracer)\n"
-                 "  --algorithm pt  --spp N  --width W  --height H  --time S  --output NAME  [--threads N]\n"
+                 "  --algorithm pt  --spp N  --width W  --height H  --time S  --output NAME  [--threads N]  [--scene FILE.obj]\n"
                  "  [--seed N] [--device N] [--max-depth N] [--engine 0..4] [--samples-per-launch N]" << std::endl;
     return option.help ? 0 : -1;
   }
-  if (!option.scene.empty()) { std::cerr << "--scene is not supported (the reference imports through assimp)" << std::endl; return -1; }
   if (option.spp == 0 && option.time == 0) std::cerr << "note: --spp 0 without --time renders until SIGINT" << std::endl;
 
   rendering::HipPathTracingOptions hip;
@@ -92,7 +93,20 @@ int main(int argc, char** argv) {
     std::cerr << e.what() << std::endl;
     return -1;                                                         // application.cc:60-65
   }
-  const auto scene = etude::CornelBox(0.050f, 0.050f, 6);             // application.cc:68-73
+  std::unique_ptr<scene::RGBScene> scene_holder;
+  if (option.scene.empty()) {
+    scene_holder = std::make_unique<scene::RGBScene>(etude::CornelBox(0.050f, 0.050f, 6));   // application.cc:68-73
+  } else {
+    try {                                                              // application.cc:74-87
+      std::cerr << "Loading scene ... ";
+      scene_holder = std::make_unique<scene::RGBScene>(cli::ImportSceneBVH(option.scene));
+      std::cerr << "done." << std::endl;
+    } catch (const std::exception& e) {
+      std::cerr << std::endl << e.what() << std::endl;
+      return -1;
+    }
+  }
+  const scene::RGBScene& scene = *scene_holder;
   const rendering::Sensor sensor(option.width, option.height, static_cast<float>(0.036),
                                  static_cast<float>(0.036 / option.width * option.height));   // application.cc:89-94
 

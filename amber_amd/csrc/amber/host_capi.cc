@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../../../include/amber_host.h"
+#include "import.h"
 #include "postprocess.h"
 #include "rendering.h"
 #include "scene.h"
@@ -28,6 +29,13 @@ const char* amber_host_last_error(void) { return g_err.c_str(); }
 amber_host_scene* amber_host_cornell_box(float focal_length, float aperture_radius, uint32_t n_blades) {
   try {
     return new amber_host_scene(etude::CornelBox(focal_length, aperture_radius, n_blades));
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
+amber_host_scene* amber_host_scene_import(const char* filename) {
+  try {
+    if (!filename) { g_err = "null filename"; return nullptr; }
+    return new amber_host_scene(cli::ImportSceneBVH(filename));
   } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
 

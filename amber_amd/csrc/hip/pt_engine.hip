@@ -69,7 +69,7 @@ struct RenderArgs {
 // kLight: the same worker loop traces LIGHT paths (algorithm_lt.cc:112-163): an item is (light path index, chunk of
 // passes), nothing is summed per item, Eye hits append splat records instead.
 template <int kEngine, bool kLight = false>
-__global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megakernel(const RenderArgs a) {
+__global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 1 : AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megakernel(const RenderArgs a) {
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
   constexpr bool kTwoPhase = kEngine == ENGINE_TWO_PHASE;

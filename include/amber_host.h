@@ -22,6 +22,11 @@ typedef struct amber_host_scene amber_host_scene;
 /* etude::CornelBox(focal_length, aperture_radius, n_blades), cornel_box.cc:38-204 */
 amber_host_scene* amber_host_cornell_box(float focal_length, float aperture_radius, uint32_t n_blades);
 
+/* cli::ImportScene(filename) + Scene::Create<raytracer::BVH> (import.cc:49-167, application.cc:74-86): Wavefront
+ * OBJ + MTL subset with a "#camera" line (amber_amd/csrc/amber/import.h).  Returns NULL on error, e.g.
+ * "scene file has no cameras" (import.cc:132-134). */
+amber_host_scene* amber_host_scene_import(const char* filename);
+
 /* Generic scene through the Make* factories.  objects[i].p uses the AmberFlatObject layout WITHOUT
  * the triangle normal (the model computes it); materials[i].r0 is ignored (the model computes it).
  * The lens' aperture blades are inserted first, as cornel_box.cc:62-64 does.  accel: 0 = BVH, 1 = List.

@@ -937,7 +937,8 @@ oracle_scene* oracle_scene_create(const oracle_object* objects, uint32_t n_objec
                                   const oracle_material* materials, uint32_t n_materials,
                                   const oracle_thin_lens* lens, int accel) {
   auto* sc = new oracle_scene();
-  sc->accel = accel;
+  const bool blades_last = (accel & ORACLE_BLADES_LAST) != 0;             // cli::ImportScene order, import.cc:155-157
+  sc->accel = accel & 0xff;
   const Math M{ORACLE_MATH_LIBM};
   for (uint32_t i = 0; i < n_materials; i++) {
     Material m; m.kind = materials[i].kind; m.rho = v3(materials[i].rho[0], materials[i].rho[1], materials[i].rho[2]);
@@ -963,7 +964,7 @@ oracle_scene* oracle_scene_create(const oracle_object* objects, uint32_t n_objec
   } else {
     sc->lens = MakeThinLens(lens->transform, lens->focal_length, lens->focus_distance, lens->radius, lens->n_blades, eye_id, M);
   }
-  for (const Object& b : sc->lens.blades) sc->objects.push_back(b);     // cornel_box.cc:62-64
+  if (!blades_last) for (const Object& b : sc->lens.blades) sc->objects.push_back(b);     // cornel_box.cc:62-64
   for (uint32_t i = 0; i < n_objects; i++) {
     Object o; o.kind = objects[i].kind; o.material = objects[i].material;
     const float* p = objects[i].p;
@@ -974,6 +975,7 @@ oracle_scene* oracle_scene_create(const oracle_object* objects, uint32_t n_objec
     FinishObject(o);
     sc->objects.push_back(o);
   }
+  if (blades_last) for (const Object& b : sc->lens.blades) sc->objects.push_back(b);
   sc->Finish();
   return sc;
 }

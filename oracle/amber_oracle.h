@@ -61,6 +61,9 @@ typedef struct {
 
 /* modes */
 enum { ORACLE_ACCEL_BVH = 0, ORACLE_ACCEL_LIST = 1 };
+/* OR into `accel` of oracle_scene_create: append the aperture blades AFTER the objects, the order cli::ImportScene
+ * produces (import.cc:155-157); default is blades first (cornel_box.cc:62-64). */
+enum { ORACLE_BLADES_LAST = 0x100 };
 enum { ORACLE_MATH_LIBM = 0, ORACLE_MATH_PORTABLE = 1 };
 
 typedef struct oracle_scene oracle_scene;

@@ -14,6 +14,7 @@ ROOT = Path(__file__).resolve().parent.parent
 LIB = ROOT / "oracle" / "liboracle.so"
 
 ACCEL_BVH, ACCEL_LIST = 0, 1
+BLADES_LAST = 0x100          # ORACLE_BLADES_LAST: aperture blades after the objects (cli::ImportScene order)
 ACCUM_CHUNK = 8    # include/amber_hip.h AMBER_ACCUM_CHUNK
 MATH_LIBM, MATH_PORTABLE = 0, 1
 
