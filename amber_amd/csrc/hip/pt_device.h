@@ -473,73 +473,113 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
 // and the slab test ignores NaN axes (v_min/v_max return the non-NaN operand), so culling is conservative;
 // every object of a visited leaf gets the exact reference test with the (t, index) tie rule.  Result = List.
 #define AMBER_BVH_STACK 32
-__device__ __forceinline__ void SlabTest(const float* mn, const float* mx, V3 inv, V3 oi, float t_best, bool& hit, float& t_in) {
+__device__ __forceinline__ void SlabTest(const float* mn, const float* mx, V3 inv, V3 oi, float oi_mag, float t_best, bool& hit, float& t_in) {
   // (plane - o) / d as one FMA per plane: plane * inv - o * inv (oi = o * inv, once per ray).  Culling only has to be
   // conservative; the extra rounding of this form is covered by the slack below and the padded boxes.
+  // Axes the ray is parallel to arrive with inv = oi = NaN (BvhBegin): their planes are NaN and min/max skip them.
   const float x0 = __builtin_fmaf(mn[0], inv.x, -oi.x), x1 = __builtin_fmaf(mx[0], inv.x, -oi.x);
   const float y0 = __builtin_fmaf(mn[1], inv.y, -oi.y), y1 = __builtin_fmaf(mx[1], inv.y, -oi.y);
   const float z0 = __builtin_fmaf(mn[2], inv.z, -oi.z), z1 = __builtin_fmaf(mx[2], inv.z, -oi.z);
   float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
   float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-  // widen by a few ulps of the magnitudes involved: the slab arithmetic itself rounds
-  const float slack = 9.5367431640625e-07f * (__builtin_fmaxf(Abs(tn), Abs(tf)) + __builtin_fmaxf(__builtin_fmaxf(Abs(oi.x), Abs(oi.y)), Abs(oi.z)));
+  // widen by a few ulps of the magnitudes involved: the slab arithmetic itself rounds.  The slack must stay FINITE:
+  // with an infinite slack (oi_mag taken over an infinite oi, or |tn| = inf) tn - slack is -inf or NaN and every box
+  // of the tree "hits" -- an axis-parallel ray then walks all 2 M nodes (0.75 s for one lane, found on config 3).
+  const float slack = 9.5367431640625e-07f * __builtin_fminf(__builtin_fmaxf(Abs(tn), Abs(tf)) + oi_mag, 3.0e38f);
   tn -= slack; tf += slack;
   t_in = tn;
   hit = !(tn > tf) && !(tn > t_best);        // NaN anywhere -> treated as a hit
 }
 
-__device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, HitRec& best) {
+// Traversal state of one ray.  It lives in registers (+ the lane's LDS stack) so that a traversal can be suspended
+// while other lanes of the wave are shaded (pt_bvh_megakernel) and resumed afterwards.
+struct BvhTrav {
+  V3 inv, oi;          // 1/d and o/d (slab test operands)
+  float oi_mag;        // max |oi| over the axes where it is finite (rounding slack of the slab test)
+  int32_t cur;         // >= 0 inner node, < 0 leaf reference, kBvhDone finished
+  int sp;              // entries on the lane's stack
+  bool overflow;       // the stack was too small (cannot happen with the builder's depth cap): fall back to the list scan
+};
+#define AMBER_BVH_DONE 0x7fffffff
+
+__device__ __forceinline__ void BvhBegin(const DevScene& sc, V3 o, V3 d, BvhTrav& tr, HitRec& best) {
   best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;
-  const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  const V3 oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);   // inf * 0 = NaN on axis-parallel rays: that axis is then ignored (conservative)
+  tr.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  tr.oi = v3(o.x * tr.inv.x, o.y * tr.inv.y, o.z * tr.inv.z);
+  // An axis whose 1/d or o/d is not finite (d component 0 or denormal, huge origin) is taken OUT of the slab test by
+  // making both operands NaN: fma(plane, NaN, NaN) = NaN, which min/max skip.  Leaving +-inf in would not be
+  // conservative in the one-FMA form: for a box that contains the origin, plane*inf - o*inf is -inf for one plane
+  // and inf - inf = NaN for the other, and max(-inf, NaN) = -inf would cull the box.
+  {
+    const float kNaN = __builtin_nanf("");
+    if (!(Abs(tr.inv.x) < 3.0e38f) || !(Abs(tr.oi.x) < 3.0e38f)) { tr.inv.x = kNaN; tr.oi.x = kNaN; }
+    if (!(Abs(tr.inv.y) < 3.0e38f) || !(Abs(tr.oi.y) < 3.0e38f)) { tr.inv.y = kNaN; tr.oi.y = kNaN; }
+    if (!(Abs(tr.inv.z) < 3.0e38f) || !(Abs(tr.oi.z) < 3.0e38f)) { tr.inv.z = kNaN; tr.oi.z = kNaN; }
+    const float ax = Abs(tr.oi.x), ay = Abs(tr.oi.y), az = Abs(tr.oi.z);
+    tr.oi_mag = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);      // fmax skips the NaN axes; all NaN -> NaN -> slack clamps
+  }
+  // A ray with a NaN component cannot hit anything: every exact test forms dot products over all components of o and
+  // d, so every t it computes is NaN, and Closer() never accepts a NaN t (the List scan returns "no hit" too).  Such
+  // rays do occur (a handful per 1e7 paths in the 1M-sphere scene); without this exit the conservative slab test
+  // ("NaN -> visit") walks the ENTIRE tree for them -- one lane, 1.5 M steps, 0.75 s per launch.
+  const bool nan_ray = !(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z);
+  tr.cur = nan_ray ? AMBER_BVH_DONE : sc.bvh_root; tr.sp = 0; tr.overflow = false;
+}
+
+// One "while-while" round for this lane: descend through inner nodes until the lane holds a leaf (or runs out of
+// work), test the leaf's objects exactly, pop the next subtree.  Returns false when the traversal is complete.
+// The expensive exact tests of a wave thus run together instead of being interleaved with other lanes' box tests.
+__device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, BvhTrav& tr, HitRec& best) {
   int32_t* stack = lds_stack + threadIdx.x;          // element k at stack[k * blockDim.x]
   const uint32_t stride = blockDim.x;
-  int sp = 0;
-  bool overflow = false;
-  // "while-while" traversal: every lane first descends through inner nodes until it holds a leaf (or runs out of
-  // work), then all lanes of the wave test their leaves together -- the expensive exact tests run with as many lanes
-  // as possible instead of being interleaved with other lanes' box tests.
-  const int32_t kDone = 0x7fffffff;
-  int32_t cur = sc.bvh_root;
-  for (;;) {
-    while (cur >= 0 && cur != kDone) {
-      const DevBvhNode* nd = sc.bvh_nodes + cur;
-      const float4 a = *reinterpret_cast<const float4*>(nd->lmin), b = *reinterpret_cast<const float4*>(nd->lmax);
-      const float4 c = *reinterpret_cast<const float4*>(nd->rmin), e = *reinterpret_cast<const float4*>(nd->rmax);
-      const float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {b.x, b.y, b.z}, rmn[3] = {c.x, c.y, c.z}, rmx[3] = {e.x, e.y, e.z};
-      const int32_t left = __float_as_int(a.w), right = __float_as_int(c.w);
-      bool hl, hr; float tl, tr;
-      SlabTest(lmn, lmx, inv, oi, best.t, hl, tl);
-      SlabTest(rmn, rmx, inv, oi, best.t, hr, tr);
-      if (hl && hr) {
-        const bool left_first = !(tr < tl);
-        const int32_t near_ = left_first ? left : right, far_ = left_first ? right : left;
-        if (sp < AMBER_BVH_STACK) { stack[sp * stride] = far_; ++sp; }
-        else overflow = true;                          // cannot happen with the builder's depth cap; stay correct anyway
-        cur = near_;
-      } else if (hl) {
-        cur = left;
-      } else if (hr) {
-        cur = right;
-      } else if (sp > 0) {
-        --sp; cur = stack[sp * stride];
-      } else {
-        cur = kDone;
-      }
+  int32_t cur = tr.cur;
+  int sp = tr.sp;
+  while (cur >= 0 && cur != AMBER_BVH_DONE) {
+    const DevBvhNode* nd = sc.bvh_nodes + cur;
+    const float4 a = *reinterpret_cast<const float4*>(nd->lmin), b = *reinterpret_cast<const float4*>(nd->lmax);
+    const float4 c = *reinterpret_cast<const float4*>(nd->rmin), e = *reinterpret_cast<const float4*>(nd->rmax);
+    const float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {b.x, b.y, b.z}, rmn[3] = {c.x, c.y, c.z}, rmx[3] = {e.x, e.y, e.z};
+    const int32_t left = __float_as_int(a.w), right = __float_as_int(c.w);
+    bool hl, hr; float tl, tr_;
+    SlabTest(lmn, lmx, tr.inv, tr.oi, tr.oi_mag, best.t, hl, tl);
+    SlabTest(rmn, rmx, tr.inv, tr.oi, tr.oi_mag, best.t, hr, tr_);
+    if (hl && hr) {
+      const bool left_first = !(tr_ < tl);
+      const int32_t near_ = left_first ? left : right, far_ = left_first ? right : left;
+      if (sp < AMBER_BVH_STACK) { stack[sp * stride] = far_; ++sp; }
+      else tr.overflow = true;                         // stay correct anyway (list scan at the end)
+      cur = near_;
+    } else if (hl) {
+      cur = left;
+    } else if (hr) {
+      cur = right;
+    } else if (sp > 0) {
+      --sp; cur = stack[sp * stride];
+    } else {
+      cur = AMBER_BVH_DONE;
     }
-    if (cur == kDone) break;
-    {                                                  // cur < 0: a leaf
-      const uint32_t ref = static_cast<uint32_t>(-(cur + 1));
-      const uint32_t first = ref >> 3, count = ref & 7u;
-      for (uint32_t k = 0; k < count; ++k) {
-        const uint32_t oi = sc.bvh_prims[first + k];
-        const DevObject& ob = sc.objects[oi];
-        IntersectObject<true>(ob, ob.kind, static_cast<int>(oi), static_cast<int>(oi), o, d, best);
-      }
-    }
-    if (sp > 0) { --sp; cur = stack[sp * stride]; } else break;
   }
-  if (__any(overflow)) { if (overflow) ClosestHitList(sc, o, d, best); }
+  bool more = false;
+  if (cur != AMBER_BVH_DONE) {                         // cur < 0: a leaf
+    const uint32_t ref = static_cast<uint32_t>(-(cur + 1));
+    const uint32_t first = ref >> 3, count = ref & 7u;
+    for (uint32_t k = 0; k < count; ++k) {
+      const uint32_t oi = sc.bvh_prims[first + k];
+      const DevObject& ob = sc.objects[oi];
+      IntersectObject<true>(ob, ob.kind, static_cast<int>(oi), static_cast<int>(oi), o, d, best);
+    }
+    if (sp > 0) { --sp; cur = stack[sp * stride]; more = true; }
+    else cur = AMBER_BVH_DONE;
+  }
+  tr.cur = cur; tr.sp = sp;
+  return more;
+}
+
+__device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, HitRec& best) {
+  BvhTrav tr;
+  BvhBegin(sc, o, d, tr, best);
+  while (BvhRound(sc, lds_stack, o, d, tr, best)) {}
+  if (__any(tr.overflow)) { if (tr.overflow) ClosestHitList(sc, o, d, best); }
 }
 
 enum { ENGINE_LIST = 1, ENGINE_TWO_PHASE = 2, ENGINE_BVH = 3 };
@@ -843,11 +883,22 @@ struct Bounce { int object; float t; V3 pos; V3 weight_before; };
 // emitted radiance, and the material is sampled with SampleImportance.
 struct SplatSink { DevSplat* records; unsigned int* count; uint32_t capacity; uint32_t path, sample; float size_f; };
 
+template <bool kTrace, int kEngine, bool kLight>
+__device__ __forceinline__ bool PathShade(const DevScene& sc, const DevObject* lds_objects, const HitRec& h, V3& o, V3& d, V3& weight, V3& measurement,
+                                          uint64_t& rng, uint32_t& casts, int& origin_slot, Bounce* trace AMBER_STAMP_PARAM, const SplatSink* sink);
+
 template <bool kTrace, int kEngine, bool kLight = false>
 __device__ __forceinline__ bool PathStep(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3& o, V3& d, V3& weight, V3& measurement,
                                          uint64_t& rng, uint32_t& casts, int& origin_slot, Bounce* trace AMBER_STAMP_PARAM, const SplatSink* sink = nullptr) {
   HitRec h;
   ClosestHit<kEngine>(sc, lds_objects, lds_stack, o, d, origin_slot, h AMBER_STAMP_ARG);
+  return PathShade<kTrace, kEngine, kLight>(sc, lds_objects, h, o, d, weight, measurement, rng, casts, origin_slot, trace AMBER_STAMP_ARG, sink);
+}
+
+// Everything of a bounce after the closest-hit query (algorithm_pt.cc:140-157): h is the result of Scene::Cast.
+template <bool kTrace, int kEngine, bool kLight>
+__device__ __forceinline__ bool PathShade(const DevScene& sc, const DevObject* lds_objects, const HitRec& h, V3& o, V3& d, V3& weight, V3& measurement,
+                                          uint64_t& rng, uint32_t& casts, int& origin_slot, Bounce* trace AMBER_STAMP_PARAM, const SplatSink* sink) {
   casts++;
   if (h.idx < 0) {
     if (kTrace) { trace->object = -1; trace->t = __builtin_nanf(""); trace->pos = v3(0, 0, 0); trace->weight_before = v3(0, 0, 0); }

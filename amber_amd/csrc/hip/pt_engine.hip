@@ -1,11 +1,11 @@
 // pt_engine.hip -- kernels and C ABI (include/amber_hip.h) of the gfx950 path-tracing engine.
 //
-// Engine MEGAKERNEL (this file): one lane owns one pixel of the band and walks its samples in
-// order; a lane whose path ended regenerates the next (pixel, sample) eye ray in place, so every
-// loop iteration of a wave performs one closest-hit query for each lane that still has work
-// (path regeneration, persistent lanes).  Ray / throughput / sampler state never leaves VGPRs;
-// the 25-object Cornell scene is read with wave-uniform indices, i.e. through scalar loads into
-// SGPRs.  HBM traffic is the final 12 B/pixel read-modify-write of the framebuffer only.
+// Engine MEGAKERNEL (this file): persistent waves pull work items (pixel, chunk of 8 samples) from one global
+// queue; a lane whose path ended regenerates the next eye ray in place, so every loop iteration of a wave performs
+// one closest-hit query for each lane that still has work.  Ray / throughput / sampler state never leaves VGPRs;
+// scene records are read with wave-uniform indices through scalar loads (two-phase / list engines) or per lane
+// through a flattened BVH.  HBM traffic: one 12-byte item sum per (pixel, chunk), reduced into the framebuffer by
+// reduce_partials_kernel in chunk order.  wavefront.inc holds the streaming (SoA queues in HBM) formulation.
 //
 // Replaces: PathTracing<RGB>::Thread::operator() / Render
 //           (/root/reference/src/amber/rendering/algorithm_pt.cc:112-160).
@@ -170,6 +170,129 @@ __global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 1 : AMBER_MEGAKER
   if (lane == 0 && a.stamps) for (int k = 0; k < 8; k++) atomicAdd(a.stamps + k, stamp_ctx->acc[k]);
 #endif
   // one atomic per wave for the ray counter
+  unsigned long long r = rays;
+  for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
+  if (lane == 0 && r) atomicAdd(a.ray_count, r);
+}
+
+// Engine BVH worker.  Same work queue, item walk and accumulation order as pt_megakernel, but the closest-hit query
+// is a per-lane tree traversal whose length varies by an order of magnitude between the lanes of a wave (1M-sphere
+// scene: 24 % VALU lane utilisation when every bounce waits for the slowest lane).  Traversal is therefore
+// RESUMABLE (BvhTrav in registers, stack in LDS): the wave keeps running traversal rounds until
+// AMBER_BVH_SHADE_BATCH lanes have finished theirs (or nobody traverses any more), shades exactly those lanes --
+// hit resolution, material sampling, Russian roulette, regeneration -- starts their next rays and resumes.  Lanes
+// never wait for more than a batch to fill; results do not depend on the schedule (paths are independent and a
+// lane's samples are still summed in order).
+#ifndef AMBER_BVH_SHADE_BATCH
+#define AMBER_BVH_SHADE_BATCH 24
+#endif
+template <bool kLight>
+__global__ void __launch_bounds__(256) pt_bvh_megakernel(const RenderArgs a) {
+  const DevScene& sc = a.scene;
+  const uint32_t lane = threadIdx.x & 63u;
+  __shared__ int32_t lds_stack[AMBER_BVH_STACK * 256];
+
+  uint32_t pool_next = 0, pool_end = 0;
+  bool exhausted = false;
+  bool lane_done = false, have_item = false, alive = false, traversing = false;
+  uint32_t s = 0, s_end = 0, px = 0, py = 0, pixel = 0, slot = 0;
+  V3 sum = v3(0.f, 0.f, 0.f), meas = v3(0.f, 0.f, 0.f);
+  V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), w = v3(0.f, 0.f, 0.f);
+  uint64_t rng = 1;
+  uint32_t casts = 0, rays = 0;
+  int origin_slot = -1;
+  BvhTrav tr; tr.inv = v3(0.f, 0.f, 0.f); tr.oi = v3(0.f, 0.f, 0.f); tr.oi_mag = 0.f; tr.cur = AMBER_BVH_DONE; tr.sp = 0; tr.overflow = false;
+  HitRec hit; hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.idx = -1; hit.slot = -1;
+#ifdef AMBER_STAMPS
+  StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
+#endif
+
+  for (;;) {
+    bool need = !alive && s >= s_end && !lane_done;
+    if (need && have_item) {                                // item finished: publish its sum
+      if (!kLight) {
+        float* p = a.partial + static_cast<size_t>(slot) * 3u;
+        p[0] = sum.x; p[1] = sum.y; p[2] = sum.z;
+      }
+      have_item = false;
+    }
+    unsigned long long mask = __ballot(need);
+    while (mask) {                                          // hand out work items (see pt_megakernel)
+      const uint32_t avail = pool_end - pool_next;
+      if (avail == 0) {
+        if (exhausted) break;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.next_item, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= a.n_items) { exhausted = true; break; }
+        pool_next = base;
+        pool_end = base + 64u < a.n_items ? base + 64u : a.n_items;
+        continue;
+      }
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+      if (need && rank < avail) {
+        const uint32_t item = pool_next + rank;
+        const uint32_t plocal = item / a.n_chunks, chunk = item - plocal * a.n_chunks;
+        const uint32_t lrow = plocal / sc.sensor.w;
+        px = plocal - lrow * sc.sensor.w;
+        py = a.row_begin + (a.stripe_rows ? (lrow / a.stripe_rows) * a.stripe_period + lrow % a.stripe_rows : lrow);
+        pixel = px + py * sc.sensor.w;
+        slot = chunk * a.n_pixels + plocal;
+        s = a.first_sample + chunk * AMBER_ACCUM_CHUNK;
+        const uint32_t left = a.first_sample + a.n_samples - s;
+        s_end = s + (left < AMBER_ACCUM_CHUNK ? left : AMBER_ACCUM_CHUNK);
+        sum = v3(0.f, 0.f, 0.f);
+        have_item = true;
+        need = false;
+      }
+      const uint32_t wanted = static_cast<uint32_t>(__popcll(mask));
+      pool_next += wanted < avail ? wanted : avail;
+      mask = __ballot(need);
+    }
+    if (need) lane_done = true;
+    if (__ballot(!lane_done) == 0ull) break;
+
+    if (!alive && !lane_done) {                             // regenerate: next sample of the item, start its traversal
+      rng = XorShiftSeed(a.hashed_seed, pixel, s);
+      if (kLight) {
+        GenerateLightRay(sc, rng, o, d, w, origin_slot);
+      } else {
+        float ew;
+        GenerateEyeRay(sc, px, py, rng, o, d, ew, origin_slot);
+        w = v3(ew, ew, ew);
+      }
+      meas = v3(0.f, 0.f, 0.f);
+      casts = 0;
+      alive = true;
+      ++s;
+      BvhBegin(sc, o, d, tr, hit);
+      traversing = true;
+    }
+
+    for (;;) {                                              // traversal rounds until a batch of lanes is ready to shade
+      const unsigned long long tm = __ballot(traversing);
+      if (tm == 0ull) break;
+      if (__popcll(__ballot(alive && !traversing)) >= AMBER_BVH_SHADE_BATCH) break;
+      if (traversing) {
+        traversing = BvhRound(sc, lds_stack, o, d, tr, hit);
+        if (!traversing && tr.overflow) ClosestHitList(sc, o, d, hit);
+      }
+    }
+
+    if (alive && !traversing) {                             // shade the lanes whose closest hit is known
+      if (kLight) {
+        const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, pixel, s - 1u, sc.sensor.size_f};
+        alive = PathShade<false, ENGINE_BVH, true>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, &sink);
+      } else {
+        alive = PathShade<false, ENGINE_BVH, false>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, nullptr);
+      }
+      ++rays;
+      if (alive) { BvhBegin(sc, o, d, tr, hit); traversing = true; }
+      else sum = sum + meas;                                // sequential sum over the item's samples
+    }
+  }
+
   unsigned long long r = rays;
   for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
   if (lane == 0 && r) atomicAdd(a.ray_count, r);
@@ -349,6 +472,7 @@ struct DevBuf {
 int ValidateScene(const AmberFlatScene* s, const AmberSensor* sensor) {
   if (!s || !sensor) return Fail(AMBER_EINVAL, "null scene or sensor");
   if (!s->objects || s->n_objects == 0) return Fail(AMBER_EINVAL, "scene has no objects");
+  if (s->n_objects >= (1u << 28)) return Fail(AMBER_EINVAL, "too many objects (BVH leaf references hold 28-bit offsets)");
   if (!s->materials || s->n_materials == 0) return Fail(AMBER_EINVAL, "scene has no materials");
   if (sensor->width == 0 || sensor->height == 0) return Fail(AMBER_EINVAL, "empty sensor");
   if (static_cast<uint64_t>(sensor->width) * sensor->height >= (1ull << 32)) return Fail(AMBER_EINVAL, "sensor too large");
@@ -586,6 +710,12 @@ int AcquireEventPair(amber_hip_pt* h, std::pair<hipEvent_t, hipEvent_t>** out) {
 
 namespace {
 
+// Workgroups of pt_megakernel that fit a CU at once: the BVH instantiation needs 105 VGPRs and 32 KB of LDS for its
+// traversal stacks (4 waves/SIMD); the others are capped to AMBER_MEGAKERNEL_WAVES_PER_SIMD by their launch bounds.
+uint32_t ResidentBlocksPerCu(uint32_t hit_engine) {
+  return hit_engine == AMBER_ENGINE_BVH ? 4u : (AMBER_MEGAKERNEL_WAVES_PER_SIMD > 5 ? static_cast<uint32_t>(AMBER_MEGAKERNEL_WAVES_PER_SIMD) : 5u);   // uncapped: 87 VGPRs -> 5
+}
+
 // Engine WAVEFRONT host loop: batches of <= max_chunks accumulation chunks; per batch generate, then bounce launches
 // until the live-ray count read back from the device is zero, then the ordered reduction into the framebuffer.
 int RenderPassWavefront(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples) {
@@ -694,8 +824,8 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
     a.scene = h->scene; a.partial = h->d_partial; a.ray_count = h->d_rays; a.next_item = h->d_next; a.stamps = h->d_stamps; a.splats = nullptr; a.splat_count = nullptr; a.splat_capacity = 0; a.hashed_seed = h->hashed_seed;
     a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first_sample + done; a.n_samples = n;
     a.n_chunks = n_chunks; a.n_items = n_pixels * n_chunks;
-    // persistent workers: 5 workgroups of 4 waves per CU (90 VGPRs -> 5 waves/SIMD), fewer if the queue is short
-    uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * (AMBER_MEGAKERNEL_WAVES_PER_SIMD > 5 ? AMBER_MEGAKERNEL_WAVES_PER_SIMD : 5u);
+    // persistent workers: one workgroup of 4 waves per CU and resident wave slot, fewer if the queue is short
+    uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine);
     const uint32_t by_work = (a.n_items + 255u) / 256u;
     if (by_work < n_blocks) n_blocks = by_work;
     HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
@@ -704,7 +834,7 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
     auto& ev = *evp;
     HIP_TRY(hipEventRecord(ev.first, h->stream));
     if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(pt_megakernel<ENGINE_TWO_PHASE>, dim3(n_blocks), dim3(256), 0, h->stream, a);
-    else if (h->hit_engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(pt_megakernel<ENGINE_BVH>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else if (h->hit_engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(pt_bvh_megakernel<false>, dim3(n_blocks), dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL(pt_megakernel<ENGINE_LIST>, dim3(n_blocks), dim3(256), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, h->stream));
@@ -744,11 +874,11 @@ int amber_hip_lt_trace(amber_hip_pt* h, uint32_t first_sample, uint32_t n_sample
   a.splats = h->d_splats; a.splat_count = h->d_splat_count; a.splat_capacity = dev_capacity; a.hashed_seed = h->hashed_seed_lt;
   a.row_begin = 0; a.stripe_rows = 0; a.stripe_period = 0; a.n_pixels = n_paths; a.first_sample = first_sample; a.n_samples = n_samples;
   a.n_chunks = n_chunks; a.n_items = n_paths * n_chunks;
-  uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * (AMBER_MEGAKERNEL_WAVES_PER_SIMD > 5 ? AMBER_MEGAKERNEL_WAVES_PER_SIMD : 5u);
+  uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine);
   const uint32_t by_work = (a.n_items + 255u) / 256u;
   if (by_work < n_blocks) n_blocks = by_work;
   if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
-  else if (h->hit_engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL((pt_megakernel<ENGINE_BVH, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+  else if (h->hit_engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(pt_bvh_megakernel<true>, dim3(n_blocks), dim3(256), 0, h->stream, a);
   else hipLaunchKernelGGL((pt_megakernel<ENGINE_LIST, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
   unsigned int produced = 0;
