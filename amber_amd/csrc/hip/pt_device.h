@@ -120,6 +120,7 @@ struct DevScene {
   const DevObject* __restrict__ prog_objects;   // objects in program order, kind |= scene index << 8 (staged to LDS)
   const DevBvhNode* __restrict__ bvh_nodes;     // engine BVH
   const uint32_t* __restrict__ bvh_prims;       // leaf order -> object index
+  const DevObject* __restrict__ bvh_objects;    // the object records in leaf order (HitRec.slot of engine BVH indexes this array)
   int32_t bvh_root;                             // child reference of the whole scene
   const DevLight* __restrict__ lights;          // light tracing
   uint32_t n_lights;
@@ -472,7 +473,9 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
 // stack held in LDS (layout [level][thread]: conflict-free for ds_read/write_b32).  Boxes are padded on the host
 // and the slab test ignores NaN axes (v_min/v_max return the non-NaN operand), so culling is conservative;
 // every object of a visited leaf gets the exact reference test with the (t, index) tie rule.  Result = List.
+#ifndef AMBER_BVH_STACK
 #define AMBER_BVH_STACK 32
+#endif
 __device__ __forceinline__ void SlabTest(const float* mn, const float* mx, V3 inv, V3 oi, float oi_mag, float t_best, bool& hit, float& t_in) {
   // (plane - o) / d as one FMA per plane: plane * inv - o * inv (oi = o * inv, once per ray).  Culling only has to be
   // conservative; the extra rounding of this form is covered by the slack below and the padded boxes.
@@ -489,6 +492,16 @@ __device__ __forceinline__ void SlabTest(const float* mn, const float* mx, V3 in
   tn -= slack; tf += slack;
   t_in = tn;
   hit = !(tn > tf) && !(tn > t_best);        // NaN anywhere -> treated as a hit
+}
+
+// Fallback of engine BVH (traversal stack overflow; cannot happen with the builder's depth cap): scan the leaf-order
+// array.  The (t, scene index) tie rule makes the visiting order irrelevant, so this equals ClosestHitList.
+__device__ __forceinline__ void ClosestHitLeafList(const DevScene& sc, V3 o, V3 d, HitRec& best) {
+  best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;
+  for (uint32_t k = 0; k < sc.n_objects; ++k) {
+    const DevObject& ob = sc.bvh_objects[k];
+    IntersectObject<true>(ob, ob.kind, static_cast<int>(sc.bvh_prims[k]), static_cast<int>(k), o, d, best);
+  }
 }
 
 // Traversal state of one ray.  It lives in registers (+ the lane's LDS stack) so that a traversal can be suspended
@@ -529,7 +542,7 @@ __device__ __forceinline__ void BvhBegin(const DevScene& sc, V3 o, V3 d, BvhTrav
 // One "while-while" round for this lane: descend through inner nodes until the lane holds a leaf (or runs out of
 // work), test the leaf's objects exactly, pop the next subtree.  Returns false when the traversal is complete.
 // The expensive exact tests of a wave thus run together instead of being interleaved with other lanes' box tests.
-__device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, BvhTrav& tr, HitRec& best) {
+__device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, BvhTrav& tr, HitRec& best, const int stack_cap = AMBER_BVH_STACK) {
   int32_t* stack = lds_stack + threadIdx.x;          // element k at stack[k * blockDim.x]
   const uint32_t stride = blockDim.x;
   int32_t cur = tr.cur;
@@ -546,7 +559,7 @@ __device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack,
     if (hl && hr) {
       const bool left_first = !(tr_ < tl);
       const int32_t near_ = left_first ? left : right, far_ = left_first ? right : left;
-      if (sp < AMBER_BVH_STACK) { stack[sp * stride] = far_; ++sp; }
+      if (sp < stack_cap) { stack[sp * stride] = far_; ++sp; }
       else tr.overflow = true;                         // stay correct anyway (list scan at the end)
       cur = near_;
     } else if (hl) {
@@ -564,9 +577,9 @@ __device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack,
     const uint32_t ref = static_cast<uint32_t>(-(cur + 1));
     const uint32_t first = ref >> 3, count = ref & 7u;
     for (uint32_t k = 0; k < count; ++k) {
-      const uint32_t oi = sc.bvh_prims[first + k];
-      const DevObject& ob = sc.objects[oi];
-      IntersectObject<true>(ob, ob.kind, static_cast<int>(oi), static_cast<int>(oi), o, d, best);
+      const uint32_t oi = sc.bvh_prims[first + k];                 // scene index (tie rule, reported hit); independent of ...
+      const DevObject& ob = sc.bvh_objects[first + k];             // ... the record itself, stored in leaf order: no dependent load
+      IntersectObject<true>(ob, ob.kind, static_cast<int>(oi), static_cast<int>(first + k), o, d, best);
     }
     if (sp > 0) { --sp; cur = stack[sp * stride]; more = true; }
     else cur = AMBER_BVH_DONE;
@@ -579,7 +592,7 @@ __device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_s
   BvhTrav tr;
   BvhBegin(sc, o, d, tr, best);
   while (BvhRound(sc, lds_stack, o, d, tr, best)) {}
-  if (__any(tr.overflow)) { if (tr.overflow) ClosestHitList(sc, o, d, best); }
+  if (__any(tr.overflow)) { if (tr.overflow) ClosestHitLeafList(sc, o, d, best); }
 }
 
 enum { ENGINE_LIST = 1, ENGINE_TWO_PHASE = 2, ENGINE_BVH = 3 };
@@ -905,7 +918,7 @@ __device__ __forceinline__ bool PathShade(const DevScene& sc, const DevObject* l
     return false;
   }
   V3 pos, normal; uint32_t mat;
-  ResolveHit(kEngine == ENGINE_TWO_PHASE ? lds_objects : sc.objects, h, o, d, pos, normal, mat);
+  ResolveHit(kEngine == ENGINE_TWO_PHASE ? lds_objects : (kEngine == ENGINE_BVH ? sc.bvh_objects : sc.objects), h, o, d, pos, normal, mat);
   const DevMaterial m = sc.materials[mat];
   const V3 dir_out = -d;
   if (kTrace) { trace->object = h.idx; trace->t = h.t; trace->pos = pos; trace->weight_before = weight; }

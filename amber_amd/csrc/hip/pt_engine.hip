@@ -184,13 +184,15 @@ __global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 1 : AMBER_MEGAKER
 // never wait for more than a batch to fill; results do not depend on the schedule (paths are independent and a
 // lane's samples are still summed in order).
 #ifndef AMBER_BVH_SHADE_BATCH
-#define AMBER_BVH_SHADE_BATCH 24
+#define AMBER_BVH_SHADE_BATCH 40   // config 3 at 128 spp, one process: 8 -> 241 ms, 16 -> 220, 24 -> 213, 40 -> 209, 64 (wait for all lanes) -> 238
 #endif
-template <bool kLight>
-__global__ void __launch_bounds__(256) pt_bvh_megakernel(const RenderArgs a) {
+// kStack: entries of the per-lane LDS stack (chosen from the tree depth at create time).  24 entries = 24 KB per
+// workgroup let 5 workgroups share a CU (96 VGPRs), 32 entries only 4: config 3, 128 spp: 193 vs 208 ms.
+template <bool kLight, int kStack>
+__global__ void __launch_bounds__(256, kStack <= 24 ? 5 : 4) pt_bvh_megakernel(const RenderArgs a) {
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
-  __shared__ int32_t lds_stack[AMBER_BVH_STACK * 256];
+  __shared__ int32_t lds_stack[kStack * 256];
 
   uint32_t pool_next = 0, pool_end = 0;
   bool exhausted = false;
@@ -275,8 +277,8 @@ __global__ void __launch_bounds__(256) pt_bvh_megakernel(const RenderArgs a) {
       if (tm == 0ull) break;
       if (__popcll(__ballot(alive && !traversing)) >= AMBER_BVH_SHADE_BATCH) break;
       if (traversing) {
-        traversing = BvhRound(sc, lds_stack, o, d, tr, hit);
-        if (!traversing && tr.overflow) ClosestHitList(sc, o, d, hit);
+        traversing = BvhRound(sc, lds_stack, o, d, tr, hit, kStack);
+        if (!traversing && tr.overflow) ClosestHitLeafList(sc, o, d, hit);
       }
     }
 
@@ -335,7 +337,7 @@ __global__ void kat_cast_kernel(const DevScene sc, uint32_t n, const float* org,
     return;
   }
   V3 pos, nrm; uint32_t mat;
-  ResolveHit(kEngine == ENGINE_TWO_PHASE ? lds_objects : sc.objects, h, o, d, pos, nrm, mat);
+  ResolveHit(kEngine == ENGINE_TWO_PHASE ? lds_objects : (kEngine == ENGINE_BVH ? sc.bvh_objects : sc.objects), h, o, d, pos, nrm, mat);
   out_t[i] = h.t;
   out_pos[3 * i] = pos.x; out_pos[3 * i + 1] = pos.y; out_pos[3 * i + 2] = pos.z;
   out_n[3 * i] = nrm.x; out_n[3 * i + 1] = nrm.y; out_n[3 * i + 2] = nrm.z;
@@ -427,7 +429,9 @@ struct amber_hip_pt {
   DevObject* d_prog_objects = nullptr;
   DevBvhNode* d_bvh_nodes = nullptr;
   uint32_t* d_bvh_prims = nullptr;
+  DevObject* d_bvh_objects = nullptr;
   bool two_phase = false;
+  uint32_t bvh_depth = 0;                   // depth of the flattened tree (selects the traversal-stack size)
   float* d_fb = nullptr;
   unsigned long long* d_rays = nullptr;
   unsigned int* d_next = nullptr;
@@ -587,6 +591,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   if (h->hit_engine == AMBER_ENGINE_BVH) {
     bvh = amber_bvh::BuildBvh(objs);
     if (bvh.depth > static_cast<uint32_t>(amber_bvh::kMaxDepth)) { delete h; return Fail(AMBER_EINVAL, "BVH deeper than the device stack"); }
+    h->bvh_depth = bvh.depth;
   }
   amber_filter::FilterProgram fprog;
   if (h->two_phase) amber_filter::BuildFilterProgram(objs, fprog);
@@ -630,6 +635,12 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMalloc(&h->d_bvh_prims, (bvh.prim_index.size() + 1) * sizeof(uint32_t)));
   if (!bvh.nodes.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(DevBvhNode), hipMemcpyHostToDevice));
   if (!bvh.prim_index.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_prims, bvh.prim_index.data(), bvh.prim_index.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  {
+    std::vector<DevObject> leaf_order(bvh.prim_index.size());
+    for (size_t k = 0; k < leaf_order.size(); k++) leaf_order[k] = objs[bvh.prim_index[k]];
+    HIP_TRY_H(hipMalloc(&h->d_bvh_objects, (leaf_order.size() + 1) * sizeof(DevObject)));
+    if (!leaf_order.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_objects, leaf_order.data(), leaf_order.size() * sizeof(DevObject), hipMemcpyHostToDevice));
+  }
   if (!fprog.spheres.empty()) HIP_TRY_H(hipMemcpy(h->d_sphere_filters, fprog.spheres.data(), fprog.spheres.size() * sizeof(DevSphereFilter), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_objects, objs.data(), objs.size() * sizeof(DevObject), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
@@ -650,7 +661,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades;
   sc.planes = h->d_planes; sc.tri_filters = h->d_tri_filters; sc.sphere_filters = h->d_sphere_filters;
   sc.n_planes = static_cast<uint32_t>(fprog.planes.size()); sc.n_sphere_filters = static_cast<uint32_t>(fprog.spheres.size());
-  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_prims = h->d_bvh_prims; sc.bvh_root = bvh.root_ref;
+  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_root = bvh.root_ref;
   sc.lights = h->d_lights; sc.n_lights = s->n_lights; sc.total_power = s->n_lights ? s->lights[s->n_lights - 1].cum_power : 0.0f;
   sc.n_prog_tris = fprog.n_prog_tris; sc.always_mask = fprog.always_mask; sc.prog_objects = h->d_prog_objects;
   sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;
@@ -710,10 +721,10 @@ int AcquireEventPair(amber_hip_pt* h, std::pair<hipEvent_t, hipEvent_t>** out) {
 
 namespace {
 
-// Workgroups of pt_megakernel that fit a CU at once: the BVH instantiation needs 105 VGPRs and 32 KB of LDS for its
-// traversal stacks (4 waves/SIMD); the others are capped to AMBER_MEGAKERNEL_WAVES_PER_SIMD by their launch bounds.
-uint32_t ResidentBlocksPerCu(uint32_t hit_engine) {
-  return hit_engine == AMBER_ENGINE_BVH ? 4u : (AMBER_MEGAKERNEL_WAVES_PER_SIMD > 5 ? static_cast<uint32_t>(AMBER_MEGAKERNEL_WAVES_PER_SIMD) : 5u);   // uncapped: 87 VGPRs -> 5
+// Workgroups of the persistent kernels that fit a CU at once: pt_bvh_megakernel is bounded by its LDS traversal stacks
+// and VGPRs (5 with 24-entry stacks, else 4); the others are capped to AMBER_MEGAKERNEL_WAVES_PER_SIMD by their launch bounds.
+uint32_t ResidentBlocksPerCu(uint32_t hit_engine, uint32_t bvh_depth) {
+  return hit_engine == AMBER_ENGINE_BVH ? (bvh_depth <= 24 ? 5u : 4u) : (AMBER_MEGAKERNEL_WAVES_PER_SIMD > 5 ? static_cast<uint32_t>(AMBER_MEGAKERNEL_WAVES_PER_SIMD) : 5u);   // uncapped: 87 VGPRs -> 5
 }
 
 // Engine WAVEFRONT host loop: batches of <= max_chunks accumulation chunks; per batch generate, then bounce launches
@@ -825,7 +836,7 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
     a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first_sample + done; a.n_samples = n;
     a.n_chunks = n_chunks; a.n_items = n_pixels * n_chunks;
     // persistent workers: one workgroup of 4 waves per CU and resident wave slot, fewer if the queue is short
-    uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine);
+    uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth);
     const uint32_t by_work = (a.n_items + 255u) / 256u;
     if (by_work < n_blocks) n_blocks = by_work;
     HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
@@ -834,7 +845,10 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
     auto& ev = *evp;
     HIP_TRY(hipEventRecord(ev.first, h->stream));
     if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(pt_megakernel<ENGINE_TWO_PHASE>, dim3(n_blocks), dim3(256), 0, h->stream, a);
-    else if (h->hit_engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(pt_bvh_megakernel<false>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else if (h->hit_engine == AMBER_ENGINE_BVH) {
+      if (h->bvh_depth <= 24) hipLaunchKernelGGL((pt_bvh_megakernel<false, 24>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+      else hipLaunchKernelGGL((pt_bvh_megakernel<false, AMBER_BVH_STACK>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    }
     else hipLaunchKernelGGL(pt_megakernel<ENGINE_LIST>, dim3(n_blocks), dim3(256), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, h->stream));
@@ -874,11 +888,14 @@ int amber_hip_lt_trace(amber_hip_pt* h, uint32_t first_sample, uint32_t n_sample
   a.splats = h->d_splats; a.splat_count = h->d_splat_count; a.splat_capacity = dev_capacity; a.hashed_seed = h->hashed_seed_lt;
   a.row_begin = 0; a.stripe_rows = 0; a.stripe_period = 0; a.n_pixels = n_paths; a.first_sample = first_sample; a.n_samples = n_samples;
   a.n_chunks = n_chunks; a.n_items = n_paths * n_chunks;
-  uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine);
+  uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth);
   const uint32_t by_work = (a.n_items + 255u) / 256u;
   if (by_work < n_blocks) n_blocks = by_work;
   if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
-  else if (h->hit_engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(pt_bvh_megakernel<true>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+  else if (h->hit_engine == AMBER_ENGINE_BVH) {
+    if (h->bvh_depth <= 24) hipLaunchKernelGGL((pt_bvh_megakernel<true, 24>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL((pt_bvh_megakernel<true, AMBER_BVH_STACK>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+  }
   else hipLaunchKernelGGL((pt_megakernel<ENGINE_LIST, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
   unsigned int produced = 0;
@@ -981,6 +998,7 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_prog_objects) (void)hipFree(h->d_prog_objects);
   if (h->d_bvh_nodes) (void)hipFree(h->d_bvh_nodes);
   if (h->d_bvh_prims) (void)hipFree(h->d_bvh_prims);
+  if (h->d_bvh_objects) (void)hipFree(h->d_bvh_objects);
   if (h->d_wf) (void)hipFree(h->d_wf);
   if (h->d_fb) (void)hipFree(h->d_fb);
   if (h->d_rays) (void)hipFree(h->d_rays);
