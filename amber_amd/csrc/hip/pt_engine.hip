@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 1 : AMBER_MEGAKER
 // never wait for more than a batch to fill; results do not depend on the schedule (paths are independent and a
 // lane's samples are still summed in order).
 #ifndef AMBER_BVH_SHADE_BATCH
-#define AMBER_BVH_SHADE_BATCH 40   // config 3 at 128 spp, one process: 8 -> 241 ms, 16 -> 220, 24 -> 213, 40 -> 209, 64 (wait for all lanes) -> 238
+#define AMBER_BVH_SHADE_BATCH 52   // config 3 at 128 spp, one process (descent budget 5): 24 -> 173 ms, 32 -> 172, 40 -> 166, 48 -> 162, 52 -> 160, 56 -> 160.5, 60 -> 164, 64 (wait for all lanes) -> 181
 #endif
 // kStack: entries of the per-lane LDS stack (chosen from the tree depth at create time).  24 entries = 24 KB per
 // workgroup let 5 workgroups share a CU (96 VGPRs), 32 entries only 4: config 3, 128 spp: 193 vs 208 ms.
