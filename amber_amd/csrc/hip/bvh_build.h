@@ -4,7 +4,7 @@
 // pointer tree of unique_ptr<Node>, recursive Cast) with a builder designed for the GPU side:
 //   * binned SAH (16 bins per axis over the CENTROID bounds, O(N log N)) instead of the reference's
 //     3 sorts + 15 candidate planes per node (26.6 s for 1M spheres);
-//   * a flat array of 64-byte 2-wide nodes: a node stores BOTH children's boxes, so one 64-byte fetch decides
+//   * a flat array of 64-byte 2-wide nodes (planes grouped for packed FMAs): a node stores BOTH children's boxes, so one 64-byte fetch decides
 //     both subtrees (the reference also tests both children at the parent, acceleration_bvh.h:360-372);
 //   * leaves of up to kLeafSize objects referenced through a permutation array;
 //   * depth capped (kMaxDepth) so that the per-lane traversal stack fits a fixed LDS allocation.
@@ -28,7 +28,10 @@ namespace amber_bvh {
 using amber_dev::DevBvhNode;
 using amber_dev::DevObject;
 
-constexpr int kLeafSize = 4;
+#ifndef AMBER_BVH_LEAF_SIZE
+#define AMBER_BVH_LEAF_SIZE 3   // config 3 at 128 spp: 2 -> 151.5 ms, 3 -> 151.1, 4 -> 157.9, 6 -> 173.6
+#endif
+constexpr int kLeafSize = AMBER_BVH_LEAF_SIZE;   // <= 7 (leaf references hold a 3-bit count)
 constexpr int kMaxDepth = 30;     // device stack holds 32 entries
 constexpr int kBins = 16;
 
@@ -159,7 +162,9 @@ struct Builder {
     const int32_t r = Build(mid, last, depth + 1, rb);
     PadBox(lb, extent); PadBox(rb, extent);
     DevBvhNode& nd = nodes[me];
-    for (int c = 0; c < 3; c++) { nd.lmin[c] = lb.mn[c]; nd.lmax[c] = lb.mx[c]; nd.rmin[c] = rb.mn[c]; nd.rmax[c] = rb.mx[c]; }
+    nd.lxy[0] = lb.mn[0]; nd.lxy[1] = lb.mn[1]; nd.lxy[2] = lb.mx[0]; nd.lxy[3] = lb.mx[1];
+    nd.rxy[0] = rb.mn[0]; nd.rxy[1] = rb.mn[1]; nd.rxy[2] = rb.mx[0]; nd.rxy[3] = rb.mx[1];
+    nd.z[0] = lb.mn[2]; nd.z[1] = lb.mx[2]; nd.z[2] = rb.mn[2]; nd.z[3] = rb.mx[2];
     nd.left = l; nd.right = r; nd.pad0 = 0; nd.pad1 = 0;
     return static_cast<int32_t>(me);
   }

@@ -72,11 +72,13 @@ struct alignas(16) DevSphereFilter { // 32 B
 };
 // Flattened 2-wide BVH node (engine BVH, bvh_build.h): both children's (padded) boxes live in the parent.
 // Child reference: >= 0 inner node index; < 0 leaf: -(ref+1) = first*8 + count into prim_index (count <= 7).
+// The planes are grouped so that the slab test runs on packed FMAs (v_pk_fma_f32): (x, y) pairs of every corner
+// against (1/d.x, 1/d.y), and the four z planes in two pairs against (1/d.z, 1/d.z).
 struct alignas(16) DevBvhNode {   // 64 B
-  float lmin[3]; int32_t left;
-  float lmax[3]; int32_t pad0;
-  float rmin[3]; int32_t right;
-  float rmax[3]; int32_t pad1;
+  float lxy[4];                   // left child:  min.x min.y max.x max.y
+  float rxy[4];                   // right child: min.x min.y max.x max.y
+  float z[4];                     // left min.z, left max.z, right min.z, right max.z
+  int32_t left, right, pad0, pad1;
 };
 // Light-tracing source record: one per DiffuseLight object, sorted by power (scene/light_set.h:61-82).
 struct alignas(16) DevLight {     // 96 B
@@ -476,22 +478,26 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
 #ifndef AMBER_BVH_STACK
 #define AMBER_BVH_STACK 32
 #endif
-__device__ __forceinline__ void SlabTest(const float* mn, const float* mx, V3 inv, V3 oi, float oi_mag, float t_best, bool& hit, float& t_in) {
-  // (plane - o) / d as one FMA per plane: plane * inv - o * inv (oi = o * inv, once per ray).  Culling only has to be
-  // conservative; the extra rounding of this form is covered by the slack below and the padded boxes.
-  // Axes the ray is parallel to arrive with inv = oi = NaN (BvhBegin): their planes are NaN and min/max skip them.
-  const float x0 = __builtin_fmaf(mn[0], inv.x, -oi.x), x1 = __builtin_fmaf(mx[0], inv.x, -oi.x);
-  const float y0 = __builtin_fmaf(mn[1], inv.y, -oi.y), y1 = __builtin_fmaf(mx[1], inv.y, -oi.y);
-  const float z0 = __builtin_fmaf(mn[2], inv.z, -oi.z), z1 = __builtin_fmaf(mx[2], inv.z, -oi.z);
+// Packed FMAs (v_pk_fma_f32) save 6 of ~45 VALU instructions per node but cost two more live registers: at the 96-VGPR
+// cap of pt_bvh_megakernel that is 32 B of scratch instead of 16 B, and config 3 runs 1.7 % slower (159.3 vs 156.6 ms).
+#ifndef AMBER_BVH_PACKED
+#define AMBER_BVH_PACKED 0
+#endif
+typedef float F2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ F2 f2(float x, float y) { F2 r = {x, y}; return r; }
+
+// Slab test of one child box from its six plane parameters t = (plane - o) / d, computed by the caller as one FMA per
+// plane, plane * inv - o * inv (packed).  Culling only has to be conservative; the extra rounding of the FMA form is
+// covered by the slack and by the padded boxes: the entry is lowered and the exit raised by 2^-20 of their own
+// magnitude plus slack_abs = 2^-20 * max|o/d| (a bound on the absolute error inherited from o/d).  Axes the ray is
+// parallel to arrive as NaN planes (BvhBegin) and min/max skip them.  NaN anywhere -> treated as a hit.
+__device__ __forceinline__ void SlabDecide(float x0, float x1, float y0, float y1, float z0, float z1, float slack_abs, float t_best, bool& hit, float& t_in) {
   float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
   float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-  // widen by a few ulps of the magnitudes involved: the slab arithmetic itself rounds.  The slack must stay FINITE:
-  // with an infinite slack (oi_mag taken over an infinite oi, or |tn| = inf) tn - slack is -inf or NaN and every box
-  // of the tree "hits" -- an axis-parallel ray then walks all 2 M nodes (0.75 s for one lane, found on config 3).
-  const float slack = 9.5367431640625e-07f * __builtin_fminf(__builtin_fmaxf(Abs(tn), Abs(tf)) + oi_mag, 3.0e38f);
-  tn -= slack; tf += slack;
+  tn = __builtin_fmaf(tn, -9.5367431640625e-07f, tn - slack_abs);            // tn >= 0
+  tf = __builtin_fmaf(Abs(tf), 9.5367431640625e-07f, tf + slack_abs);
   t_in = tn;
-  hit = !(tn > tf) && !(tn > t_best);        // NaN anywhere -> treated as a hit
+  hit = !(tn > tf) && !(tn > t_best);
 }
 
 // Fallback of engine BVH (traversal stack overflow; cannot happen with the builder's depth cap): scan the leaf-order
@@ -507,8 +513,9 @@ __device__ __forceinline__ void ClosestHitLeafList(const DevScene& sc, V3 o, V3 
 // Traversal state of one ray.  It lives in registers (+ the lane's LDS stack) so that a traversal can be suspended
 // while other lanes of the wave are shaded (pt_bvh_megakernel) and resumed afterwards.
 struct BvhTrav {
-  V3 inv, oi;          // 1/d and o/d (slab test operands)
-  float oi_mag;        // max |oi| over the axes where it is finite (rounding slack of the slab test)
+  F2 inv_xy, oi_xy;    // (1/d.x, 1/d.y) and (o.x/d.x, o.y/d.y): packed slab-test operands
+  F2 inv_zz, oi_zz;    // (1/d.z, 1/d.z) and (o.z/d.z, o.z/d.z)
+  float slack_abs;     // 2^-20 * max |o/d| over the axes that take part (rounding slack of the slab test)
   int32_t cur;         // >= 0 inner node, < 0 leaf reference, kBvhDone finished
   int sp;              // entries on the lane's stack
   bool overflow;       // the stack was too small (cannot happen with the builder's depth cap): fall back to the list scan
@@ -517,24 +524,25 @@ struct BvhTrav {
 
 __device__ __forceinline__ void BvhBegin(const DevScene& sc, V3 o, V3 d, BvhTrav& tr, HitRec& best) {
   best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;
-  tr.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  tr.oi = v3(o.x * tr.inv.x, o.y * tr.inv.y, o.z * tr.inv.z);
+  V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  V3 oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
   // An axis whose 1/d or o/d is not finite (d component 0 or denormal, huge origin) is taken OUT of the slab test by
   // making both operands NaN: fma(plane, NaN, NaN) = NaN, which min/max skip.  Leaving +-inf in would not be
   // conservative in the one-FMA form: for a box that contains the origin, plane*inf - o*inf is -inf for one plane
-  // and inf - inf = NaN for the other, and max(-inf, NaN) = -inf would cull the box.
-  {
-    const float kNaN = __builtin_nanf("");
-    if (!(Abs(tr.inv.x) < 3.0e38f) || !(Abs(tr.oi.x) < 3.0e38f)) { tr.inv.x = kNaN; tr.oi.x = kNaN; }
-    if (!(Abs(tr.inv.y) < 3.0e38f) || !(Abs(tr.oi.y) < 3.0e38f)) { tr.inv.y = kNaN; tr.oi.y = kNaN; }
-    if (!(Abs(tr.inv.z) < 3.0e38f) || !(Abs(tr.oi.z) < 3.0e38f)) { tr.inv.z = kNaN; tr.oi.z = kNaN; }
-    const float ax = Abs(tr.oi.x), ay = Abs(tr.oi.y), az = Abs(tr.oi.z);
-    tr.oi_mag = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);      // fmax skips the NaN axes; all NaN -> NaN -> slack clamps
-  }
+  // and inf - inf = NaN for the other, and max(-inf, NaN) = -inf would cull the box.  (An infinite o/d must not
+  // reach the slack either: an infinite slack makes every box "hit", and an axis-parallel ray then walks the whole
+  // tree -- 2 M nodes, 0.75 s for one lane, found on config 3.)
+  const float kNaN = __builtin_nanf("");
+  if (!(Abs(inv.x) < 3.0e38f) || !(Abs(oi.x) < 3.0e38f)) { inv.x = kNaN; oi.x = kNaN; }
+  if (!(Abs(inv.y) < 3.0e38f) || !(Abs(oi.y) < 3.0e38f)) { inv.y = kNaN; oi.y = kNaN; }
+  if (!(Abs(inv.z) < 3.0e38f) || !(Abs(oi.z) < 3.0e38f)) { inv.z = kNaN; oi.z = kNaN; }
+  float mag = __builtin_fmaxf(__builtin_fmaxf(Abs(oi.x), Abs(oi.y)), Abs(oi.z));    // fmax skips the NaN axes
+  if (!(mag == mag)) mag = 0.0f;                                                      // no axis takes part
+  tr.slack_abs = 9.5367431640625e-07f * mag;
+  tr.inv_xy = f2(inv.x, inv.y); tr.oi_xy = f2(oi.x, oi.y);
+  tr.inv_zz = f2(inv.z, inv.z); tr.oi_zz = f2(oi.z, oi.z);
   // A ray with a NaN component cannot hit anything: every exact test forms dot products over all components of o and
-  // d, so every t it computes is NaN, and Closer() never accepts a NaN t (the List scan returns "no hit" too).  Such
-  // rays do occur (a handful per 1e7 paths in the 1M-sphere scene); without this exit the conservative slab test
-  // ("NaN -> visit") walks the ENTIRE tree for them -- one lane, 1.5 M steps, 0.75 s per launch.
+  // d, so every t it computes is NaN, and Closer() never accepts a NaN t (the List scan returns "no hit" too).
   const bool nan_ray = !(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z);
   tr.cur = nan_ray ? AMBER_BVH_DONE : sc.bvh_root; tr.sp = 0; tr.overflow = false;
 }
@@ -555,13 +563,23 @@ __device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack,
   int budget = AMBER_BVH_DESCENT_BUDGET;
   while (cur >= 0 && cur != AMBER_BVH_DONE && budget-- > 0) {
     const DevBvhNode* nd = sc.bvh_nodes + cur;
-    const float4 a = *reinterpret_cast<const float4*>(nd->lmin), b = *reinterpret_cast<const float4*>(nd->lmax);
-    const float4 c = *reinterpret_cast<const float4*>(nd->rmin), e = *reinterpret_cast<const float4*>(nd->rmax);
-    const float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {b.x, b.y, b.z}, rmn[3] = {c.x, c.y, c.z}, rmx[3] = {e.x, e.y, e.z};
-    const int32_t left = __float_as_int(a.w), right = __float_as_int(c.w);
+    const float4 a = *reinterpret_cast<const float4*>(nd->lxy), b = *reinterpret_cast<const float4*>(nd->rxy);
+    const float4 c = *reinterpret_cast<const float4*>(nd->z);
+    const int2 kids = *reinterpret_cast<const int2*>(&nd->left);
+    const int32_t left = kids.x, right = kids.y;
+#if AMBER_BVH_PACKED
+    const F2 lmn = __builtin_elementwise_fma(f2(a.x, a.y), tr.inv_xy, -tr.oi_xy), lmx = __builtin_elementwise_fma(f2(a.z, a.w), tr.inv_xy, -tr.oi_xy);
+    const F2 rmn = __builtin_elementwise_fma(f2(b.x, b.y), tr.inv_xy, -tr.oi_xy), rmx = __builtin_elementwise_fma(f2(b.z, b.w), tr.inv_xy, -tr.oi_xy);
+    const F2 lz = __builtin_elementwise_fma(f2(c.x, c.y), tr.inv_zz, -tr.oi_zz), rz = __builtin_elementwise_fma(f2(c.z, c.w), tr.inv_zz, -tr.oi_zz);
+#else
+    const float ix = tr.inv_xy.x, iy = tr.inv_xy.y, iz = tr.inv_zz.x, ox = tr.oi_xy.x, oy = tr.oi_xy.y, oz = tr.oi_zz.x;
+    const F2 lmn = f2(__builtin_fmaf(a.x, ix, -ox), __builtin_fmaf(a.y, iy, -oy)), lmx = f2(__builtin_fmaf(a.z, ix, -ox), __builtin_fmaf(a.w, iy, -oy));
+    const F2 rmn = f2(__builtin_fmaf(b.x, ix, -ox), __builtin_fmaf(b.y, iy, -oy)), rmx = f2(__builtin_fmaf(b.z, ix, -ox), __builtin_fmaf(b.w, iy, -oy));
+    const F2 lz = f2(__builtin_fmaf(c.x, iz, -oz), __builtin_fmaf(c.y, iz, -oz)), rz = f2(__builtin_fmaf(c.z, iz, -oz), __builtin_fmaf(c.w, iz, -oz));
+#endif
     bool hl, hr; float tl, tr_;
-    SlabTest(lmn, lmx, tr.inv, tr.oi, tr.oi_mag, best.t, hl, tl);
-    SlabTest(rmn, rmx, tr.inv, tr.oi, tr.oi_mag, best.t, hr, tr_);
+    SlabDecide(lmn.x, lmx.x, lmn.y, lmx.y, lz.x, lz.y, tr.slack_abs, best.t, hl, tl);
+    SlabDecide(rmn.x, rmx.x, rmn.y, rmx.y, rz.x, rz.y, tr.slack_abs, best.t, hr, tr_);
     if (hl && hr) {
       const bool left_first = !(tr_ < tl);
       const int32_t near_ = left_first ? left : right, far_ = left_first ? right : left;

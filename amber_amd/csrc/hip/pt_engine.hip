@@ -203,7 +203,8 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? 5 : 4) pt_bvh_megakernel(c
   uint64_t rng = 1;
   uint32_t casts = 0, rays = 0;
   int origin_slot = -1;
-  BvhTrav tr; tr.inv = v3(0.f, 0.f, 0.f); tr.oi = v3(0.f, 0.f, 0.f); tr.oi_mag = 0.f; tr.cur = AMBER_BVH_DONE; tr.sp = 0; tr.overflow = false;
+  BvhTrav tr; tr.inv_xy = f2(0.f, 0.f); tr.oi_xy = f2(0.f, 0.f); tr.inv_zz = f2(0.f, 0.f); tr.oi_zz = f2(0.f, 0.f); tr.slack_abs = 0.f;
+  tr.cur = AMBER_BVH_DONE; tr.sp = 0; tr.overflow = false;
   HitRec hit; hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.idx = -1; hit.slot = -1;
 #ifdef AMBER_STAMPS
   StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;

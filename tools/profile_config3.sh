@@ -20,7 +20,7 @@ out = sys.argv[1]
 agg = collections.defaultdict(list)
 for f in glob.glob(out + "/pmc_*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "pt_megakernel" in r["Kernel_Name"]:
+        if "megakernel" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
     print("%-34s last launch %.6g  (launches %d)" % (k, v[-1], len(v)))
