@@ -55,7 +55,9 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, FilterProgram
   const double diam = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
   const double eps = 5.9604644775390625e-08;
   const double c = 32.0 * eps * (diam + 1.5 * e_max);
-  struct Group { double n[3], d0, kt, ktol; std::vector<DevTriFilter> tris; std::vector<uint32_t> index; };
+  // per triangle of a group: the three affine coordinate functions (of v0, v1, v2) in double, for pairing
+  struct Tri { uint32_t index; double v[3][3]; double coef[3][4]; double g; };   // coef[k] = (gradient, constant) of the coordinate of vertex k
+  struct Group { double n[3], d0, kt, ktol; std::vector<Tri> tris; };
   std::vector<Group> groups;
   std::vector<uint32_t> sphere_index, always_index;
   for (size_t i = 0; i < objs.size() && i < 32; i++) {
@@ -83,19 +85,19 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, FilterProgram
         for (const auto& vtx : verts) dmax = std::max(dmax, std::fabs(gq.n[0] * vtx[0] + gq.n[1] * vtx[1] + gq.n[2] * vtx[2] - gq.d0));
         if (dmax <= 4.0 * eps * diam) { grp = &gq; dist = dmax; break; }
       }
-      DevTriFilter f;
-      std::memset(&f, 0, sizeof f);
-      for (int k = 0; k < 3; k++) { f.A[k] = static_cast<float>(A[k]); f.B[k] = static_cast<float>(B[k]); }
-      f.a0 = static_cast<float>(-(A[0] * v0[0] + A[1] * v0[1] + A[2] * v0[2]));
-      f.b0 = static_cast<float>(-(B[0] * v0[0] + B[1] * v0[1] + B[2] * v0[2]));
+      Tri t;
+      t.index = idx; t.g = g;
+      for (int k = 0; k < 3; k++) for (int c2 = 0; c2 < 3; c2++) t.v[k][c2] = verts[k][c2];
+      const double a0 = -(A[0] * v0[0] + A[1] * v0[1] + A[2] * v0[2]), b0 = -(B[0] * v0[0] + B[1] * v0[1] + B[2] * v0[2]);
+      for (int k = 0; k < 3; k++) { t.coef[1][k] = A[k]; t.coef[2][k] = B[k]; t.coef[0][k] = -(A[k] + B[k]); }
+      t.coef[1][3] = a0; t.coef[2][3] = b0; t.coef[0][3] = 1.0 - a0 - b0;
       const double ktol = (c + dist) * g * 1.0001 + 1e-7;
       const double kt = 2.0 * (c + dist) * std::max(1.0, inv_sin) + 1e-7;
-      if (!std::isfinite(ktol) || !std::isfinite(f.a0) || !std::isfinite(f.b0) || !std::isfinite(kt)) { always_index.push_back(idx); continue; }
-      if (!grp) { groups.push_back(Group{{n[0], n[1], n[2]}, d0, 0.0, 0.0, {}, {}}); grp = &groups.back(); }
+      if (!std::isfinite(ktol) || !std::isfinite(static_cast<float>(a0)) || !std::isfinite(static_cast<float>(b0)) || !std::isfinite(kt)) { always_index.push_back(idx); continue; }
+      if (!grp) { groups.push_back(Group{{n[0], n[1], n[2]}, d0, 0.0, 0.0, {}}); grp = &groups.back(); }
       grp->kt = std::max(grp->kt, kt);
       grp->ktol = std::max(grp->ktol, ktol);
-      grp->tris.push_back(f);
-      grp->index.push_back(idx);
+      grp->tris.push_back(t);
     } else if (o.kind == AMBER_PRIM_SPHERE) {
       DevSphereFilter f;
       std::memset(&f, 0, sizeof f);
@@ -109,15 +111,69 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, FilterProgram
       always_index.push_back(idx);                   // disk, cylinder: always tested exactly
     }
   }
+  auto record = [](const Tri& t, int row_a, int row_b) {          // rows = vertex whose coordinate function is evaluated
+    DevTriFilter f;
+    std::memset(&f, 0, sizeof f);
+    for (int k = 0; k < 3; k++) { f.A[k] = static_cast<float>(t.coef[row_a][k]); f.B[k] = static_cast<float>(t.coef[row_b][k]); }
+    f.a0 = static_cast<float>(t.coef[row_a][3]); f.b0 = static_cast<float>(t.coef[row_b][3]);
+    return f;
+  };
   for (const Group& g : groups) {
+    // Parallelogram pairs: triangle j shares two corners with triangle i and its third corner is D = A + C - B
+    // (B = i's unshared corner), everything up to 1e-6 of the scene diameter; the actual mismatch (corners are
+    // rebuilt from binary32 edge vectors) joins the barycentric tolerance through the gradient magnitude.
+    const size_t nt = g.tris.size();
+    std::vector<int> partner(nt, -1), unshared(nt, -1);
+    double pair_slack = 0;
+    auto apart = [](const double* p, const double* r) { return std::max(std::fabs(p[0] - r[0]), std::max(std::fabs(p[1] - r[1]), std::fabs(p[2] - r[2]))); };
+    for (size_t i = 0; i < nt; i++) {
+      if (partner[i] >= 0) continue;
+      for (size_t j = i + 1; j < nt && partner[i] < 0; j++) {
+        if (partner[j] >= 0) continue;
+        int match_i[3] = {-1, -1, -1}, n_shared = 0;               // match_i[k] = corner of j equal to corner k of i
+        bool used_j[3] = {false, false, false};
+        double err = 0;
+        for (int k = 0; k < 3; k++)
+          for (int l = 0; l < 3; l++)
+            if (!used_j[l] && match_i[k] < 0 && apart(g.tris[i].v[k], g.tris[j].v[l]) <= 1e-6 * diam) {
+              match_i[k] = l; used_j[l] = true; n_shared++;
+              err = std::max(err, apart(g.tris[i].v[k], g.tris[j].v[l]));
+            }
+        if (n_shared != 2) continue;
+        int bi = -1, dj = -1;
+        for (int k = 0; k < 3; k++) if (match_i[k] < 0) bi = k;
+        for (int l = 0; l < 3; l++) if (!used_j[l]) dj = l;
+        double expect[3];
+        for (int c2 = 0; c2 < 3; c2++) {
+          expect[c2] = -g.tris[i].v[bi][c2];
+          for (int k = 0; k < 3; k++) if (k != bi) expect[c2] += g.tris[i].v[k][c2];
+        }
+        err = std::max(err, apart(expect, g.tris[j].v[dj]));
+        if (err <= 1e-6 * diam) {
+          partner[i] = static_cast<int>(j); partner[j] = static_cast<int>(i); unshared[i] = bi;
+          pair_slack = std::max(pair_slack, 4.0 * err * std::max(g.tris[i].g, g.tris[j].g));
+        }
+      }
+    }
     DevPlane p;
     std::memset(&p, 0, sizeof p);
     for (int k = 0; k < 3; k++) p.n[k] = static_cast<float>(g.n[k]);
-    p.d0 = static_cast<float>(g.d0); p.kt = static_cast<float>(g.kt * 1.0001); p.ktol = static_cast<float>(g.ktol * 1.0001);
-    p.n_tris = static_cast<uint32_t>(g.tris.size());
+    // the pair evaluation adds two roundings of 1 - x (<= 1.2e-7 each) and the corner mismatch measured above
+    p.d0 = static_cast<float>(g.d0); p.kt = static_cast<float>(g.kt * 1.0001); p.ktol = static_cast<float>((g.ktol + 4e-7 + pair_slack) * 1.0001);
+    for (size_t i = 0; i < nt; i++) {
+      if (partner[i] < 0 || static_cast<size_t>(partner[i]) < i) continue;
+      const int bi = unshared[i], ai = (bi + 1) % 3;
+      fp.tris.push_back(record(g.tris[i], bi, ai));
+      fp.order.push_back(g.tris[i].index); fp.order.push_back(g.tris[static_cast<size_t>(partner[i])].index);
+      p.n_pairs++;
+    }
+    for (size_t i = 0; i < nt; i++) {
+      if (partner[i] >= 0) continue;
+      fp.tris.push_back(record(g.tris[i], 1, 2));                  // u, v = coordinates of v1, v2
+      fp.order.push_back(g.tris[i].index);
+      p.n_tris++;
+    }
     fp.planes.push_back(p);
-    fp.tris.insert(fp.tris.end(), g.tris.begin(), g.tris.end());
-    fp.order.insert(fp.order.end(), g.index.begin(), g.index.end());
   }
   fp.n_prog_tris = static_cast<uint32_t>(fp.order.size());
   fp.order.insert(fp.order.end(), sphere_index.begin(), sphere_index.end());

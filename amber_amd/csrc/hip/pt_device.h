@@ -60,9 +60,14 @@ struct alignas(16) DevPlane {       // 32 B: one s_load_dwordx8
   float n[3]; float d0;             // unit normal, n.v0
   float kt;                         // tolerance of the t >= kEPS test   (multiplied by |1/(n.d)|)
   float ktol;                       // barycentric tolerance, max over the plane's triangles (same factor)
-  uint32_t n_tris, pad;
+  uint32_t n_tris;                  // single-triangle records that follow the pair records
+  uint32_t n_pairs;                 // parallelogram records: ONE DevTriFilter, TWO consecutive candidate bits
 };
-struct alignas(16) DevTriFilter {   // 32 B: one s_load_dwordx8.  Candidate bit = position in the program.
+// A single triangle: u, v = barycentric coordinates of v1, v2.  A parallelogram pair (two coplanar triangles that
+// share an edge, fourth corner D = A + C - B): row A is the coordinate "beta" of the first triangle's unshared
+// corner B, row B the coordinate "alpha" of a shared corner; with gamma = 1 - alpha - beta the second triangle's
+// coordinates are (1 - gamma, -beta, 1 - alpha), so both minima come from one pair of affine evaluations.
+struct alignas(16) DevTriFilter {   // 32 B: one s_load_dwordx8.  Candidate bits follow the program order.
   float A[3]; float a0;             // u = A.P + a0 for P on the plane
   float B[3]; float b0;             // v = B.P + b0
 };
@@ -405,7 +410,18 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
       const bool t_ok = tp >= AMBER_KEPS - cw_f(pl, 4) * rho;
       const bool grazing = !(Abs(nd) >= AMBER_GRAZING);     // true for NaN
       const float mtol = -cw_f(pl, 5) * rho;
-      const int nt = static_cast<int>(pl[6]);
+      const int nt = static_cast<int>(pl[6]), np = static_cast<int>(pl[7]);
+      for (int k = 0; k < np; ++k, tr += 8, bit <<= 2) {    // parallelogram pairs: one record, two candidate bits
+        const float b = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 1), Py, __builtin_fmaf(cw_f(tr, 2), Pz, cw_f(tr, 3))));
+        const float a = __builtin_fmaf(cw_f(tr, 4), Px, __builtin_fmaf(cw_f(tr, 5), Py, __builtin_fmaf(cw_f(tr, 6), Pz, cw_f(tr, 7))));
+        const float g = 1.0f - b - a;
+        const float m1 = __builtin_fminf(__builtin_fminf(b, a), g);
+        const float m2 = __builtin_fminf(__builtin_fminf(-b, 1.0f - a), 1.0f - g);
+        const bool keep1 = ((m1 >= mtol) && t_ok) || grazing;
+        const bool keep2 = ((m2 >= mtol) && t_ok) || grazing;
+        cand |= keep1 ? bit : 0u;
+        cand |= keep2 ? (bit << 1) : 0u;
+      }
       for (int k = 0; k < nt; ++k, tr += 8, bit <<= 1) {    // DevTriFilter = 8 dwords
         const float u = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 1), Py, __builtin_fmaf(cw_f(tr, 2), Pz, cw_f(tr, 3))));
         const float v = __builtin_fmaf(cw_f(tr, 4), Px, __builtin_fmaf(cw_f(tr, 5), Py, __builtin_fmaf(cw_f(tr, 6), Pz, cw_f(tr, 7))));
