@@ -32,3 +32,41 @@ def as_tuples(scene_kwargs):
     objects = [(int(kind), int(m), [float(x) for x in p[: n_par[int(kind)]]]) for kind, m, p in zip(k["kinds"], k["material_index"], k["params"])]
     return dict(objects=objects, materials=k["materials"], transform=k["transform"], focal_length=k["focal_length"],
                 focus_distance=k["focus_distance"], radius=k["radius"], n_blades=k["n_blades"])
+
+
+def mesh_room(subdivisions: int = 8, seed: int = 3):
+    """A triangle-mesh stress scene for engine BVH (not a BASELINE config): a Cornell-like room of 10 wall triangles and
+    a ceiling light, containing a bumpy icosphere of 20 * 4**subdivisions triangles (subdivisions = 8: 1.3 M) with a
+    glossy material.  Returns the keyword arguments of HostScene.create_arrays."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = np.array([(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)], np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+                  (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)], np.int64)
+    for _ in range(subdivisions):
+        e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1)
+        ue, inv = np.unique(e, axis=0, return_inverse=True)
+        mid = v[ue[:, 0]] + v[ue[:, 1]]
+        mid /= np.linalg.norm(mid, axis=1, keepdims=True)
+        m = len(v) + inv.reshape(3, -1)                       # midpoint index of edges (0,1), (1,2), (2,0) of every face
+        v = np.concatenate([v, mid])
+        a, b, c = f[:, 0], f[:, 1], f[:, 2]
+        f = np.concatenate([np.stack([a, m[0], m[2]], 1), np.stack([b, m[1], m[0]], 1), np.stack([c, m[2], m[1]], 1), np.stack([m[0], m[1], m[2]], 1)])
+    rng = np.random.Generator(np.random.MT19937(seed))
+    bump = 1.0 + 0.02 * np.sin(9.0 * v[:, 0]) * np.sin(7.0 * v[:, 1] + 1.0) * np.sin(8.0 * v[:, 2] + 2.0) + 0.002 * rng.standard_normal(len(v))
+    p = (np.array([0.1, -0.35, -0.1]) + 0.6 * v * bump[:, None]).astype(np.float32)
+    tri = np.concatenate([p[f[:, 0]], p[f[:, 1]], p[f[:, 2]]], axis=1)                       # (n, 9)
+    c8 = np.array([(-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1)], np.float32)
+    quads = [(0, 1, 2, 3, 1), (0, 4, 5, 1, 1), (3, 2, 6, 7, 1), (0, 3, 7, 4, 2), (1, 5, 6, 2, 3)]    # back, floor, ceiling, left (red), right (green)
+    walls, wall_mat = [], []
+    for a, b, c, d, m in quads:
+        walls += [np.concatenate([c8[a], c8[b], c8[c]]), np.concatenate([c8[c], c8[d], c8[a]])]; wall_mat += [m, m]
+    L = np.array([(-0.3, 0.99, -0.3), (0.3, 0.99, -0.3), (0.3, 0.99, 0.3), (-0.3, 0.99, 0.3)], np.float32)
+    walls += [np.concatenate([L[0], L[1], L[2]]), np.concatenate([L[2], L[3], L[0]])]; wall_mat += [0, 0]
+    params = np.zeros((len(walls) + len(tri), 12), np.float32)
+    params[: len(walls), :9] = np.array(walls); params[len(walls):, :9] = tri
+    material = np.concatenate([np.array(wall_mat, np.uint32), np.full(len(tri), 4, np.uint32)])
+    materials = [(api.MAT_DIFFUSE_LIGHT, (20.0, 20.0, 20.0), 0.0), (api.MAT_LAMBERTIAN, (0.75, 0.75, 0.75), 0.0), (api.MAT_LAMBERTIAN, (0.75, 0.25, 0.25), 0.0),
+                 (api.MAT_LAMBERTIAN, (0.25, 0.75, 0.25), 0.0), (api.MAT_PHONG, (0.8, 0.8, 0.8), 40.0)]
+    return dict(kinds=np.full(len(params), api.PRIM_TRIANGLE, np.uint32), material_index=material, params=params, materials=materials,
+                transform=[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 4, 0, 0, 0, 1], focal_length=0.05, focus_distance=4.0, radius=0.01, n_blades=6)
