@@ -48,31 +48,45 @@ def stripe_partition(height: int, world_size: int, stripe_rows: int = STRIPE_ROW
     return parts
 
 
-def gather_rows(local_rows, parts, width: int, rank: int, world_size: int, dst: int = 0):
-    """The job's single collective: gather every rank's rows (torch tensor (n_r, width, 3) on the backend's
-    device) to rank `dst` and scatter them to their global row positions.  Returns the (height, width, 3) image
-    on `dst`, None elsewhere."""
-    import torch
-    import torch.distributed as dist
+class RowGatherer:
+    """The job's single collective with its buffers and index tensors allocated once: gathers every rank's rows
+    (tensor (n_r, width, 3) on the backend's device) to rank `dst` and scatters them to their global row positions.
+    At 8 ranks a Cornell step is 13 ms per rank, so per-step allocations and index uploads would show."""
 
-    max_rows = max(len(p["index"]) for p in parts)
-    dev = local_rows.device
-    n = len(parts[rank]["index"])
-    if world_size == 1:
-        return local_rows.reshape(n, width, 3)
-    send = torch.zeros((max_rows, width, 3), dtype=torch.float32, device=dev)
-    if n:
-        send[:n].copy_(local_rows.reshape(n, width, 3))
-    recv = [torch.empty_like(send) for _ in range(world_size)] if rank == dst else None
-    dist.gather(send, gather_list=recv, dst=dst)
-    if rank != dst:
-        return None
-    height = sum(len(p["index"]) for p in parts)
-    full = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
-    for r, p in enumerate(parts):
-        if len(p["index"]):
-            full.index_copy_(0, torch.as_tensor(p["index"], dtype=torch.long, device=dev), recv[r][: len(p["index"])])
-    return full
+    def __init__(self, parts, width: int, rank: int, world_size: int, device, dst: int = 0):
+        import torch
+
+        self.parts, self.width, self.rank, self.world, self.dst = parts, width, rank, world_size, dst
+        self.n = len(parts[rank]["index"])
+        self.max_rows = max(len(p["index"]) for p in parts)
+        self.height = sum(len(p["index"]) for p in parts)
+        if world_size > 1:
+            self.send = torch.zeros((self.max_rows, width, 3), dtype=torch.float32, device=device)
+            if rank == dst:
+                self.recv = [torch.empty_like(self.send) for _ in range(world_size)]
+                self.full = torch.empty((self.height, width, 3), dtype=torch.float32, device=device)
+                self.index = [torch.as_tensor(np.asarray(p["index"]), dtype=torch.long, device=device) for p in parts]
+
+    def __call__(self, local_rows):
+        """Returns the (height, width, 3) image on `dst` (a buffer reused by the next call), None elsewhere."""
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return local_rows.reshape(self.n, self.width, 3)
+        if self.n:
+            self.send[: self.n].copy_(local_rows.reshape(self.n, self.width, 3))
+        dist.gather(self.send, gather_list=self.recv if self.rank == self.dst else None, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        for r, p in enumerate(self.parts):
+            if len(p["index"]):
+                self.full.index_copy_(0, self.index[r], self.recv[r][: len(p["index"])])
+        return self.full
+
+
+def gather_rows(local_rows, parts, width: int, rank: int, world_size: int, dst: int = 0):
+    """One-shot form of RowGatherer (allocates its buffers per call)."""
+    return RowGatherer(parts, width, rank, world_size, local_rows.device, dst)(local_rows)
 
 
 def gather_bands(local_band, bands, width: int, rank: int, world_size: int, dst: int = 0):

@@ -71,7 +71,7 @@ def main():
     import torch
 
     import amber_amd
-    from amber_amd.distributed import band_tensor, gather_rows, stripe_partition
+    from amber_amd.distributed import RowGatherer, band_tensor, stripe_partition
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,6 +102,7 @@ def main():
                                   stream=stream, engine={"auto": 0, "list": 1, "two_phase": 2, "bvh": 3, "wavefront": 4}[args.engine])
     fb = band_tensor(tracer, f"cuda:{local_rank}")
     launches = [(s, min(args.spp_per_launch, args.spp - s)) for s in range(0, args.spp, args.spp_per_launch)]
+    gather = RowGatherer(parts, W, rank, world, "cpu" if (args.rehearse_on_one_gpu and world > 1) else fb.device)   # buffers allocated once
 
     def step():
         tracer.clear()
@@ -109,8 +110,8 @@ def main():
             tracer.render_pass(first, n)
         if args.rehearse_on_one_gpu and world > 1:
             torch.cuda.synchronize()
-            return gather_rows(fb.cpu(), parts, W, rank, world)    # gloo: host tensors
-        return gather_rows(fb, parts, W, rank, world)              # the single collective of the job
+            return gather(fb.cpu())                                # gloo: host tensors
+        return gather(fb)                                          # the single collective of the job
 
     def fence():
         torch.cuda.synchronize()
