@@ -62,11 +62,20 @@ int main() {
     const auto objs = ToDev(fs);
     amber_filter::FilterProgram fp;
     amber_filter::BuildFilterProgram(objs, fp);
-    if (fp.order.size() != objs.size() || fp.planes.size() != 9 || fp.tris.size() != 22 || fp.spheres.size() != 3 || fp.always_mask != 0) {
-      std::printf("FAIL filter program: planes %zu tris %zu spheres %zu always %x\n", fp.planes.size(), fp.tris.size(), fp.spheres.size(), fp.always_mask);
+    uint32_t pairs = 0, singles = 0;
+    for (const auto& pl : fp.planes) { pairs += pl.n_pairs; singles += pl.n_tris; }
+    std::vector<int> slot_of(objs.size(), 0);
+    for (uint32_t idx : fp.order) if (idx < objs.size()) slot_of[idx]++;
+    bool each_once = true;
+    for (int c : slot_of) each_once = each_once && c == 1;
+    // every Cornell quad and the hexagonal aperture (three rhombi) pair up: 22 triangles in 11 parallelogram records
+    if (fp.order.size() != objs.size() || !each_once || fp.planes.size() != 9 || fp.tris.size() != pairs + singles || 2 * pairs + singles != 22 ||
+        pairs != 11 || fp.n_prog_tris != 22 || fp.spheres.size() != 3 || fp.always_mask != 0) {
+      std::printf("FAIL filter program: planes %zu records %zu (pairs %u singles %u) spheres %zu always %x\n", fp.planes.size(), fp.tris.size(), pairs, singles,
+                  fp.spheres.size(), fp.always_mask);
       return 1;
     }
-    std::printf("ok   filter program: 9 planes, 22 triangles, 3 spheres\n");
+    std::printf("ok   filter program: 9 planes, 22 triangles in 11 pair records, 3 spheres\n");
     CheckBvh(objs, "cornell");
   }
   // 2. degenerate inputs: pinhole (zero-area triangle), one object, coincident centres, extreme coordinates
