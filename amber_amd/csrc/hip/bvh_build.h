@@ -15,10 +15,12 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "pt_device.h"
@@ -84,21 +86,34 @@ inline void PadBox(Box& b, float scene_extent) {
   }
 }
 
-struct Builder {
-  const std::vector<DevObject>& objs;
+// Arrays shared by every builder of one tree: index ranges handed to different builders are disjoint.
+struct Shared {
   std::vector<Box> boxes;
   std::vector<float> cent;          // 3 per object
   std::vector<uint32_t> index;      // permutation (leaf order)
-  std::vector<DevBvhNode> nodes;
   float extent = 0;
-  uint32_t max_depth_seen = 0;
+};
 
-  explicit Builder(const std::vector<DevObject>& o) : objs(o) {}
+// A subtree whose construction was deferred to a worker thread: range, depth, and where its root reference goes.
+struct Deferred { uint32_t first, last, depth, parent; bool is_left; };
+
+struct Builder {
+  Shared& s;
+  std::vector<DevBvhNode> nodes;
+  uint32_t max_depth_seen = 0;
+  uint32_t grain = 0;               // > 0: ranges of at most `grain` objects below depth 0 are deferred, not built
+  std::vector<Deferred>* deferred = nullptr;
+
+  explicit Builder(Shared& shared) : s(shared) {}
 
   static int32_t LeafRef(uint32_t first, uint32_t count) { return -static_cast<int32_t>(first * 8u + count) - 1; }   // count <= 7
+  static constexpr int32_t kPending = 0x7ffffffe;       // placeholder of a deferred child reference
 
   // returns child reference (>= 0 inner node index, < 0 leaf) and the box of the range
-  int32_t Build(uint32_t first, uint32_t last, uint32_t depth, Box& out_box) {
+  int32_t Build(uint32_t first, uint32_t last, uint32_t depth, Box& out_box, uint32_t parent = 0, bool is_left = false) {
+    std::vector<Box>& boxes = s.boxes;
+    std::vector<float>& cent = s.cent;
+    std::vector<uint32_t>& index = s.index;
     max_depth_seen = std::max(max_depth_seen, depth);
     Box bb; bb.reset();
     Box cb; cb.reset();
@@ -106,6 +121,7 @@ struct Builder {
     out_box = bb;
     const uint32_t n = last - first;
     if (n <= static_cast<uint32_t>(kLeafSize)) return LeafRef(first, n);
+    if (grain && depth > 0 && n <= grain) { deferred->push_back(Deferred{first, last, depth, parent, is_left}); return kPending; }
     // the remaining levels must be able to hold n objects even with median splits
     const bool force_median = (depth + 1 + static_cast<uint32_t>(std::ceil(std::log2(double(n) / kLeafSize))) + 2) >= static_cast<uint32_t>(kMaxDepth);
     uint32_t mid = first + n / 2;
@@ -158,9 +174,9 @@ struct Builder {
     const uint32_t me = static_cast<uint32_t>(nodes.size());
     nodes.emplace_back();
     Box lb, rb;
-    const int32_t l = Build(first, mid, depth + 1, lb);
-    const int32_t r = Build(mid, last, depth + 1, rb);
-    PadBox(lb, extent); PadBox(rb, extent);
+    const int32_t l = Build(first, mid, depth + 1, lb, me, true);
+    const int32_t r = Build(mid, last, depth + 1, rb, me, false);
+    PadBox(lb, s.extent); PadBox(rb, s.extent);
     DevBvhNode& nd = nodes[me];
     nd.lxy[0] = lb.mn[0]; nd.lxy[1] = lb.mn[1]; nd.lxy[2] = lb.mx[0]; nd.lxy[3] = lb.mx[1];
     nd.rxy[0] = rb.mn[0]; nd.rxy[1] = rb.mn[1]; nd.rxy[2] = rb.mx[0]; nd.rxy[3] = rb.mx[1];
@@ -177,31 +193,88 @@ struct FlatBvh {
   uint32_t depth = 0;
 };
 
+// Runs fn(k) for k in [0, n) on `threads` threads (work handed out by an atomic counter).
+template <typename Fn>
+inline void ParallelFor(size_t n, unsigned threads, Fn fn) {
+  if (threads <= 1 || n <= 1) { for (size_t k = 0; k < n; k++) fn(k); return; }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> pool;
+  const unsigned nt = static_cast<unsigned>(std::min<size_t>(threads, n));
+  for (unsigned t = 0; t < nt; t++) pool.emplace_back([&] { for (size_t k; (k = next.fetch_add(1)) < n;) fn(k); });
+  for (auto& th : pool) th.join();
+}
+
+// The top of the tree is built on the calling thread down to ranges of n / (8 * threads) objects; those subtrees are
+// built by worker threads, each into its own node array, and appended in the (deterministic) order in which the
+// top-level pass met them.  Topology, boxes and leaf order do not depend on the number of threads; only the node
+// numbering differs from a single-threaded build.  AMBER_BVH_THREADS overrides the thread count (1 = serial).
 inline FlatBvh BuildBvh(const std::vector<DevObject>& objs) {
-  Builder b(objs);
   const uint32_t n = static_cast<uint32_t>(objs.size());
-  b.boxes.resize(n); b.cent.resize(3 * size_t(n)); b.index.resize(n);
+  unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* env = std::getenv("AMBER_BVH_THREADS")) threads = static_cast<unsigned>(std::max(1, std::atoi(env)));
+  if (n < 65536) threads = 1;
+  Shared s;
+  s.boxes.resize(n); s.cent.resize(3 * size_t(n)); s.index.resize(n);
   Box all; all.reset();
   for (uint32_t i = 0; i < n; i++) all.grow(ObjectBox(objs[i]));
   const double dx = double(all.mx[0]) - all.mn[0], dy = double(all.mx[1]) - all.mn[1], dz = double(all.mx[2]) - all.mn[2];
   double slack_factor = 16.0;
   if (const char* env = std::getenv("AMBER_BVH_SPHERE_SLACK")) slack_factor = std::atof(env);   // test hook: the image must not depend on it
   const double sphere_slack2 = slack_factor * 5.9604644775390625e-08 * (dx * dx + dy * dy + dz * dz);   // 16 eps D^2
+  const size_t n_chunks = threads > 1 ? threads * 4 : 1;
+  std::vector<Box> chunk_box(n_chunks);
+  ParallelFor(n_chunks, threads, [&](size_t c) {
+    Box cb; cb.reset();
+    for (size_t i = n * c / n_chunks; i < n * (c + 1) / n_chunks; i++) {
+      s.boxes[i] = ObjectBox(objs[i], sphere_slack2);
+      for (int k = 0; k < 3; k++) s.cent[3 * i + k] = 0.5f * (s.boxes[i].mn[k] + s.boxes[i].mx[k]);
+      s.index[i] = static_cast<uint32_t>(i);
+      cb.grow(s.boxes[i]);
+    }
+    chunk_box[c] = cb;
+  });
   all.reset();
-  for (uint32_t i = 0; i < n; i++) {
-    b.boxes[i] = ObjectBox(objs[i], sphere_slack2);
-    for (int c = 0; c < 3; c++) b.cent[3 * size_t(i) + c] = 0.5f * (b.boxes[i].mn[c] + b.boxes[i].mx[c]);
-    b.index[i] = i;
-    all.grow(b.boxes[i]);
-  }
-  b.extent = std::max(all.mx[0] - all.mn[0], std::max(all.mx[1] - all.mn[1], all.mx[2] - all.mn[2]));
-  b.nodes.reserve(n);
+  for (const Box& cb : chunk_box) all.grow(cb);
+  s.extent = std::max(all.mx[0] - all.mn[0], std::max(all.mx[1] - all.mn[1], all.mx[2] - all.mn[2]));
+
+  Builder top(s);
+  std::vector<Deferred> tasks;
+  if (threads > 1) { top.grain = std::max<uint32_t>(4096u, n / (8u * threads)); top.deferred = &tasks; }
+  top.nodes.reserve(threads > 1 ? 4096 : n);
   Box root_box;
   FlatBvh out;
-  out.root_ref = b.Build(0, n, 0, root_box);
-  out.nodes = std::move(b.nodes);
-  out.prim_index = std::move(b.index);
-  out.depth = b.max_depth_seen;
+  out.root_ref = top.Build(0, n, 0, root_box);
+  out.depth = top.max_depth_seen;
+  out.nodes = std::move(top.nodes);
+  if (!tasks.empty()) {
+    std::vector<std::vector<DevBvhNode>> sub_nodes(tasks.size());
+    std::vector<int32_t> sub_root(tasks.size());
+    std::vector<uint32_t> sub_depth(tasks.size());
+    ParallelFor(tasks.size(), threads, [&](size_t k) {
+      Builder b(s);
+      b.nodes.reserve((tasks[k].last - tasks[k].first) / 2 + 16);
+      Box box;
+      sub_root[k] = b.Build(tasks[k].first, tasks[k].last, tasks[k].depth, box);
+      sub_depth[k] = b.max_depth_seen;
+      sub_nodes[k] = std::move(b.nodes);
+    });
+    size_t total = out.nodes.size();
+    for (const auto& v : sub_nodes) total += v.size();
+    out.nodes.reserve(total);
+    for (size_t k = 0; k < tasks.size(); k++) {
+      const int32_t base = static_cast<int32_t>(out.nodes.size());
+      for (DevBvhNode nd : sub_nodes[k]) {
+        if (nd.left >= 0) nd.left += base;
+        if (nd.right >= 0) nd.right += base;
+        out.nodes.push_back(nd);
+      }
+      const int32_t ref = sub_root[k] >= 0 ? sub_root[k] + base : sub_root[k];
+      DevBvhNode& parent = out.nodes[tasks[k].parent];
+      (tasks[k].is_left ? parent.left : parent.right) = ref;
+      out.depth = std::max(out.depth, sub_depth[k]);
+    }
+  }
+  out.prim_index = std::move(s.index);
   return out;
 }
 
