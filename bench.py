@@ -26,6 +26,25 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-le
 BYTES_PER_RAY = 96.0      # algorithmic ray-state bytes per bounce (DESIGN.md "Roofline")
 
 
+def measured_copy_bandwidth(torch, device) -> float:
+    """Achievable HBM bandwidth of this device: a 1 GiB device-to-device copy (read + write), GB/s (SURVEY.md 8(d):
+    the roofline fraction is also reported against what the box actually reaches, not only the vendor figure)."""
+    n = 1 << 28                                          # 2^28 float32 = 1 GiB
+    a = torch.empty(n, dtype=torch.float32, device=device).normal_()
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 10
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * 4.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(width: int, seed: int, budget_s: float = 15.0):
     """The CPU restatement (oracle, kind "port") on the host cores, reference threading model (rows of whole-image
     1-spp passes pulled by T threads), on a bounded sample of the SAME workload: full 1024x1024 frame, few spp."""
@@ -176,6 +195,14 @@ def main():
                 out["roofline"]["traffic_source"] = f"profiles/{profs[-1].name}"
             except Exception:
                 pass
+        if world == 1:
+            try:
+                bw = measured_copy_bandwidth(torch, f"cuda:{local_rank}")
+                out["roofline"]["measured_copy_bw"] = round(bw, 1)
+                out["roofline"]["frac_of_measured_copy_bw"] = round(achieved / bw, 5)
+            except Exception as e:                                     # never lose the bench line over the side measurement
+                out["roofline"]["measured_copy_bw"] = None
+                out["roofline"]["measured_copy_bw_error"] = str(e)[:120]
         if not args.no_cpu_baseline and world == 1:                    # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(W, args.seed)
         print(json.dumps(out), flush=True)

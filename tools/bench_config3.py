@@ -3,9 +3,10 @@ import sys, os, time; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__
 import amber_amd as A
 from amber_amd import scenes
 spp=int(sys.argv[1]) if len(sys.argv)>1 else 256
+engine=int(sys.argv[2]) if len(sys.argv)>2 else 0   # AMBER_ENGINE_*: 0 auto (BVH), 4 wavefront
 t=time.time(); hs=A.HostScene.create_arrays(**scenes.random_spheres(1_000_000,7)); t_scene=time.time()-t
 sn=A.Sensor.default(1920,1080)
-t=time.time(); pt=A.PathTracer(hs,sn,seed=1); t_create=time.time()-t
+t=time.time(); pt=A.PathTracer(hs,sn,seed=1,engine=engine); t_create=time.time()-t
 pt.render_pass(0,8); pt.sync(); pt.clear()
 t=time.time(); pt.render_pass(0,spp); pt.sync(); wall=time.time()-t
 n,ms=pt.kernel_time(); r=pt.ray_count()
