@@ -65,9 +65,16 @@ def cpu_baseline(width: int, seed: int, budget_s: float = 15.0):
     t0 = time.perf_counter()
     _, cnt = sc.render_xorshift(width, width, seed, 1, spp, math=O.MATH_LIBM, threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": round(cnt.casts / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"Cornell {width}x{width} @ {spp} spp of the 1024 ({cnt.casts} rays in {dt:.2f} s), oracle in BVH/libm mode, "
-                      f"{cores} threads; scale linearly in spp"}
+    out = {"value": round(cnt.casts / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+           "sample": f"Cornell {width}x{width} @ {spp} spp of the 1024 ({cnt.casts} rays in {dt:.2f} s), oracle in BVH/libm mode, "
+                     f"{cores} threads; scale linearly in spp"}
+    if cores > 1:                                # also one thread (a quarter of the frame's rows, 1 spp)
+        t0 = time.perf_counter()
+        _, c1 = sc.render_xorshift(width, width, seed, 0, 1, math=O.MATH_LIBM, threads=1, rows=(0, max(1, width // 4)))
+        d1 = time.perf_counter() - t0
+        out["single_thread_value"] = round(c1.casts / d1 / 1e6, 3)
+        out["sample"] += f"; 1 thread: rows 0..{max(1, width // 4)} @ 1 spp ({c1.casts} rays in {d1:.2f} s)"
+    return out
 
 
 def main():
