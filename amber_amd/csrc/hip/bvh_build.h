@@ -67,10 +67,15 @@ inline Box ObjectBox(const DevObject& o, double sphere_slack2 = 0.0) {
   } else if (kind == 1) {     // sphere
     const float r = static_cast<float>(std::sqrt(double(o.radius) * o.radius + sphere_slack2) * 1.000001);
     for (int c = 0; c < 3; c++) { b.mn[c] = o.a[c] - r; b.mx[c] = o.a[c] + r; }
-  } else {                    // disk / cylinder: bounding sphere of the swept disk (normal is not guaranteed unit)
-    double nl = std::sqrt(double(o.e1[0]) * o.e1[0] + double(o.e1[1]) * o.e1[1] + double(o.e1[2]) * o.e1[2]);
-    const double h = kind == 3 ? std::fabs(double(o.height)) * nl : 0.0;
-    const double r = std::fabs(double(o.radius)) * std::max(1.0, nl) + h;
+  } else if (kind == 2) {     // disk: the test is geometric for any normal length (t from the plane, |p - c|^2 <= r^2, primitive_disk.cc:94-114)
+    const double r = std::fabs(double(o.radius)) * 1.000001;
+    for (int c = 0; c < 3; c++) { b.mn[c] = static_cast<float>(o.a[c] - r); b.mx[c] = static_cast<float>(o.a[c] + r); }
+  } else {                    // cylinder (primitive_cylinder.cc:100-142) with axis vector N of length nu, not guaranteed unit:
+    // the accepted points P satisfy |P_perp|^2 + (1 - nu^2)^2 |P_par|^2 = r^2 and 0 <= P.N <= height, i.e. radial distance
+    // <= r and axial distance <= height / nu from the base centre: bounding sphere of radius hypot(r, height / nu)
+    const double nu = std::sqrt(double(o.e1[0]) * o.e1[0] + double(o.e1[1]) * o.e1[1] + double(o.e1[2]) * o.e1[2]);
+    const double axial = nu > 1e-30 ? std::fabs(double(o.height)) / nu : 1e30;
+    const double r = std::min(1e30, std::hypot(double(o.radius), axial) * 1.000001);
     for (int c = 0; c < 3; c++) { b.mn[c] = static_cast<float>(o.a[c] - r); b.mx[c] = static_cast<float>(o.a[c] + r); }
   }
   return b;
@@ -187,6 +192,9 @@ struct Builder {
 };
 
 struct FlatBvh {
+  float bounds_min[3] = {0, 0, 0}, bounds_max[3] = {0, 0, 0};   // bounds of all (widened) object boxes
+  float min_sphere_radius = 0;       // smallest |radius| over the spheres, 0 if there is none (BvhBegin's per-ray margin)
+  bool has_spheres = false;
   std::vector<DevBvhNode> nodes;     // nodes[0] is the root (if root_ref >= 0)
   std::vector<uint32_t> prim_index;  // leaf order -> object index
   int32_t root_ref = -1;             // >= 0: inner node 0 ; < 0: the whole scene is one leaf
@@ -275,6 +283,11 @@ inline FlatBvh BuildBvh(const std::vector<DevObject>& objs) {
     }
   }
   out.prim_index = std::move(s.index);
+  for (int c = 0; c < 3; c++) { out.bounds_min[c] = all.mn[c]; out.bounds_max[c] = all.mx[c]; }
+  float rmin = 3.0e38f;
+  for (const DevObject& o : objs)
+    if ((o.kind & 0xffu) == 1) { out.has_spheres = true; rmin = std::min(rmin, std::fabs(o.radius)); }
+  out.min_sphere_radius = out.has_spheres ? rmin : 0.0f;
   return out;
 }
 

@@ -129,6 +129,9 @@ struct DevScene {
   const uint32_t* __restrict__ bvh_prims;       // leaf order -> object index
   const DevObject* __restrict__ bvh_objects;    // the object records in leaf order (HitRec.slot of engine BVH indexes this array)
   int32_t bvh_root;                             // child reference of the whole scene
+  float bvh_center[3];                          // centre and half diagonal of the scene bounds (per-ray box margin, BvhBegin)
+  float bvh_half_diag;
+  float bvh_inv_rmin;                           // 1 / smallest sphere radius ; 0 when the scene has no spheres
   const DevLight* __restrict__ lights;          // light tracing
   uint32_t n_lights;
   float total_power;
@@ -138,6 +141,7 @@ struct DevScene {
   DevSensor sensor;
 };
 
+#define AMBER_PHONG_MAX_TRIES 1024
 enum { PRIM_TRIANGLE = 0, PRIM_SPHERE = 1, PRIM_DISK = 2, PRIM_CYLINDER = 3 };
 enum { MAT_LAMBERTIAN = 0, MAT_PHONG = 1, MAT_SPECULAR = 2, MAT_REFRACTION = 3, MAT_DIFFUSE_LIGHT = 4, MAT_EYE = 5 };
 
@@ -494,24 +498,18 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
 #ifndef AMBER_BVH_STACK
 #define AMBER_BVH_STACK 32
 #endif
-// Packed FMAs (v_pk_fma_f32) save 6 of ~45 VALU instructions per node but cost two more live registers: at the 96-VGPR
-// cap of pt_bvh_megakernel that is 32 B of scratch instead of 16 B, and config 3 runs 1.7 % slower (159.3 vs 156.6 ms).
-#ifndef AMBER_BVH_PACKED
-#define AMBER_BVH_PACKED 0
-#endif
-typedef float F2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ F2 f2(float x, float y) { F2 r = {x, y}; return r; }
-
 // Slab test of one child box from its six plane parameters t = (plane - o) / d, computed by the caller as one FMA per
-// plane, plane * inv - o * inv (packed).  Culling only has to be conservative; the extra rounding of the FMA form is
-// covered by the slack and by the padded boxes: the entry is lowered and the exit raised by 2^-20 of their own
-// magnitude plus slack_abs = 2^-20 * max|o/d| (a bound on the absolute error inherited from o/d).  Axes the ray is
-// parallel to arrive as NaN planes (BvhBegin) and min/max skip them.  NaN anywhere -> treated as a hit.
+// plane (plane * inv - o * inv).  Culling only has to be conservative; the extra rounding of the FMA form is covered by
+// the slack and by the padded boxes: the entry is lowered and the exit raised by 2^-20 of their own magnitude plus
+// slack_abs (per ray, BvhBegin).  Axes the ray is parallel to arrive as NaN planes and min/max skip them.
+// NaN anywhere -> treated as a hit.  (Packed v_pk_fma_f32 evaluation of the planes was tried: 6 fewer VALU
+// instructions per node but two more live registers, 1.7 % slower at the kernel's register cap.)
+#define AMBER_BVH_REL_SLACK 9.5367431640625e-07f   /* 2^-20: rounding of the one-FMA plane parameters; 2^-16 costs 13 % on config 3 (the absolute part scales with |o/d|) */
 __device__ __forceinline__ void SlabDecide(float x0, float x1, float y0, float y1, float z0, float z1, float slack_abs, float t_best, bool& hit, float& t_in) {
   float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
   float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-  tn = __builtin_fmaf(tn, -9.5367431640625e-07f, tn - slack_abs);            // tn >= 0
-  tf = __builtin_fmaf(Abs(tf), 9.5367431640625e-07f, tf + slack_abs);
+  tn = __builtin_fmaf(tn, -AMBER_BVH_REL_SLACK, tn - slack_abs);            // tn >= 0
+  tf = __builtin_fmaf(Abs(tf), AMBER_BVH_REL_SLACK, tf + slack_abs);
   t_in = tn;
   hit = !(tn > tf) && !(tn > t_best);
 }
@@ -529,17 +527,17 @@ __device__ __forceinline__ void ClosestHitLeafList(const DevScene& sc, V3 o, V3 
 // Traversal state of one ray.  It lives in registers (+ the lane's LDS stack) so that a traversal can be suspended
 // while other lanes of the wave are shaded (pt_bvh_megakernel) and resumed afterwards.
 struct BvhTrav {
-  F2 inv_xy, oi_xy;    // (1/d.x, 1/d.y) and (o.x/d.x, o.y/d.y): packed slab-test operands
-  F2 inv_zz, oi_zz;    // (1/d.z, 1/d.z) and (o.z/d.z, o.z/d.z)
-  float slack_abs;     // 2^-20 * max |o/d| over the axes that take part (rounding slack of the slab test)
-  int32_t cur;         // >= 0 inner node, < 0 leaf reference, kBvhDone finished
+  V3 inv;              // 1/d
+  V3 oi_mn, oi_mx;     // o/d + E/d and o/d - E/d: offsets of the min and max planes of boxes widened by the per-ray margin E
+  float slack_abs;     // absolute widening of [t_in, t_out] for this ray (BvhBegin)
+  int32_t cur;         // >= 0 inner node, < 0 leaf reference, AMBER_BVH_DONE finished
   int sp;              // entries on the lane's stack
   bool overflow;       // the stack was too small (cannot happen with the builder's depth cap): fall back to the list scan
 };
 #define AMBER_BVH_DONE 0x7fffffff
 
-__device__ __forceinline__ void BvhBegin(const DevScene& sc, V3 o, V3 d, BvhTrav& tr, HitRec& best) {
-  best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;
+// Slab-test operands of a ray.
+__device__ __forceinline__ void BvhOperands(const DevScene& sc, V3 o, V3 d, BvhTrav& tr) {
   V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   V3 oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
   // An axis whose 1/d or o/d is not finite (d component 0 or denormal, huge origin) is taken OUT of the slab test by
@@ -554,9 +552,44 @@ __device__ __forceinline__ void BvhBegin(const DevScene& sc, V3 o, V3 d, BvhTrav
   if (!(Abs(inv.z) < 3.0e38f) || !(Abs(oi.z) < 3.0e38f)) { inv.z = kNaN; oi.z = kNaN; }
   float mag = __builtin_fmaxf(__builtin_fmaxf(Abs(oi.x), Abs(oi.y)), Abs(oi.z));    // fmax skips the NaN axes
   if (!(mag == mag)) mag = 0.0f;                                                      // no axis takes part
-  tr.slack_abs = 9.5367431640625e-07f * mag;
-  tr.inv_xy = f2(inv.x, inv.y); tr.oi_xy = f2(oi.x, oi.y);
-  tr.inv_zz = f2(inv.z, inv.z); tr.oi_zz = f2(oi.z, oi.z);
+  float slack = AMBER_BVH_REL_SLACK * mag;
+  // Direction length.  The reference never renormalises sampled directions (vector3.h:236-239) and its sphere test
+  // assumes |d| = 1 (a = 1 in SolveQuadratic, primitive_sphere.cc:80-83): with |d|^2 = 1 + delta it accepts a ray whose
+  // closest approach p to the centre, at distance s along the ray, satisfies p^2 <= r^2 + delta * s^2 (+ rounding, which
+  // the sphere's box already covers).  delta is 1e-7 .. 5e-6 on ordinary paths (oracle_direction_length_stats) and
+  // anything at all in scenes with non-unit disk normals.  The ray must therefore be allowed to miss a sphere's box by
+  // E = sqrt(r^2 + delta s^2) - r <= min(delta * S^2 / r_min, sqrt(delta) * S), where S = |o - scene centre| + half the
+  // scene diagonal bounds s (no point of the scene is farther from the origin) and r_min is the smallest sphere radius
+  // (no spheres: E = 0).  (Shrinking S to the best hit distance as the traversal goes was tried: the recomputation in
+  // the leaf loop costs 50 B of scratch and 35 % of the speed.)
+  // Widening every box by E costs nothing per node: (mn - E) * inv - o * inv = mn * inv - (o * inv + E * inv), so the
+  // margin moves into two offset vectors, one for the min planes and one for the max planes (adding E * max|1/d| to
+  // the slack instead needs no registers, but a ray with one tiny direction component then gets an enormous slack
+  // and walks the whole tree -- measured: config 3 four times slower).
+  // t itself is measured in units of |d|: the reference's sphere distance and the geometric entry into the sphere's
+  // box differ by a relative |delta|, which joins the slack as the absolute term 2 |delta| * S / |d|.
+  const float len2 = d.x * d.x + d.y * d.y + d.z * d.z;
+  const float delta = len2 - 1.0f;
+  V3 omn = oi, omx = oi;
+  if (sc.bvh_inv_rmin > 0.0f && !(Abs(delta) <= 2.0e-8f)) {                          // NaN delta: nan_ray in BvhBegin
+    const float cx = o.x - sc.bvh_center[0], cy = o.y - sc.bvh_center[1], cz = o.z - sc.bvh_center[2];
+    const float S = 1.001f * (__builtin_amdgcn_sqrtf(cx * cx + cy * cy + cz * cz) + sc.bvh_half_diag);
+    const float dpos = delta > 0.0f ? delta : 0.0f;
+    const float E = 1.001f * __builtin_fminf(dpos * S * S * sc.bvh_inv_rmin, __builtin_amdgcn_sqrtf(dpos) * S);
+    const V3 ei = v3(E * inv.x, E * inv.y, E * inv.z);                                // NaN on axes taken out above: stays NaN
+    omn = v3(oi.x + ei.x, oi.y + ei.y, oi.z + ei.z); omx = v3(oi.x - ei.x, oi.y - ei.y, oi.z - ei.z);
+    if (!(Abs(omn.x) < 3.0e38f) || !(Abs(omx.x) < 3.0e38f)) { inv.x = kNaN; omn.x = kNaN; omx.x = kNaN; }
+    if (!(Abs(omn.y) < 3.0e38f) || !(Abs(omx.y) < 3.0e38f)) { inv.y = kNaN; omn.y = kNaN; omx.y = kNaN; }
+    if (!(Abs(omn.z) < 3.0e38f) || !(Abs(omx.z) < 3.0e38f)) { inv.z = kNaN; omn.z = kNaN; omx.z = kNaN; }
+    slack += 2.0f * Abs(delta) * S * __builtin_amdgcn_rsqf(__builtin_fminf(len2, 1.0f));   // t <= S / |d|
+  }
+  tr.slack_abs = slack;
+  tr.inv = inv; tr.oi_mn = omn; tr.oi_mx = omx;
+}
+
+__device__ __forceinline__ void BvhBegin(const DevScene& sc, V3 o, V3 d, BvhTrav& tr, HitRec& best) {
+  best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;
+  BvhOperands(sc, o, d, tr);
   // A ray with a NaN component cannot hit anything: every exact test forms dot products over all components of o and
   // d, so every t it computes is NaN, and Closer() never accepts a NaN t (the List scan returns "no hit" too).
   const bool nan_ray = !(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z);
@@ -583,19 +616,13 @@ __device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack,
     const float4 c = *reinterpret_cast<const float4*>(nd->z);
     const int2 kids = *reinterpret_cast<const int2*>(&nd->left);
     const int32_t left = kids.x, right = kids.y;
-#if AMBER_BVH_PACKED
-    const F2 lmn = __builtin_elementwise_fma(f2(a.x, a.y), tr.inv_xy, -tr.oi_xy), lmx = __builtin_elementwise_fma(f2(a.z, a.w), tr.inv_xy, -tr.oi_xy);
-    const F2 rmn = __builtin_elementwise_fma(f2(b.x, b.y), tr.inv_xy, -tr.oi_xy), rmx = __builtin_elementwise_fma(f2(b.z, b.w), tr.inv_xy, -tr.oi_xy);
-    const F2 lz = __builtin_elementwise_fma(f2(c.x, c.y), tr.inv_zz, -tr.oi_zz), rz = __builtin_elementwise_fma(f2(c.z, c.w), tr.inv_zz, -tr.oi_zz);
-#else
-    const float ix = tr.inv_xy.x, iy = tr.inv_xy.y, iz = tr.inv_zz.x, ox = tr.oi_xy.x, oy = tr.oi_xy.y, oz = tr.oi_zz.x;
-    const F2 lmn = f2(__builtin_fmaf(a.x, ix, -ox), __builtin_fmaf(a.y, iy, -oy)), lmx = f2(__builtin_fmaf(a.z, ix, -ox), __builtin_fmaf(a.w, iy, -oy));
-    const F2 rmn = f2(__builtin_fmaf(b.x, ix, -ox), __builtin_fmaf(b.y, iy, -oy)), rmx = f2(__builtin_fmaf(b.z, ix, -ox), __builtin_fmaf(b.w, iy, -oy));
-    const F2 lz = f2(__builtin_fmaf(c.x, iz, -oz), __builtin_fmaf(c.y, iz, -oz)), rz = f2(__builtin_fmaf(c.z, iz, -oz), __builtin_fmaf(c.w, iz, -oz));
-#endif
+    // child planes: lxy = (min.x, min.y, max.x, max.y), z = (left min.z, left max.z, right min.z, right max.z)
+    const float lx0 = __builtin_fmaf(a.x, tr.inv.x, -tr.oi_mn.x), ly0 = __builtin_fmaf(a.y, tr.inv.y, -tr.oi_mn.y), lx1 = __builtin_fmaf(a.z, tr.inv.x, -tr.oi_mx.x), ly1 = __builtin_fmaf(a.w, tr.inv.y, -tr.oi_mx.y);
+    const float rx0 = __builtin_fmaf(b.x, tr.inv.x, -tr.oi_mn.x), ry0 = __builtin_fmaf(b.y, tr.inv.y, -tr.oi_mn.y), rx1 = __builtin_fmaf(b.z, tr.inv.x, -tr.oi_mx.x), ry1 = __builtin_fmaf(b.w, tr.inv.y, -tr.oi_mx.y);
+    const float lz0 = __builtin_fmaf(c.x, tr.inv.z, -tr.oi_mn.z), lz1 = __builtin_fmaf(c.y, tr.inv.z, -tr.oi_mx.z), rz0 = __builtin_fmaf(c.z, tr.inv.z, -tr.oi_mn.z), rz1 = __builtin_fmaf(c.w, tr.inv.z, -tr.oi_mx.z);
     bool hl, hr; float tl, tr_;
-    SlabDecide(lmn.x, lmx.x, lmn.y, lmx.y, lz.x, lz.y, tr.slack_abs, best.t, hl, tl);
-    SlabDecide(rmn.x, rmx.x, rmn.y, rmx.y, rz.x, rz.y, tr.slack_abs, best.t, hr, tr_);
+    SlabDecide(lx0, lx1, ly0, ly1, lz0, lz1, tr.slack_abs, best.t, hl, tl);
+    SlabDecide(rx0, rx1, ry0, ry1, rz0, rz1, tr.slack_abs, best.t, hr, tr_);
     if (hl && hr) {
       const bool left_first = !(tr_ < tl);
       const int32_t near_ = left_first ? left : right, far_ = left_first ? right : left;
@@ -726,7 +753,10 @@ __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 
     const float signed_cos_o = Dot(dir_out, normal);
     const V3 w = phong ? PerfectReflection(dir_out, normal, signed_cos_o) : (signed_cos_o > 0.0f ? normal : -normal);
     V3 u, v; OrthonormalBasis(w, u, v);                  // CosinePower rebuilds the same basis on every attempt
-    for (;;) {
+    // The reference's Phong loop re-samples forever when no direction of the lobe lies on dir_out's side (possible with a
+    // normal that is not of unit length); a kernel must terminate, so attempt AMBER_PHONG_MAX_TRIES is accepted as it
+    // is (the oracle does the same; with a proper normal at least half of the lobe is acceptable: probability 2^-1024).
+    for (int attempt = 1;; ++attempt) {
       const float r0 = Uniform(rng);
       const float r1 = Uniform(rng);
       float cos_theta, sin_theta;
@@ -742,7 +772,7 @@ __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 
       const V3 di = u * sin_theta * cp + v * sin_theta * sp + w * cos_theta;
       if (!phong) { dir_in = di; weight = 1.0f * rho; break; }
       const float signed_cos_i = Dot(di, normal);
-      if (signed_cos_o * signed_cos_i <= 0.0f) continue;
+      if (signed_cos_o * signed_cos_i <= 0.0f && attempt < AMBER_PHONG_MAX_TRIES) continue;
       dir_in = di;
       weight = ((m.param + 2.0f) / (m.param + 1.0f) * Abs(signed_cos_i)) * rho;
       break;

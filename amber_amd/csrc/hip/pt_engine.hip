@@ -198,13 +198,14 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? 5 : 4) pt_bvh_megakernel(c
   uint32_t pool_next = 0, pool_end = 0;
   bool exhausted = false;
   bool lane_done = false, have_item = false, alive = false, traversing = false;
-  uint32_t s = 0, s_end = 0, px = 0, py = 0, pixel = 0, slot = 0;
+  uint32_t s = 0, s_end = 0, pixel = 0, slot = 0;          // the pixel's x, y are recomputed where a path starts: two registers less
   V3 sum = v3(0.f, 0.f, 0.f), meas = v3(0.f, 0.f, 0.f);
   V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), w = v3(0.f, 0.f, 0.f);
   uint64_t rng = 1;
-  uint32_t casts = 0, rays = 0;
+  uint32_t casts = 0;
+  uint32_t rays_wave = 0;                                   // wave-uniform (SGPR): rays shaded by this wave
   int origin_slot = -1;
-  BvhTrav tr; tr.inv_xy = f2(0.f, 0.f); tr.oi_xy = f2(0.f, 0.f); tr.inv_zz = f2(0.f, 0.f); tr.oi_zz = f2(0.f, 0.f); tr.slack_abs = 0.f;
+  BvhTrav tr; tr.inv = v3(0.f, 0.f, 0.f); tr.oi_mn = v3(0.f, 0.f, 0.f); tr.oi_mx = v3(0.f, 0.f, 0.f); tr.slack_abs = 0.f;
   tr.cur = AMBER_BVH_DONE; tr.sp = 0; tr.overflow = false;
   HitRec hit; hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.idx = -1; hit.slot = -1;
 #ifdef AMBER_STAMPS
@@ -239,8 +240,8 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? 5 : 4) pt_bvh_megakernel(c
         const uint32_t item = pool_next + rank;
         const uint32_t plocal = item / a.n_chunks, chunk = item - plocal * a.n_chunks;
         const uint32_t lrow = plocal / sc.sensor.w;
-        px = plocal - lrow * sc.sensor.w;
-        py = a.row_begin + (a.stripe_rows ? (lrow / a.stripe_rows) * a.stripe_period + lrow % a.stripe_rows : lrow);
+        const uint32_t px = plocal - lrow * sc.sensor.w;
+        const uint32_t py = a.row_begin + (a.stripe_rows ? (lrow / a.stripe_rows) * a.stripe_period + lrow % a.stripe_rows : lrow);
         pixel = px + py * sc.sensor.w;
         slot = chunk * a.n_pixels + plocal;
         s = a.first_sample + chunk * AMBER_ACCUM_CHUNK;
@@ -263,7 +264,8 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? 5 : 4) pt_bvh_megakernel(c
         GenerateLightRay(sc, rng, o, d, w, origin_slot);
       } else {
         float ew;
-        GenerateEyeRay(sc, px, py, rng, o, d, ew, origin_slot);
+        const uint32_t py = pixel / sc.sensor.w;
+        GenerateEyeRay(sc, pixel - py * sc.sensor.w, py, rng, o, d, ew, origin_slot);
         w = v3(ew, ew, ew);
       }
       meas = v3(0.f, 0.f, 0.f);
@@ -284,6 +286,7 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? 5 : 4) pt_bvh_megakernel(c
       }
     }
 
+    rays_wave += static_cast<uint32_t>(__popcll(__ballot(alive && !traversing)));
     if (alive && !traversing) {                             // shade the lanes whose closest hit is known
       if (kLight) {
         const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, pixel, s - 1u, sc.sensor.size_f};
@@ -291,15 +294,12 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? 5 : 4) pt_bvh_megakernel(c
       } else {
         alive = PathShade<false, ENGINE_BVH, false>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, nullptr);
       }
-      ++rays;
       if (alive) { BvhBegin(sc, o, d, tr, hit); traversing = true; }
       else sum = sum + meas;                                // sequential sum over the item's samples
     }
   }
 
-  unsigned long long r = rays;
-  for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
-  if (lane == 0 && r) atomicAdd(a.ray_count, r);
+  if (lane == 0 && rays_wave) atomicAdd(a.ray_count, static_cast<unsigned long long>(rays_wave));
 }
 
 // fb[e] += partial[0][e] + partial[1][e] + ... in chunk order (e = pixel*3 + channel of the band)
@@ -670,6 +670,17 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.planes = h->d_planes; sc.tri_filters = h->d_tri_filters; sc.sphere_filters = h->d_sphere_filters;
   sc.n_planes = static_cast<uint32_t>(fprog.planes.size()); sc.n_sphere_filters = static_cast<uint32_t>(fprog.spheres.size());
   sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_root = bvh.root_ref;
+  {
+    // per-ray box margin of engine BVH (BvhBegin): centre and half diagonal of the scene bounds, 1 / smallest sphere radius
+    double d2 = 0;
+    for (int c = 0; c < 3; c++) {
+      sc.bvh_center[c] = 0.5f * (bvh.bounds_min[c] + bvh.bounds_max[c]);
+      const double e = double(bvh.bounds_max[c]) - bvh.bounds_min[c];
+      d2 += e * e;
+    }
+    sc.bvh_half_diag = static_cast<float>(0.5 * std::sqrt(d2) * 1.0001);
+    sc.bvh_inv_rmin = !bvh.has_spheres ? 0.0f : (bvh.min_sphere_radius > 0 ? static_cast<float>(std::min(3.0e38, 1.0001 / bvh.min_sphere_radius)) : 3.0e38f);
+  }
   sc.lights = h->d_lights; sc.n_lights = s->n_lights; sc.total_power = s->n_lights ? s->lights[s->n_lights - 1].cum_power : 0.0f;
   sc.n_prog_tris = fprog.n_prog_tris; sc.always_mask = fprog.always_mask; sc.prog_objects = h->d_prog_objects;
   sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;

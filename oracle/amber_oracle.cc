@@ -531,10 +531,13 @@ Scatter SampleLight(const Material& m, V3 normal, V3 dir_out, Sampler& smp, cons
     case ORACLE_MAT_PHONG: {                                            // material_phong.cc:81-106
       const V3 refl = PerfectReflection(dir_out, normal, Dot(dir_out, normal));
       const float signed_cos_o = Dot(dir_out, normal);
-      for (;;) {
+      // The reference re-samples until the direction is on dir_out's side -- forever when that cannot happen (a
+      // normal that is not of unit length can put the whole lobe on the other side).  The device engine must
+      // terminate, so both sides accept attempt number ORACLE_PHONG_MAX_TRIES as it is (probability 2^-1024 otherwise).
+      for (int attempt = 1;; ++attempt) {
         const V3 dir_in = CosinePower(refl, m.param, smp, M);
         const float signed_cos_i = Dot(dir_in, normal);
-        if (signed_cos_o * signed_cos_i <= 0) continue;
+        if (signed_cos_o * signed_cos_i <= 0 && attempt < ORACLE_PHONG_MAX_TRIES) continue;
         sc.dir = dir_in;
         sc.weight = ((m.param + 2) / (m.param + 1) * std::abs(signed_cos_i)) * m.rho;
         return sc;
@@ -836,6 +839,12 @@ namespace {
 
 struct PathResult { V3 measurement; uint32_t casts, hits; };
 
+// Diagnostic (oracle_direction_length_stats, single-threaded): histogram of | |d|^2 - 1 | over the rays that are cast.
+// The reference never renormalises sampled directions (vector3.h:236-239); engine BVH's sphere bounds depend on how
+// far from unit length they drift.
+struct DirStats { uint64_t rays = 0, above[6] = {0, 0, 0, 0, 0, 0}; double max_dev = 0; };
+DirStats* g_dir_stats = nullptr;
+
 // PathTracing::Thread::Render algorithm_pt.cc:125-160.  max_depth == 0 means RR-only (reference).
 PathResult TracePath(const oracle_scene& sc, const Sensor& S, uint64_t px, uint64_t py, Sampler& smp,
                      const Math& M, uint32_t max_depth, oracle_bounce* trace, uint32_t max_trace,
@@ -850,6 +859,13 @@ PathResult TracePath(const oracle_scene& sc, const Sensor& S, uint64_t px, uint6
   V3 weight = splat(eye.weight);                                        // Leading<Radiant>(.., Radiant(weight))
   PathResult r{splat(0), 0, 0};
   for (;;) {
+    if (g_dir_stats) {
+      const double dev = std::fabs(double(ray.d.x) * ray.d.x + double(ray.d.y) * ray.d.y + double(ray.d.z) * ray.d.z - 1.0);
+      static const double kEdges[6] = {1e-7, 3e-7, 1e-6, 3e-6, 1e-5, 1e-4};
+      g_dir_stats->rays++;
+      for (int k = 0; k < 6; k++) if (dev > kEdges[k]) g_dir_stats->above[k]++;
+      if (dev > g_dir_stats->max_dev) g_dir_stats->max_dev = dev;
+    }
     Hit hit; const Object* obj = nullptr;
     sc.Cast(ray, hit, obj);
     r.casts++;
@@ -1265,3 +1281,24 @@ uint64_t oracle_fnv1a64(const void* data, uint64_t n_bytes) {
 }
 
 }  // extern "C"
+
+
+// Diagnostic: | |d|^2 - 1 | of every ray of a single-threaded XorShift-mode render.  out[0] = rays, out[1..6] = rays
+// above 1e-7, 3e-7, 1e-6, 3e-6, 1e-5, 1e-4, out[7] = maximum.
+extern "C" void oracle_direction_length_stats(const oracle_scene* sc, const oracle_sensor* sensor, uint64_t seed, uint32_t first_sample,
+                                              uint32_t n_samples, int math, double out[8]) {
+  const Sensor S{sensor->width, sensor->height, sensor->scene_width, sensor->scene_height};
+  const Math M{math};
+  DirStats st;
+  g_dir_stats = &st;
+  for (uint32_t y = 0; y < S.h; y++)
+    for (uint32_t x = 0; x < S.w; x++)
+      for (uint32_t s = first_sample; s < first_sample + n_samples; s++) {
+        XorShiftSampler smp(XorShiftSeed(seed, x + y * S.w, s));
+        (void)TracePath(*sc, S, x, y, smp, M, 0, nullptr, 0, nullptr);
+      }
+  g_dir_stats = nullptr;
+  out[0] = static_cast<double>(st.rays);
+  for (int k = 0; k < 6; k++) out[1 + k] = static_cast<double>(st.above[k]);
+  out[7] = st.max_dev;
+}

@@ -61,6 +61,8 @@ typedef struct {
 
 /* modes */
 enum { ORACLE_ACCEL_BVH = 0, ORACLE_ACCEL_LIST = 1 };
+/* Phong rejection sampling (material_phong.cc:81-106) gives up re-sampling at this attempt; same constant on the device */
+#define ORACLE_PHONG_MAX_TRIES 1024
 /* OR into `accel` of oracle_scene_create: append the aperture blades AFTER the objects, the order cli::ImportScene
  * produces (import.cc:155-157); default is blades first (cornel_box.cc:62-64). */
 enum { ORACLE_BLADES_LAST = 0x100 };
