@@ -11,6 +11,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n_scenes = int(args[0]) if args else 200
 first_seed = int(args[1]) if len(args) > 1 else 0
 use_oracle = "--oracle" in sys.argv
+use_lt = "--lt" in sys.argv           # also compare light tracing (splat records) between the work-queue engines
 if use_oracle:
     sys.path.insert(0, os.path.join(R, "tests"))
     import oracle_binding as O
@@ -42,6 +43,17 @@ for seed in range(first_seed, first_seed + n_scenes):
             bad = np.argwhere(img.view(np.uint32) != ref[0])
             print("MISMATCH seed %d engine %d vs LIST: rays %d vs %d, %d differing values, first at %s" % (seed, e, rays, ref[1], len(bad), bad[:3].tolist()), flush=True)
             sys.exit(1)
+    if use_lt:
+        lref = None
+        lt_depth = int(rng.integers(0, 2)) * 5
+        for e in [x for x in engines if x != A.ENGINE_WAVEFRONT]:
+            pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=seed, engine=e, max_depth=lt_depth)
+            rec, lrays = pt.lt_trace(0, 3, capacity=1 << 14); pt.close()
+            if lref is None:
+                lref = (rec.tobytes(), lrays)
+            elif lrays != lref[1] or rec.tobytes() != lref[0]:
+                print("LT MISMATCH seed %d engine %d vs LIST: rays %d vs %d, %d records" % (seed, e, lrays, lref[1], len(rec)), flush=True)
+                sys.exit(1)
     if use_oracle and seed % 8 == 0 and not big:
         osc = O.Scene.create(**sc)
         oimg, cnt = osc.render_xorshift(W, H, seed, 0, spp)
