@@ -86,7 +86,7 @@ void ReadMtl(const std::string& path, std::vector<MtlEntry>& out) {
     else if (key == "Kd") color(cur->diffuse);
     else if (key == "Pr") scalar(cur->reflectivity, cur->has_reflectivity);
     else if (key == "Ns") scalar(cur->shininess, cur->has_shininess);
-    else if (key == "illum") { float x; scalar(x, cur->has_shading); cur->illum = static_cast<int>(x); }
+    else if (key == "illum") { float x; scalar(x, cur->has_shading); cur->illum = (x >= 0.0f && x < 1000.0f) ? static_cast<int>(x) : 0; }
     // Ka, Ni, d, Tr, Tf, map_*: not read by import.cc ("TODO refraction", import.cc:73)
   }
 }

@@ -5,6 +5,9 @@
 #include <random>
 #include <vector>
 
+#include <fstream>
+#include <string>
+#include "../amber_amd/csrc/amber/import.h"
 #include "../amber_amd/csrc/amber/postprocess.h"
 #include "../amber_amd/csrc/amber/rendering.h"
 #include "../amber_amd/csrc/amber/scene.h"
@@ -120,6 +123,45 @@ int main() {
     cli::ExportPNG(postprocess::Gamma()(postprocess::Filmic()(img)), "/tmp/amber_sanitize.png");
     cli::ExportEXR(img, "/tmp/amber_sanitize.exr");
     std::printf("ok   png/exr writers\n");
+  }
+  // 5. scene import: well-formed, malformed and random inputs must parse or throw, never read out of bounds
+  {
+    const std::string dir = "/tmp/amber_sanitize_import";
+    (void)std::system(("mkdir -p " + dir).c_str());
+    auto write = [&](const std::string& name, const std::string& text) { std::ofstream f(dir + "/" + name, std::ios::binary); f << text; };
+    const std::string cam = "#camera 0 0 4 0 0 -1 0 1 0\n";
+    const char* cases[] = {
+        "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n",                                  // no camera
+        "#camera 1 2 3\nv 0 0 0\n",                                                // short camera
+        "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n",                                  // index out of range
+        "v 0 0 0\nv 1 0 0\nv 0 1 0\nf -1 -2 -7\n",                               // negative index out of range
+        "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 0 1 2\n",                                  // index 0
+        "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1/ 2//3 3/x\n",                            // malformed corners
+        "v 1e400 nan inf\nv 1 0 0\nv 0 1 0\nf 1 2 3\n",                          // overflowing / non-finite coordinates
+        "v 0 0\n", "f\n", "f 1\n", "usemtl\nmtllib\no\ng\n", "\r\n\r\n#\n", "",
+        "mtllib self.mtl\nusemtl a\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nv 2 2 0\nf 1 2 3 4 5\nf -1 -2 -3\n",
+    };
+    write("self.mtl", "newmtl a\nKd 1 1\n");                                     // malformed colour -> error
+    int parsed = 0, thrown = 0;
+    for (size_t i = 0; i < sizeof cases / sizeof cases[0]; i++) {
+      for (int with_cam = 0; with_cam < 2; with_cam++) {
+        write("case.obj", (with_cam ? cam : std::string()) + cases[i]);
+        try { auto sc = cli::ImportSceneBVH(dir + "/case.obj"); (void)sc.Flatten(); parsed++; } catch (const std::exception&) { thrown++; }
+      }
+    }
+    write("self.mtl", "newmtl a\nKd 1 1 1\nKe 0 0 0\nKr 1 1 1\nPr 0.5\nKs 1 1 1\nNs 10\nillum 2\nnewmtl\nnewmtl b\nNs\n");
+    try { (void)cli::ImportSceneBVH(dir + "/case.obj"); parsed++; } catch (const std::exception&) { thrown++; }
+    std::mt19937 rng(11);
+    const char alphabet[] = "vf 0123456789.-/e\n\n #camtlibuseongKdsr";
+    for (int rep = 0; rep < 300; rep++) {
+      std::string text = rep % 2 ? cam : std::string();
+      const int len = static_cast<int>(rng() % 400);
+      for (int k = 0; k < len; k++) text += alphabet[rng() % (sizeof alphabet - 1)];
+      write("rand.obj", text);
+      try { auto sc = cli::ImportSceneBVH(dir + "/rand.obj"); (void)sc.Flatten(); parsed++; } catch (const std::exception&) { thrown++; }
+    }
+    if (parsed == 0 || thrown == 0) { std::printf("FAIL import fuzz: parsed %d thrown %d\n", parsed, thrown); return 1; }
+    std::printf("ok   scene import: %d inputs parsed, %d rejected with an exception\n", parsed, thrown);
   }
   std::printf("ALL OK\n");
   return 0;

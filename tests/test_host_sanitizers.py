@@ -13,7 +13,7 @@ ROOT = Path(__file__).resolve().parent.parent
 def test_host_code_under_asan_ubsan(tmp_path):
     exe = tmp_path / "host_sanitize"
     srcs = [ROOT / "tests" / "host_sanitize.hip", ROOT / "amber_amd" / "csrc" / "amber" / "amber_host.cc",
-            ROOT / "amber_amd" / "csrc" / "amber" / "postprocess.cc"]
+            ROOT / "amber_amd" / "csrc" / "amber" / "postprocess.cc", ROOT / "amber_amd" / "csrc" / "amber" / "import.cc"]
     # amber_host.cc references the C ABI; the driver never renders, so resolve it against the real library
     cmd = ["hipcc", "--cuda-host-only", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
            "-fno-sanitize-recover=undefined", "-o", str(exe)] + [str(s) for s in srcs] + \
