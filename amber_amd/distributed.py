@@ -53,14 +53,15 @@ class RowGatherer:
     (tensor (n_r, width, 3) on the backend's device) to rank `dst` and scatters them to their global row positions.
     At 8 ranks a Cornell step is 13 ms per rank, so per-step allocations and index uploads would show."""
 
-    def __init__(self, parts, width: int, rank: int, world_size: int, device, dst: int = 0):
+    def __init__(self, parts, width: int, rank: int, world_size: int, device, dst: int = 0, force_collective: bool = False):
         import torch
 
         self.parts, self.width, self.rank, self.world, self.dst = parts, width, rank, world_size, dst
         self.n = len(parts[rank]["index"])
         self.max_rows = max(len(p["index"]) for p in parts)
         self.height = sum(len(p["index"]) for p in parts)
-        if world_size > 1:
+        self.collective = world_size > 1 or force_collective     # force_collective: run the gather even for one rank (RCCL smoke test)
+        if self.collective:
             self.send = torch.zeros((self.max_rows, width, 3), dtype=torch.float32, device=device)
             if rank == dst:
                 self.recv = [torch.empty_like(self.send) for _ in range(world_size)]
@@ -71,7 +72,7 @@ class RowGatherer:
         """Returns the (height, width, 3) image on `dst` (a buffer reused by the next call), None elsewhere."""
         import torch.distributed as dist
 
-        if self.world == 1:
+        if not self.collective:
             return local_rows.reshape(self.n, self.width, 3)
         if self.n:
             self.send[: self.n].copy_(local_rows.reshape(self.n, self.width, 3))

@@ -110,7 +110,16 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_collective = world == 1 and os.environ.get("AMBER_BENCH_FORCE_COLLECTIVE") == "1"   # one-rank RCCL rehearsal of the N > 1 code path
+    if force_collective:
+        os.environ.setdefault("MASTER_PORT", "29571")
+    json_fd = 1
+    if world > 1 or force_collective:
+        # RCCL prints a version banner on STDOUT when the communicator is created; the contract is ONE JSON line on
+        # stdout, so everything else written to fd 1 from here on goes to stderr and the JSON line to the saved fd
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse_on_one_gpu:
@@ -128,7 +137,7 @@ def main():
                                   stream=stream, engine={"auto": 0, "list": 1, "two_phase": 2, "bvh": 3, "wavefront": 4}[args.engine])
     fb = band_tensor(tracer, f"cuda:{local_rank}")
     launches = [(s, min(args.spp_per_launch, args.spp - s)) for s in range(0, args.spp, args.spp_per_launch)]
-    gather = RowGatherer(parts, W, rank, world, "cpu" if (args.rehearse_on_one_gpu and world > 1) else fb.device)   # buffers allocated once
+    gather = RowGatherer(parts, W, rank, world, "cpu" if (args.rehearse_on_one_gpu and world > 1) else fb.device, force_collective=force_collective)   # buffers allocated once
 
     def step():
         tracer.clear()
@@ -212,7 +221,8 @@ def main():
                 out["roofline"]["measured_copy_bw_error"] = str(e)[:120]
         if not args.no_cpu_baseline and world == 1:                    # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(W, args.seed)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
