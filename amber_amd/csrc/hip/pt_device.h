@@ -129,6 +129,8 @@ struct DevScene {
   const uint32_t* __restrict__ bvh_prims;       // leaf order -> object index
   const DevObject* __restrict__ bvh_objects;    // the object records in leaf order (HitRec.slot of engine BVH indexes this array)
   int32_t bvh_root;                             // child reference of the whole scene
+  float fp_center[3];                           // two-phase filter: rays whose origin is farther than fp_reach (max norm) from here,
+  float fp_reach;                               // or with |d| > 2, bypass the filter (all objects become candidates)
   float bvh_center[3];                          // centre and half diagonal of the scene bounds (per-ray box margin, BvhBegin)
   float bvh_half_diag;
   float bvh_inv_rmin;                           // 1 / smallest sphere radius ; 0 when the scene has no spheres
@@ -447,6 +449,14 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
       const bool miss = (__builtin_fmaf(bb, bb, -cc) < -tol) || (bb < 0.0f && cc > tol);  // no real root | both roots behind
       cand |= miss ? 0u : bit;                                                            // NaN -> keep
     }
+  }
+  // The filter's tolerances are derived for rays of the scene: origin within the model box, |d| <= 2 (DESIGN.md section
+  // 5).  Anything else -- possible only when a scene hands the reference non-unit normals, whose sphere test then
+  // reports "hits" far outside the scene -- skips the filter: every object becomes a candidate for the exact tests.
+  {
+    const float ex = Abs(o.x - sc.fp_center[0]), ey = Abs(o.y - sc.fp_center[1]), ez = Abs(o.z - sc.fp_center[2]);
+    const bool in_model = __builtin_fmaxf(__builtin_fmaxf(ex, ey), ez) <= sc.fp_reach && (d.x * d.x + d.y * d.y + d.z * d.z) <= 4.0f;   // NaN -> false
+    if (!in_model) cand = sc.n_objects >= 32u ? 0xffffffffu : ((1u << sc.n_objects) - 1u);
   }
   AMBER_STAMP(2);
   // Self trip.  A ray that leaves a triangle always re-selects that triangle in Phase A (t' ~ 0), and the exact test

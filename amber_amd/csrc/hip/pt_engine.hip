@@ -681,6 +681,17 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     sc.bvh_half_diag = static_cast<float>(0.5 * std::sqrt(d2) * 1.0001);
     sc.bvh_inv_rmin = !bvh.has_spheres ? 0.0f : (bvh.min_sphere_radius > 0 ? static_cast<float>(std::min(3.0e38, 1.0001 / bvh.min_sphere_radius)) : 3.0e38f);
   }
+  {
+    // model box of the two-phase filter: bounds of every object and of the lens, doubled
+    double lo[3] = {L.origin[0], L.origin[1], L.origin[2]}, hi[3] = {L.origin[0], L.origin[1], L.origin[2]};
+    for (const DevObject& ob : objs) {
+      const amber_bvh::Box bx = amber_bvh::ObjectBox(ob);
+      for (int c = 0; c < 3; c++) { lo[c] = std::min<double>(lo[c], bx.mn[c]); hi[c] = std::max<double>(hi[c], bx.mx[c]); }
+    }
+    double reach = 0;
+    for (int c = 0; c < 3; c++) { sc.fp_center[c] = static_cast<float>(0.5 * (lo[c] + hi[c])); reach = std::max(reach, 0.5 * (hi[c] - lo[c])); }
+    sc.fp_reach = static_cast<float>(std::min(3.0e38, 2.0 * reach + 1e-3));
+  }
   sc.lights = h->d_lights; sc.n_lights = s->n_lights; sc.total_power = s->n_lights ? s->lights[s->n_lights - 1].cum_power : 0.0f;
   sc.n_prog_tris = fprog.n_prog_tris; sc.always_mask = fprog.always_mask; sc.prog_objects = h->d_prog_objects;
   sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;

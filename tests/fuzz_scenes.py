@@ -8,7 +8,8 @@ def f32(v):
     return [float(np.float32(x)) for x in v]
 
 
-def random_scene(rng, big):
+def random_scene(rng, big, normal_scale=1.0):
+    """normal_scale multiplies the (already non-unit) disk normals: sampled directions then have lengths far from 1."""
     mats = [(4, tuple(rng.uniform(5, 40, 3)), 0.0), (0, tuple(rng.uniform(0.2, 0.9, 3)), 0.0), (1, tuple(rng.uniform(0.5, 0.95, 3)), float(rng.choice([4.0, 32.0, 256.0]))),
             (2, tuple(rng.uniform(0.7, 0.95, 3)), 0.0), (3, (1.0, 1.0, 1.0), float(rng.choice([1.125, 1.333, 1.5]))), (0, (0.5, 0.5, 0.5), 0.0)]
     objs = []
@@ -63,7 +64,7 @@ def random_scene(rng, big):
         elif kind == "sphere":
             objs.append((1, mat(), f32(list(point()) + [rng.uniform(0.05, 0.6)])))
         elif kind == "disk":
-            objs.append((2, mat(), f32(list(point()) + list(point()) + [rng.uniform(0.1, 0.8)])))
+            objs.append((2, mat(), f32(list(point()) + list(point() * normal_scale) + [rng.uniform(0.1, 0.8)])))
         else:
             n = point(); n /= np.linalg.norm(n)
             objs.append((3, mat(), f32(list(point()) + list(n) + [rng.uniform(0.05, 0.4), rng.uniform(0.2, 1.0)])))

@@ -21,3 +21,4 @@ for rnd in range(3):
         print(path, rnd, "%.1f ms" % ms, pt.ray_count(), flush=True)
 for path in libs:
     print("%-32s median %.1f ms  (%s)" % (path, statistics.median(res[path]), " ".join("%.1f" % x for x in res[path])))
+sys.stdout.flush(); os._exit(0)   # several copies of the library are loaded: skip their exit-time teardown (it can abort)
