@@ -8,8 +8,9 @@ def f32(v):
     return [float(np.float32(x)) for x in v]
 
 
-def random_scene(rng, big, normal_scale=1.0):
-    """normal_scale multiplies the (already non-unit) disk normals: sampled directions then have lengths far from 1."""
+def random_scene(rng, big, normal_scale=1.0, scale=1.0, offset=(0.0, 0.0, 0.0)):
+    """normal_scale multiplies the (already non-unit) disk normals: sampled directions then have lengths far from 1.
+    scale / offset apply a similarity transform to all geometry and to the camera position (precision stress)."""
     mats = [(4, tuple(rng.uniform(5, 40, 3)), 0.0), (0, tuple(rng.uniform(0.2, 0.9, 3)), 0.0), (1, tuple(rng.uniform(0.5, 0.95, 3)), float(rng.choice([4.0, 32.0, 256.0]))),
             (2, tuple(rng.uniform(0.7, 0.95, 3)), 0.0), (3, (1.0, 1.0, 1.0), float(rng.choice([1.125, 1.333, 1.5]))), (0, (0.5, 0.5, 0.5), 0.0)]
     objs = []
@@ -75,4 +76,24 @@ def random_scene(rng, big, normal_scale=1.0):
         lens = dict(focal_length=0.045, focus_distance=z, radius=0.02, n_blades=0)             # pinhole
     else:
         lens = dict(focal_length=0.05, focus_distance=z, radius=float(rng.choice([0.01, 0.05])), n_blades=int(rng.integers(3, 7)))
+    if scale != 1.0 or any(offset):
+        off = np.array(offset, np.float64)
+
+        def pos(v):
+            return list(np.array(v, np.float64) * scale + off)
+        moved = []
+        for kind, m, p in objs:
+            if kind == 0:
+                p2 = pos(p[0:3]) + pos(p[3:6]) + pos(p[6:9])
+            elif kind == 1:
+                p2 = pos(p[0:3]) + [p[3] * scale]
+            elif kind == 2:
+                p2 = pos(p[0:3]) + list(p[3:6]) + [p[6] * scale]
+            else:
+                p2 = pos(p[0:3]) + list(p[3:6]) + [p[6] * scale, p[7] * scale]
+            moved.append((kind, m, f32(p2)))
+        objs = moved
+        t3 = pos([tf[3], tf[7], tf[11]])
+        tf = [1, 0, 0, float(np.float32(t3[0])), 0, 1, 0, float(np.float32(t3[1])), 0, 0, 1, float(np.float32(t3[2])), 0, 0, 0, 1]
+        lens = dict(lens, focus_distance=float(np.float32(lens["focus_distance"] * scale)))
     return dict(objects=objs, materials=[(k, tuple(float(x) for x in rho), p) for k, rho, p in mats], transform=tf, **lens)

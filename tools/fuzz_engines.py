@@ -11,6 +11,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n_scenes = int(args[0]) if args else 200
 first_seed = int(args[1]) if len(args) > 1 else 0
 use_oracle = "--oracle" in sys.argv
+scaled = "--scaled" in sys.argv      # similarity transform: scale 10^U(-2,3), offset up to 100 scales (coordinate precision stress)
 extreme = "--extreme" in sys.argv    # disk normals scaled by 10^U(-2,2): direction lengths from 0.01 to 100
 use_lt = "--lt" in sys.argv           # also compare light tracing (splat records) between the work-queue engines
 if use_oracle:
@@ -23,13 +24,17 @@ from fuzz_scenes import random_scene
 
 
 t0 = time.time()
-W, H, spp = 48, 40, 6
+W, H, spp = (128, 96, 12) if "--heavy" in sys.argv else (48, 40, 6)      # --heavy: 13x more paths per scene (rare edge-on rays)
 n_pairs_total = 0
 for seed in range(first_seed, first_seed + n_scenes):
     t_scene = time.time()
     rng = np.random.default_rng(seed)
     big = seed % 4 == 3
-    sc = random_scene(rng, big, normal_scale=(10.0 ** rng.uniform(-2, 2)) if extreme else 1.0)
+    kw = {}
+    if scaled:
+        s = float(10.0 ** rng.uniform(-2, 3))
+        kw = dict(scale=s, offset=tuple(float(x) for x in rng.uniform(-100, 100, 3) * s * float(rng.integers(0, 2))))
+    sc = random_scene(rng, big, normal_scale=(10.0 ** rng.uniform(-2, 2)) if extreme else 1.0, **kw)
     n_obj = len(sc["objects"]) + max(1, sc["n_blades"])
     hs = A.HostScene.create(**sc)
     engines = [A.ENGINE_LIST, A.ENGINE_BVH, A.ENGINE_WAVEFRONT] + ([A.ENGINE_TWO_PHASE] if n_obj <= 32 else [])
