@@ -65,7 +65,7 @@ struct RenderArgs {
 // place when a path ends, and stores the item's sum to partial[chunk][pixel]; reduce_partials_kernel adds the
 // chunks to the framebuffer in chunk order.  The summation order is therefore fixed.
 #ifndef AMBER_MEGAKERNEL_WAVES_PER_SIMD
-#define AMBER_MEGAKERNEL_WAVES_PER_SIMD 6   // 80 VGPRs + 8 B scratch; in-process A/B on config 2: 5 waves (87 VGPRs) 48.8 ms, 6: 47.9, 7: 48.2, 8: 49.5
+#define AMBER_MEGAKERNEL_WAVES_PER_SIMD 6   // 80 VGPRs, no scratch; in-process A/B on config 2 at 512 spp: 5 waves (87 VGPRs) 48.8 ms, 6: 47.9, 7: 48.2, 8: 49.5
 #endif
 // kLight: the same worker loop traces LIGHT paths (algorithm_lt.cc:112-163): an item is (light path index, chunk of
 // passes), nothing is summed per item, Eye hits append splat records instead.
@@ -81,11 +81,12 @@ __global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 1 : AMBER_MEGAKER
   uint32_t pool_next = 0, pool_end = 0;      // wave-uniform: items claimed by this wave, not yet handed out
   bool exhausted = false;                    // wave-uniform: the global queue is empty
   bool lane_done = false, have_item = false, alive = false;
-  uint32_t s = 0, s_end = 0, px = 0, py = 0, pixel = 0, slot = 0;
+  uint32_t s = 0, s_end = 0, pixel = 0, slot = 0;          // the pixel's x, y are recomputed where a path starts: two registers less
   V3 sum = v3(0.f, 0.f, 0.f), meas = v3(0.f, 0.f, 0.f);
   V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), w = v3(0.f, 0.f, 0.f);
   uint64_t rng = 1;
-  uint32_t casts = 0, rays = 0;
+  uint32_t casts = 0;
+  uint32_t rays_wave = 0;                    // wave-uniform (SGPR): rays cast by this wave
   int origin_slot = -1;                      // filter-program slot of the triangle the current ray starts on
 #ifdef AMBER_STAMPS
   StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
@@ -121,8 +122,8 @@ __global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 1 : AMBER_MEGAKER
         const uint32_t item = pool_next + rank;
         const uint32_t plocal = item / a.n_chunks, chunk = item - plocal * a.n_chunks;
         const uint32_t lrow = plocal / sc.sensor.w;
-        px = plocal - lrow * sc.sensor.w;
-        py = a.row_begin + (a.stripe_rows ? (lrow / a.stripe_rows) * a.stripe_period + lrow % a.stripe_rows : lrow);
+        const uint32_t px = plocal - lrow * sc.sensor.w;
+        const uint32_t py = a.row_begin + (a.stripe_rows ? (lrow / a.stripe_rows) * a.stripe_period + lrow % a.stripe_rows : lrow);
         pixel = px + py * sc.sensor.w;                      // Image index x + y*W (image.h:116-124)
         slot = chunk * a.n_pixels + plocal;
         s = a.first_sample + chunk * AMBER_ACCUM_CHUNK;
@@ -146,7 +147,8 @@ __global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 1 : AMBER_MEGAKER
         GenerateLightRay(sc, rng, o, d, w, origin_slot);
       } else {
         float ew;
-        GenerateEyeRay(sc, px, py, rng, o, d, ew, origin_slot);
+        const uint32_t py = pixel / sc.sensor.w;
+        GenerateEyeRay(sc, pixel - py * sc.sensor.w, py, rng, o, d, ew, origin_slot);
         w = v3(ew, ew, ew);                                 // Leading<RGB>(.., Radiant(weight)) lens_basic.h:139-144
       }
       meas = v3(0.f, 0.f, 0.f);
@@ -155,6 +157,7 @@ __global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 1 : AMBER_MEGAKER
       ++s;
     }
     AMBER_STAMP(1);
+    rays_wave += static_cast<uint32_t>(__popcll(__ballot(alive)));
     if (alive) {
       if (kLight) {
         const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, pixel, s - 1u, sc.sensor.size_f};
@@ -162,7 +165,6 @@ __global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 1 : AMBER_MEGAKER
       } else {
         alive = PathStep<false, kEngine>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG);
       }
-      ++rays;
       if (!alive) sum = sum + meas;                         // sequential sum over the item's samples
     }
   }
@@ -171,9 +173,7 @@ __global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 1 : AMBER_MEGAKER
   if (lane == 0 && a.stamps) for (int k = 0; k < 8; k++) atomicAdd(a.stamps + k, stamp_ctx->acc[k]);
 #endif
   // one atomic per wave for the ray counter
-  unsigned long long r = rays;
-  for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
-  if (lane == 0 && r) atomicAdd(a.ray_count, r);
+  if (lane == 0 && rays_wave) atomicAdd(a.ray_count, static_cast<unsigned long long>(rays_wave));
 }
 
 // Engine BVH worker.  Same work queue, item walk and accumulation order as pt_megakernel, but the closest-hit query
