@@ -12,6 +12,7 @@ n_scenes = int(args[0]) if args else 200
 first_seed = int(args[1]) if len(args) > 1 else 0
 use_oracle = "--oracle" in sys.argv
 scaled = "--scaled" in sys.argv      # similarity transform: scale 10^U(-2,3), offset up to 100 scales (coordinate precision stress)
+use_stripes = "--stripes" in sys.argv # also render the image as three interleaved stripe sets (one process per GPU does this)
 extreme = "--extreme" in sys.argv    # disk normals scaled by 10^U(-2,2): direction lengths from 0.01 to 100
 use_lt = "--lt" in sys.argv           # also compare light tracing (splat records) between the work-queue engines
 if use_oracle:
@@ -48,6 +49,21 @@ for seed in range(first_seed, first_seed + n_scenes):
         elif rays != ref[1] or not np.array_equal(img.view(np.uint32), ref[0]):
             bad = np.argwhere(img.view(np.uint32) != ref[0])
             print("MISMATCH seed %d engine %d vs LIST: rays %d vs %d, %d differing values, first at %s" % (seed, e, rays, ref[1], len(bad), bad[:3].tolist()), flush=True)
+            sys.exit(1)
+    if use_stripes:
+        from amber_amd.distributed import stripe_partition
+        parts = stripe_partition(H, 3)
+        full = ref[0].reshape(H, W, 3)
+        tot = 0
+        for part in parts:
+            pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=seed, rows=part["rows"], stripe=part["stripe"])
+            pt.render_pass(0, spp)                                  # (splitting a pass changes the summation order by design)
+            img, rays = pt.download(); pt.close(); tot += rays
+            if not np.array_equal(img.view(np.uint32), full[part["index"]]):
+                print("STRIPE MISMATCH seed %d rows %s" % (seed, part["rows"]), flush=True)
+                sys.exit(1)
+        if tot != ref[1]:
+            print("STRIPE RAY COUNT MISMATCH seed %d: %d vs %d" % (seed, tot, ref[1]), flush=True)
             sys.exit(1)
     if use_lt:
         lref = None
