@@ -1,0 +1,36 @@
+"""Large random soups (tens of thousands of triangles, spheres, disks, cylinders): engine BVH (parallel build, deep tree)
+against engine LIST, bit for bit.   python tools/fuzz_big.py [n_scenes] [n_objects]"""
+import os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import numpy as np
+import amber_amd as A
+n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+n_obj = int(sys.argv[2]) if len(sys.argv) > 2 else 80000
+W, H, spp = 64, 48, 4
+for seed in range(n_scenes):
+    rng = np.random.default_rng(1000 + seed)
+    kinds = rng.choice([0, 0, 0, 1, 2, 3], n_obj).astype(np.uint32)
+    params = np.zeros((n_obj, 12), np.float32)
+    c = rng.uniform(-1, 1, (n_obj, 3)) * rng.choice([1.0, 1.0, 30.0], (n_obj, 1))          # a third of the objects far out: deep, unbalanced tree
+    size = (10.0 ** rng.uniform(-3, -0.5, n_obj))
+    tri = kinds == 0
+    params[:, 0:3] = c
+    params[tri, 3:6] = (c + rng.normal(size=(n_obj, 3)) * size[:, None])[tri]
+    params[tri, 6:9] = (c + rng.normal(size=(n_obj, 3)) * size[:, None])[tri]
+    params[kinds == 1, 3] = size[kinds == 1]
+    nrm = rng.normal(size=(n_obj, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    dc = kinds >= 2
+    params[dc, 3:6] = nrm[dc]; params[dc, 6] = size[dc]; params[kinds == 3, 7] = (size * 3)[kinds == 3]
+    mats = [(4, (20.0, 20.0, 20.0), 0.0), (0, (0.7, 0.7, 0.7), 0.0), (2, (0.9, 0.9, 0.9), 0.0), (3, (1.0, 1.0, 1.0), 1.5), (1, (0.8, 0.8, 0.8), 16.0)]
+    material = rng.choice(5, n_obj, p=[0.05, 0.55, 0.15, 0.15, 0.10]).astype(np.uint32)
+    hs = A.HostScene.create_arrays(kinds=kinds, material_index=material, params=params, materials=mats,
+                                   transform=[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 4, 0, 0, 0, 1], focal_length=0.05, focus_distance=4.0, radius=0.02, n_blades=6)
+    res = {}
+    for e in (A.ENGINE_BVH, A.ENGINE_LIST):
+        t = time.time(); pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=seed, engine=e); tc = time.time() - t
+        t = time.time(); pt.render_pass(0, spp); img, rays = pt.download(); tr = time.time() - t; pt.close()
+        res[e] = (img.view(np.uint32).copy(), rays)
+        print("seed %d engine %d: create %.2f s, render %.2f s, rays %d" % (seed, e, tc, tr, rays), flush=True)
+    if res[A.ENGINE_BVH][1] != res[A.ENGINE_LIST][1] or not np.array_equal(res[A.ENGINE_BVH][0], res[A.ENGINE_LIST][0]):
+        print("MISMATCH seed", seed); sys.exit(1)
+print("big fuzz ok: %d scenes of %d objects" % (n_scenes, n_obj))
