@@ -33,7 +33,11 @@ struct FilterProgram {
   uint32_t n_prog_tris = 0, always_mask = 0;
 };
 
-inline void BuildFilterProgram(const std::vector<DevObject>& objs, FilterProgram& fp) {
+// `center`: the filter works in coordinates relative to this point (the device subtracts it from the ray origin), so its
+// affine maps see magnitudes of the order of the scene size however far the scene lies from the world origin; in
+// absolute coordinates u = A.P + a0 cancels two large terms and loses the precision the tolerances assume
+// (found by fuzzing with scenes offset by 1e4 of their size).
+inline void BuildFilterProgram(const std::vector<DevObject>& objs, const float center[3], FilterProgram& fp) {
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, e_max = 0;
   auto grow = [&](double x, double y, double z) {
     const double p[3] = {x, y, z};
@@ -64,7 +68,8 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, FilterProgram
     const DevObject& o = objs[i];
     const uint32_t idx = static_cast<uint32_t>(i);
     if (o.kind == AMBER_PRIM_TRIANGLE) {
-      const double v0[3] = {o.a[0], o.a[1], o.a[2]}, E1[3] = {o.e1[0], o.e1[1], o.e1[2]}, E2[3] = {o.e2[0], o.e2[1], o.e2[2]};
+      const double v0[3] = {double(o.a[0]) - center[0], double(o.a[1]) - center[1], double(o.a[2]) - center[2]};   // centred
+      const double E1[3] = {o.e1[0], o.e1[1], o.e1[2]}, E2[3] = {o.e2[0], o.e2[1], o.e2[2]};
       const double nr[3] = {E1[1] * E2[2] - E1[2] * E2[1], E1[2] * E2[0] - E1[0] * E2[2], E1[0] * E2[1] - E1[1] * E2[0]};
       const double n2 = nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2];
       if (!(n2 > 1e-60) || !std::isfinite(n2)) { always_index.push_back(idx); continue; }
@@ -101,7 +106,7 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, FilterProgram
     } else if (o.kind == AMBER_PRIM_SPHERE) {
       DevSphereFilter f;
       std::memset(&f, 0, sizeof f);
-      f.c[0] = o.a[0]; f.c[1] = o.a[1]; f.c[2] = o.a[2];
+      for (int k = 0; k < 3; k++) f.c[k] = static_cast<float>(double(o.a[k]) - center[k]);   // centred
       f.r2 = static_cast<float>(double(o.radius) * double(o.radius));
       f.ktol = 1e-5f;
       if (!std::isfinite(f.r2)) { always_index.push_back(idx); continue; }

@@ -398,10 +398,11 @@ __device__ __forceinline__ void ClosestHitList(const DevScene& sc, V3 o, V3 d, H
 //  only, object records gathered from the LDS copy; the (t, index) tie rule makes the visiting order irrelevant.
 //  The result is identical to ClosestHitList (tests: full-image and per-ray equality of both engines).
 #define AMBER_GRAZING 1e-3f
-__device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const DevObject* lds_objects, V3 o, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM) {
+__device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const DevObject* lds_objects, V3 o_world, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM) {
   best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;
   uint32_t cand = sc.always_mask;
   {
+    const V3 o = v3(o_world.x - sc.fp_center[0], o_world.y - sc.fp_center[1], o_world.z - sc.fp_center[2]);   // Phase A runs in centred coordinates (filter_build.h)
     ConstWords pl = (ConstWords)(sc.planes);
     ConstWords tr = (ConstWords)(sc.tri_filters);
     const int n_planes = static_cast<int>(sc.n_planes);
@@ -454,7 +455,7 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
   // 5).  Anything else -- possible only when a scene hands the reference non-unit normals, whose sphere test then
   // reports "hits" far outside the scene -- skips the filter: every object becomes a candidate for the exact tests.
   {
-    const float ex = Abs(o.x - sc.fp_center[0]), ey = Abs(o.y - sc.fp_center[1]), ez = Abs(o.z - sc.fp_center[2]);
+    const float ex = Abs(o_world.x - sc.fp_center[0]), ey = Abs(o_world.y - sc.fp_center[1]), ez = Abs(o_world.z - sc.fp_center[2]);
     const bool in_model = __builtin_fmaxf(__builtin_fmaxf(ex, ey), ez) <= sc.fp_reach && (d.x * d.x + d.y * d.y + d.z * d.z) <= 4.0f;   // NaN -> false
     if (!in_model) cand = sc.n_objects >= 32u ? 0xffffffffu : ((1u << sc.n_objects) - 1u);
   }
@@ -471,7 +472,7 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
         const DevObject& ob = lds_objects[origin_slot];
         const V3 A = ld3(ob.a), E1 = ld3(ob.e1), E2 = ld3(ob.e2);
         const float det = Dot(Cross(d, E2), E1);
-        const float t = Dot(Cross(o - A, E1), E2) / det;
+        const float t = Dot(Cross(o_world - A, E1), E2) / det;
         if (t <= AMBER_KEPS) cand &= ~(1u << origin_slot);
       }
     }
@@ -487,7 +488,7 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
       const int slot = __builtin_ctz(mt);
       mt &= mt - 1u;
       const DevObject& ob = lds_objects[slot];
-      IntersectTriangle<true>(ld3(ob.a), ld3(ob.e1), ld3(ob.e2), static_cast<int>(ob.kind >> 8), slot, o, d, best);
+      IntersectTriangle<true>(ld3(ob.a), ld3(ob.e1), ld3(ob.e2), static_cast<int>(ob.kind >> 8), slot, o_world, d, best);
     }
   }
   uint32_t mo = cand & ~tri_bits;
@@ -496,7 +497,7 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
       const int slot = __builtin_ctz(mo);
       mo &= mo - 1u;
       const DevObject& ob = lds_objects[slot];
-      IntersectObject<true>(ob, ob.kind & 0xffu, static_cast<int>(ob.kind >> 8), slot, o, d, best);
+      IntersectObject<true>(ob, ob.kind & 0xffu, static_cast<int>(ob.kind >> 8), slot, o_world, d, best);
     }
   }
 }

@@ -596,7 +596,19 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     h->bvh_depth = bvh.depth;
   }
   amber_filter::FilterProgram fprog;
-  if (h->two_phase) amber_filter::BuildFilterProgram(objs, fprog);
+  float fp_center[3] = {0, 0, 0}, fp_reach = 0;
+  {
+    // model box of the two-phase filter: bounds of every object and of the lens, doubled
+    double lo[3] = {L.origin[0], L.origin[1], L.origin[2]}, hi[3] = {L.origin[0], L.origin[1], L.origin[2]};
+    for (const DevObject& ob : objs) {
+      const amber_bvh::Box bx = amber_bvh::ObjectBox(ob);
+      for (int c = 0; c < 3; c++) { lo[c] = std::min<double>(lo[c], bx.mn[c]); hi[c] = std::max<double>(hi[c], bx.mx[c]); }
+    }
+    double reach = 0;
+    for (int c = 0; c < 3; c++) { fp_center[c] = static_cast<float>(0.5 * (lo[c] + hi[c])); reach = std::max(reach, 0.5 * (hi[c] - lo[c])); }
+    fp_reach = static_cast<float>(std::min(3.0e38, 2.0 * reach + 1e-3));
+  }
+  if (h->two_phase) amber_filter::BuildFilterProgram(objs, fp_center, fprog);
   if (h->two_phase && std::getenv("AMBER_DEBUG_FILTER")) {     // diagnostic: shape of the Phase-A program
     uint32_t pairs = 0, singles = 0;
     for (const DevPlane& pl : fprog.planes) { pairs += pl.n_pairs; singles += pl.n_tris; }
@@ -681,17 +693,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     sc.bvh_half_diag = static_cast<float>(0.5 * std::sqrt(d2) * 1.0001);
     sc.bvh_inv_rmin = !bvh.has_spheres ? 0.0f : (bvh.min_sphere_radius > 0 ? static_cast<float>(std::min(3.0e38, 1.0001 / bvh.min_sphere_radius)) : 3.0e38f);
   }
-  {
-    // model box of the two-phase filter: bounds of every object and of the lens, doubled
-    double lo[3] = {L.origin[0], L.origin[1], L.origin[2]}, hi[3] = {L.origin[0], L.origin[1], L.origin[2]};
-    for (const DevObject& ob : objs) {
-      const amber_bvh::Box bx = amber_bvh::ObjectBox(ob);
-      for (int c = 0; c < 3; c++) { lo[c] = std::min<double>(lo[c], bx.mn[c]); hi[c] = std::max<double>(hi[c], bx.mx[c]); }
-    }
-    double reach = 0;
-    for (int c = 0; c < 3; c++) { sc.fp_center[c] = static_cast<float>(0.5 * (lo[c] + hi[c])); reach = std::max(reach, 0.5 * (hi[c] - lo[c])); }
-    sc.fp_reach = static_cast<float>(std::min(3.0e38, 2.0 * reach + 1e-3));
-  }
+  for (int c = 0; c < 3; c++) sc.fp_center[c] = fp_center[c];
+  sc.fp_reach = fp_reach;
   sc.lights = h->d_lights; sc.n_lights = s->n_lights; sc.total_power = s->n_lights ? s->lights[s->n_lights - 1].cum_power : 0.0f;
   sc.n_prog_tris = fprog.n_prog_tris; sc.always_mask = fprog.always_mask; sc.prog_objects = h->d_prog_objects;
   sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;

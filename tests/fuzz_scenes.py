@@ -97,3 +97,13 @@ def random_scene(rng, big, normal_scale=1.0, scale=1.0, offset=(0.0, 0.0, 0.0)):
         tf = [1, 0, 0, float(np.float32(t3[0])), 0, 1, 0, float(np.float32(t3[1])), 0, 0, 1, float(np.float32(t3[2])), 0, 0, 0, 1]
         lens = dict(lens, focus_distance=float(np.float32(lens["focus_distance"] * scale)))
     return dict(objects=objs, materials=[(k, tuple(float(x) for x in rho), p) for k, rho, p in mats], transform=tf, **lens)
+
+
+def scene_for_seed(seed, scaled=False, extreme=False):
+    """The scene tools/fuzz_engines.py builds for `seed` under its --scaled / --extreme switches."""
+    rng = np.random.default_rng(seed)
+    kw = {}
+    if scaled:
+        s = float(10.0 ** rng.uniform(-2, 3))
+        kw = dict(scale=s, offset=tuple(float(x) for x in rng.uniform(-100, 100, 3) * s * float(rng.integers(0, 2))))
+    return random_scene(rng, seed % 4 == 3, normal_scale=(10.0 ** rng.uniform(-2, 2)) if extreme else 1.0, **kw), rng

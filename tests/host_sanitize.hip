@@ -64,7 +64,7 @@ int main() {
     const auto fs = scene.Flatten();
     const auto objs = ToDev(fs);
     amber_filter::FilterProgram fp;
-    amber_filter::BuildFilterProgram(objs, fp);
+    { const float zero_center[3] = {0, 0, 0}; amber_filter::BuildFilterProgram(objs, zero_center, fp); }
     uint32_t pairs = 0, singles = 0;
     for (const auto& pl : fp.planes) { pairs += pl.n_pairs; singles += pl.n_tris; }
     std::vector<int> slot_of(objs.size(), 0);
@@ -95,7 +95,7 @@ int main() {
     const auto fs = sc.Flatten();
     const auto objs = ToDev(fs);
     amber_filter::FilterProgram fp;
-    amber_filter::BuildFilterProgram(objs, fp);
+    { const float zero_center[3] = {0, 0, 0}; amber_filter::BuildFilterProgram(objs, zero_center, fp); }
     if (fp.always_mask != 0x7u || !fp.planes.empty()) { std::printf("FAIL degenerate filter program always=%x\n", fp.always_mask); return 1; }
     std::printf("ok   degenerate scene: every object is an always-candidate\n");
     CheckBvh(objs, "pinhole+disk+cylinder");

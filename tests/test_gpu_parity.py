@@ -638,14 +638,14 @@ def test_fuzz_regressions(amber):
     non-unit length, for which the reference's sphere test is not geometric (seed 5: engine BVH culled such hits) and
     for which its Phong rejection loop never ends (seeds 1037, 1039: bounded at AMBER_PHONG_MAX_TRIES in engine and
     oracle); plus a few ordinary seeds.  All engines and the oracle must agree bit for bit."""
-    from fuzz_scenes import random_scene
+    from fuzz_scenes import scene_for_seed
     W, H, spp = 48, 40, 6
-    for seed in (5, 1037, 1039, 2, 11, 16, 40, 31296):
+    # 31296 (--extreme): a disk normal of length ~40 sends a path to coordinates of 1e16 and back; the two-phase filter's
+    # tolerances do not hold out there and the engine has to bypass it.  209769 (--extreme --scaled): a scene 1e4 of its
+    # size away from the world origin; the filter's affine maps must work in centred coordinates.
+    for seed, scaled, extreme in ((5, 0, 0), (1037, 0, 0), (1039, 0, 0), (2, 0, 0), (11, 0, 0), (16, 0, 0), (40, 0, 0), (31296, 0, 1), (209769, 1, 1)):
         big = seed % 4 == 3
-        rng = np.random.default_rng(seed)
-        # 31296 ("--extreme"): a disk normal of length ~40 sends a path to coordinates of 1e16 and back; the two-phase
-        # filter's tolerances do not hold out there and the engine has to bypass it
-        sc = random_scene(rng, big, normal_scale=(10.0 ** rng.uniform(-2, 2)) if seed == 31296 else 1.0)
+        sc, _ = scene_for_seed(seed, scaled=bool(scaled), extreme=bool(extreme))
         hs = amber.HostScene.create(**sc)
         n_obj = len(sc["objects"]) + max(1, sc["n_blades"])
         engines = [amber.ENGINE_LIST, amber.ENGINE_BVH, amber.ENGINE_WAVEFRONT] + ([amber.ENGINE_TWO_PHASE] if n_obj <= 32 else [])

@@ -21,7 +21,7 @@ if use_oracle:
 
 
 sys.path.insert(0, os.path.join(R, "tests"))
-from fuzz_scenes import random_scene
+from fuzz_scenes import scene_for_seed
 
 
 t0 = time.time()
@@ -29,13 +29,8 @@ W, H, spp = (128, 96, 12) if "--heavy" in sys.argv else (48, 40, 6)      # --hea
 n_pairs_total = 0
 for seed in range(first_seed, first_seed + n_scenes):
     t_scene = time.time()
-    rng = np.random.default_rng(seed)
     big = seed % 4 == 3
-    kw = {}
-    if scaled:
-        s = float(10.0 ** rng.uniform(-2, 3))
-        kw = dict(scale=s, offset=tuple(float(x) for x in rng.uniform(-100, 100, 3) * s * float(rng.integers(0, 2))))
-    sc = random_scene(rng, big, normal_scale=(10.0 ** rng.uniform(-2, 2)) if extreme else 1.0, **kw)
+    sc, rng = scene_for_seed(seed, scaled=scaled, extreme=extreme)
     n_obj = len(sc["objects"]) + max(1, sc["n_blades"])
     hs = A.HostScene.create(**sc)
     engines = [A.ENGINE_LIST, A.ENGINE_BVH, A.ENGINE_WAVEFRONT] + ([A.ENGINE_TWO_PHASE] if n_obj <= 32 else [])

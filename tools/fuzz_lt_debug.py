@@ -4,10 +4,9 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert
 import numpy as np
 import amber_amd as A
 import oracle_binding as O
-from fuzz_scenes import random_scene
+from fuzz_scenes import scene_for_seed
 seed = int(sys.argv[1]); depth = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-rng = np.random.default_rng(seed)
-sc = random_scene(rng, seed % 4 == 3, normal_scale=(10.0 ** rng.uniform(-2, 2)) if "--extreme" in sys.argv else 1.0)
+sc, rng = scene_for_seed(seed, scaled="--scaled" in sys.argv, extreme="--extreme" in sys.argv)
 W, H = 48, 40
 hs = A.HostScene.create(**sc); osc = O.Scene.create(**sc)
 for i, o in enumerate(sc["objects"]):

@@ -4,9 +4,8 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert
 import numpy as np
 import amber_amd as A
 seed, engine = int(sys.argv[1]), int(sys.argv[2]); spp = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-sys.path.insert(0, os.path.join(R, "tests")); from fuzz_scenes import random_scene
-rng = np.random.default_rng(seed)
-sc = random_scene(rng, seed % 4 == 3, normal_scale=(10.0 ** rng.uniform(-2, 2)) if "--extreme" in sys.argv else 1.0)
+sys.path.insert(0, os.path.join(R, "tests")); from fuzz_scenes import scene_for_seed
+sc, rng = scene_for_seed(seed, scaled="--scaled" in sys.argv, extreme="--extreme" in sys.argv)
 print("seed", seed, "objects", len(sc["objects"]), "blades", sc["n_blades"], flush=True)
 hs = A.HostScene.create(**sc)
 t = time.time(); pt = A.PathTracer(hs, A.Sensor.default(48, 40), seed=seed, engine=engine); print("create %.2f s" % (time.time() - t), flush=True)
