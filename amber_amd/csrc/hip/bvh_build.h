@@ -54,7 +54,15 @@ struct Box {
 // parameter p satisfies p^2 <= r^2 + ~12 eps D^2 -- for a small distant sphere noticeably outside the geometric
 // sphere (r = 0.005, D = 6: 3.5e-3).  Those accepted hits must stay inside the leaf's box, so spheres are bounded
 // with r' = sqrt(r^2 + 16 eps D_scene^2) (found when the 1M-sphere scene lost 7 paths in 1.4e9 to tighter boxes).
-inline Box ObjectBox(const DevObject& o, double sphere_slack2 = 0.0) {
+// tri_reach: the reference's Moeller-Trumbore test (primitive_triangle.cc:97-128) forms u and v with an absolute error of
+// about 6 eps |T| |E| / |det| each and tests fl(u) + fl(v) <= 1, so along a NEEDLE (one edge much shorter than the
+// others) it accepts rays that cross the plane up to ~ 36 eps |T| e_max / e_min beyond the short edge -- 2.5e-3 scene
+// units in the fuzzer's seed 308053 (e_max / e_min = 1e4), far outside the geometric box.  Triangle boxes are widened
+// by that amount with |T| <= tri_reach (the scene diameter); for a well-shaped triangle it is 1e-6 of the scene.
+// What no static box can cover is a ray within a fraction of a degree of a triangle's plane and nearly parallel to
+// one of its edges, where the same error grows without bound: engine LIST keeps such numerical-noise hits, engine
+// BVH (like the reference's own BVH, which culls with unpadded boxes) may not -- see DESIGN.md section 5.
+inline Box ObjectBox(const DevObject& o, double sphere_slack2 = 0.0, double tri_reach = 0.0) {
   Box b; b.reset();
   const uint32_t kind = o.kind & 0xffu;
   if (kind == 0) {            // triangle: v0, v0+E1, v0+E2
@@ -64,6 +72,15 @@ inline Box ObjectBox(const DevObject& o, double sphere_slack2 = 0.0) {
     b.grow(p);
     for (int c = 0; c < 3; c++) p[c] = o.a[c] + o.e2[c];
     b.grow(p);
+    if (tri_reach > 0.0) {
+      double l1 = 0, l2 = 0, l3 = 0;
+      for (int c = 0; c < 3; c++) { l1 += double(o.e1[c]) * o.e1[c]; l2 += double(o.e2[c]) * o.e2[c]; const double e3 = double(o.e2[c]) - o.e1[c]; l3 += e3 * e3; }
+      const double emax = std::sqrt(std::max(l1, std::max(l2, l3))), emin = std::sqrt(std::min(l1, std::min(l2, l3)));
+      if (emin > 0.0 && std::isfinite(emax)) {
+        const double m = std::min(tri_reach, 36.0 * 5.9604644775390625e-08 * tri_reach * emax / emin);
+        for (int c = 0; c < 3; c++) { b.mn[c] = static_cast<float>(b.mn[c] - m); b.mx[c] = static_cast<float>(b.mx[c] + m); }
+      }
+    }
   } else if (kind == 1) {     // sphere
     const float r = static_cast<float>(std::sqrt(double(o.radius) * o.radius + sphere_slack2) * 1.000001);
     for (int c = 0; c < 3; c++) { b.mn[c] = o.a[c] - r; b.mx[c] = o.a[c] + r; }
@@ -229,12 +246,13 @@ inline FlatBvh BuildBvh(const std::vector<DevObject>& objs) {
   double slack_factor = 16.0;
   if (const char* env = std::getenv("AMBER_BVH_SPHERE_SLACK")) slack_factor = std::atof(env);   // test hook: the image must not depend on it
   const double sphere_slack2 = slack_factor * 5.9604644775390625e-08 * (dx * dx + dy * dy + dz * dz);   // 16 eps D^2
+  const double scene_diag = std::sqrt(dx * dx + dy * dy + dz * dz);
   const size_t n_chunks = threads > 1 ? threads * 4 : 1;
   std::vector<Box> chunk_box(n_chunks);
   ParallelFor(n_chunks, threads, [&](size_t c) {
     Box cb; cb.reset();
     for (size_t i = n * c / n_chunks; i < n * (c + 1) / n_chunks; i++) {
-      s.boxes[i] = ObjectBox(objs[i], sphere_slack2);
+      s.boxes[i] = ObjectBox(objs[i], sphere_slack2, scene_diag);
       for (int k = 0; k < 3; k++) s.cent[3 * i + k] = 0.5f * (s.boxes[i].mn[k] + s.boxes[i].mx[k]);
       s.index[i] = static_cast<uint32_t>(i);
       cb.grow(s.boxes[i]);

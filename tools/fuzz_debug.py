@@ -9,7 +9,7 @@ import importlib.util
 seed, ea, eb = int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 1, int(sys.argv[3]) if len(sys.argv) > 3 else 3
 sys.path.insert(0, os.path.join(R, "tests")); from fuzz_scenes import scene_for_seed
 sc, rng = scene_for_seed(seed, scaled="--scaled" in sys.argv, extreme="--extreme" in sys.argv)
-W, H, spp = 48, 40, 6
+W, H, spp = (128, 96, 12) if "--heavy" in sys.argv else (48, 40, 6)
 hs = A.HostScene.create(**sc); osc = O.Scene.create(**sc)
 px = np.repeat(np.arange(W * H, dtype=np.uint32), spp); sm = np.tile(np.arange(spp, dtype=np.uint32), W * H)
 tr = {}
