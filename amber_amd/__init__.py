@@ -22,7 +22,10 @@ from .api import (  # noqa: F401
     build_library,
     device_count,
     export,
+    MATH_GLIBC,
+    MATH_PORTABLE,
     kat_math,
+    math_mode,
     library_path,
     load_library,
     tonemap,

@@ -9,7 +9,8 @@ from pathlib import Path
 import numpy as np
 
 _ROOT = Path(__file__).resolve().parent
-_LIB_PATH = _ROOT / "lib" / "libamber_hip.so"
+# AMBER_AMD_LIB selects a measurement build next to the product library (tools/: stamps, portable math); default = the product
+_LIB_PATH = _ROOT / "lib" / os.environ.get("AMBER_AMD_LIB", "libamber_hip.so")
 _lib = None
 
 
@@ -75,8 +76,8 @@ ENGINE_AUTO, ENGINE_LIST, ENGINE_TWO_PHASE, ENGINE_BVH, ENGINE_WAVEFRONT = 0, 1,
 ABI_SYMBOLS = [
     "amber_hip_pt_create", "amber_hip_pt_render_pass", "amber_hip_pt_clear", "amber_hip_pt_sync",
     "amber_hip_pt_download", "amber_hip_pt_device_framebuffer", "amber_hip_pt_local_rows", "amber_hip_pt_kernel_time", "amber_hip_pt_destroy",
-    "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_device_count", "amber_hip_lt_trace",
-    "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math",
+    "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_math_mode", "amber_hip_device_count", "amber_hip_lt_trace",
+    "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math", "amber_hip_kat_signatures",
     "amber_host_cornell_box", "amber_host_scene_import", "amber_host_scene_create", "amber_host_scene_destroy", "amber_host_scene_flatten",
     "amber_host_pt_create", "amber_host_render", "amber_host_last_error", "amber_host_tonemap", "amber_host_export",
 ]
@@ -87,8 +88,11 @@ def library_path() -> Path:
 
 
 def build_library(force: bool = False) -> Path:
-    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    if force or not _LIB_PATH.exists():
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU).  make is incremental, so it
+    always runs where a compiler exists: an edited .hip/.h can never be tested against a stale library.  A box
+    without hipcc uses the prebuilt library that travelled with the tree."""
+    import shutil
+    if shutil.which(os.environ.get("HIPCC", "hipcc")) or not _LIB_PATH.exists():
         subprocess.run(["make", "-C", str(_ROOT / "csrc")] + (["-B"] if force else []), check=True)
     return _LIB_PATH
 
@@ -122,6 +126,7 @@ def load_library() -> C.CDLL:
     lib.amber_hip_kat_eye.argtypes = [vp, u32, vp, vp, vp]
     lib.amber_hip_kat_trace.argtypes = [vp, u32, vp, vp, u32, vp, vp]
     lib.amber_hip_kat_math.argtypes = [i32, i32, u32, vp, vp]
+    lib.amber_hip_kat_signatures.argtypes = [vp, u32, u32, vp]
     lib.amber_host_cornell_box.restype = vp
     lib.amber_host_cornell_box.argtypes = [C.c_float, C.c_float, u32]
     lib.amber_host_scene_import.restype = vp
@@ -343,6 +348,13 @@ class PathTracer:
                                                   casts.ctypes.data))
         return rec, casts
 
+    def kat_signatures(self, first_sample: int, n_samples: int) -> np.ndarray:
+        """(rows, width, n_samples) uint64: low word = hash of the path's hit-object sequence, high word = hash of its hit distances."""
+        rows, width, _ = self.band_shape
+        out = np.zeros((rows, width, n_samples), np.uint64)
+        _check(load_library().amber_hip_kat_signatures(self._h, first_sample, n_samples, out.ctypes.data))
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             load_library().amber_hip_pt_destroy(self._h)
@@ -356,12 +368,21 @@ class PathTracer:
 
 
 def kat_math(mode: int, x, device: int = 0) -> np.ndarray:
-    """Portable device math: mode 0 sincos(x[i]) -> (n,2) ; mode 1 pow(x[i,0], x[i,1]) -> (n,)."""
+    """The engine's sin/cos/pow on device: mode 0 sincos(x[i]) -> (n,2) ; mode 1 pow(x[i,0], x[i,1]) -> (n,) ;
+    mode 2 / 3: x[i]^4 / x[i]^5 in binary64 -> (n,) float64."""
     x = _f32(x)
     n = len(x)
-    out = np.empty((n, 2) if mode == 0 else (n,), np.float32)
+    out = np.empty((n,) if mode == 1 else (n, 2), np.float32)
     _check(load_library().amber_hip_kat_math(device, mode, n, x.ctypes.data, out.ctypes.data))
-    return out
+    return out.view(np.float64).reshape(n) if mode >= 2 else out
+
+
+MATH_PORTABLE, MATH_GLIBC = 1, 2
+
+
+def math_mode() -> int:
+    """amber_hip_math_mode(): MATH_GLIBC for the product build, MATH_PORTABLE for -DAMBER_BUILD_PORTABLE_MATH measurement builds."""
+    return int(load_library().amber_hip_math_mode())
 
 
 def tonemap(image) -> np.ndarray:

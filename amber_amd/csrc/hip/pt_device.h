@@ -208,8 +208,19 @@ __device__ __forceinline__ float Uniform(uint64_t& s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// portable math (bit-identical to oracle/amber_oracle.cc PortableSinCos / PortablePow)
+// sin / cos / pow.  The reference calls glibc: g++ -O2 merges std::cos(phi), std::sin(phi) (sampling.h:249-250, 283-284)
+// into ONE sincosf call, std::pow(r0, 1 / (e + 1)) (sampling.h:279) is powf.  glibc 2.35's binary32 functions are
+// double-precision kernels (the algorithms and tables of ARM's optimized-routines: s_sincosf.c, sincosf_poly.h, e_powf.c,
+// e_powf_log2_data.c, e_exp2f_data.c) whose x86-64 FMA variant -- the one every FMA-capable host selects -- fuses every
+// a*b+c of the source and rounds to binary32 once at the end.  gfx950 has IEEE binary64 mul/fma, so the engine executes
+// exactly those operations: bit-identical to the live libm for every argument the path can produce (the oracle's
+// GLIBC mode is the same restatement, proven equal to libm.so.6 over the whole argument set in tests/test_math_modes.py).
+// Domain of SinCos: |x| < 120 (the path needs [0, 2 pi]); NaN beyond.
+// -DAMBER_BUILD_PORTABLE_MATH builds round 1's + - * / forms instead (Cephes-style; 29 % of the 2^24 possible phi differ from
+// glibc in the last bit) -- kept only to measure the distance between the two.
 // ---------------------------------------------------------------------------------------------
+#ifdef AMBER_BUILD_PORTABLE_MATH
+#define AMBER_MATH_MODE 1
 __device__ __forceinline__ void SinCos(float x, float& s_out, float& c_out) {
   const float FOPI = 1.27323954473516f;
   const float DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
@@ -266,9 +277,143 @@ __device__ __forceinline__ float Pow(float x, float y) {
   if (n < -126) { q = q * __uint_as_float(static_cast<uint32_t>(n + 126 + 127) << 23); n = -126; }
   return q * __uint_as_float(static_cast<uint32_t>(n + 127) << 23);
 }
-// std::pow(float, int) promotes to double (C++11); portable form: exact square, one or two roundings
+#else
+#define AMBER_MATH_MODE 2
+__device__ const double kGlibcLog2Tab[16][2] = {   // __powf_log2_data.tab: {invc, logc}
+  {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+  {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+  {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+  {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+  {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+  {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+  {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+  {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2},
+};
+__device__ const uint64_t kGlibcExp2Tab[32] = {    // __exp2f_data.tab
+  0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+  0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+  0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+  0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+  0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+  0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+};
+// __sincosf (s_sincosf.c) for |y| < 120.  The source's two short paths are folded into reduce_fast, which computes the
+// same values there: for |y| < 0.75 it finds n = 0 and x - 0 * hpi = x exactly.  Its second coefficient table (n & 2)
+// holds the negated cosine coefficients and sign[] = {1, -1, -1, 1} flips x: round-to-nearest is symmetric, so the
+// first table's results with the signs applied afterwards are the same bits.
+__device__ __forceinline__ void SinCos(float y, float& s_out, float& c_out) {
+  const double x0 = static_cast<double>(y);
+  const double r = x0 * 0x1.45f306dc9c883p+23;                                  // hpi_inv = 2^24 * 2 / pi
+  const int n = (static_cast<int>(r) + 0x800000) >> 24;                          // nearest multiple of pi / 2
+  const double x = __builtin_fma(-static_cast<double>(n), 0x1.921fb54442d18p+0, x0);
+  const double x2 = x * x;
+  const double s1 = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);    // sincosf_poly (sysdeps/x86_64/fpu/sincosf_poly.h)
+  const double c2 = __builtin_fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+  const double c1 = __builtin_fma(x2, -0x1.ffffffd0c621cp-2, 1.0);
+  const double x3 = x2 * x, x4 = x2 * x2;
+  const double x5 = x2 * x3, x6 = x2 * x4;
+  const double s = __builtin_fma(x3, -0x1.555545995a603p-3, x);
+  const double c = __builtin_fma(x4, 0x1.55553e1068f19p-5, c1);
+  float sv = static_cast<float>(__builtin_fma(x5, s1, s));
+  float cv = static_cast<float>(__builtin_fma(x6, c2, c));
+  if ((n + 1) & 2) sv = -sv;                                                     // sign[n & 3]
+  if (n & 2) cv = -cv;                                                           // table[1]
+  const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;                     // abstop12
+  if (top < 0x398u) { sv = y; cv = 1.0f; }                                       // |y| < 2^-12: sin = y, cos = 1 (n = 0)
+  s_out = (n & 1) ? cv : sv;
+  c_out = (n & 1) ? sv : cv;
+  if (!(top < 0x42fu)) { s_out = __builtin_nanf(""); c_out = __builtin_nanf(""); }   // |y| >= 120, inf, NaN: outside the restated domain
+}
+// __powf (e_powf.c) for x >= +0 and finite y (CosinePower's r0^(1/(e+1)): r0 in [0, 1), y > 0); negative or
+// non-finite arguments follow glibc's special cases.
+__device__ __forceinline__ int GlibcCheckInt(uint32_t iy) {
+  const int e = static_cast<int>(iy >> 23 & 0xffu);
+  if (e < 0x7f) return 0;
+  if (e > 0x7f + 23) return 2;
+  if (iy & ((1u << (0x7f + 23 - e)) - 1u)) return 0;
+  if (iy & (1u << (0x7f + 23 - e))) return 1;
+  return 2;
+}
+__device__ __forceinline__ float Pow(float x, float y) {
+  uint32_t sign_bias = 0u;
+  uint32_t ix = __float_as_uint(x);
+  const uint32_t iy = __float_as_uint(y);
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || 2u * iy - 1u >= 2u * 0x7f800000u - 1u) {
+    if (2u * iy - 1u >= 2u * 0x7f800000u - 1u) {                               // y is 0, inf or NaN
+      if (2u * iy == 0u) return 1.0f;
+      if (ix == 0x3f800000u) return 1.0f;
+      if (2u * ix > 2u * 0x7f800000u || 2u * iy > 2u * 0x7f800000u) return x + y;
+      if (2u * ix == 2u * 0x3f800000u) return 1.0f;
+      if ((2u * ix < 2u * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;
+      return y * y;
+    }
+    if (2u * ix - 1u >= 2u * 0x7f800000u - 1u) {                               // x is 0, inf or NaN
+      float x2 = x * x;
+      if ((ix & 0x80000000u) && GlibcCheckInt(iy) == 1) x2 = -x2;
+      return (iy & 0x80000000u) ? 1.0f / x2 : x2;
+    }
+    if (ix & 0x80000000u) {                                                     // finite x < 0
+      const int yint = GlibcCheckInt(iy);
+      if (yint == 0) return __builtin_nanf("");
+      if (yint == 1) sign_bias = 1u << 16;
+      ix &= 0x7fffffffu;
+    }
+    if (ix < 0x00800000u) { ix = __float_as_uint(__uint_as_float(ix) * 0x1p23f); ix &= 0x7fffffffu; ix -= 23u << 23; }   // subnormal x
+  }
+  // log2_inline: x = 2^k z, z in [OFF, 2 OFF), one of 16 subintervals with centre c; log2(x) = log1p(z/c - 1)/ln2 + log2(c) + k
+  const uint32_t tmp = ix - 0x3f330000u;
+  const uint32_t i = (tmp >> 19) & 15u;
+  const uint32_t top = tmp & 0xff800000u;
+  const double z = static_cast<double>(__uint_as_float(ix - top));
+  const int k = static_cast<int32_t>(top) >> 23;
+  const double2 t_log = *reinterpret_cast<const double2*>(kGlibcLog2Tab[i]);
+  const double r = __builtin_fma(z, t_log.x, -1.0);
+  const double y0 = t_log.y + static_cast<double>(k);
+  const double r2 = r * r;
+  double yy = __builtin_fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+  const double pp = __builtin_fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+  const double r4 = r2 * r2;
+  double q = __builtin_fma(0x1.71547652ab82bp0, r, y0);
+  q = __builtin_fma(pp, r2, q);
+  yy = __builtin_fma(yy, r4, q);
+  const double ylogx = static_cast<double>(y) * yy;
+  if ((static_cast<uint64_t>(__double_as_longlong(ylogx)) >> 47 & 0xffffull) >= (0x405f800000000000ull >> 47)) {   // |y log2 x| >= 126
+    const float sgn = sign_bias ? -1.0f : 1.0f;
+    if (ylogx > 0x1.fffffffd1d571p+6) return sgn * __builtin_inff();
+    if (ylogx <= -150.0) return sgn * 0.0f;
+    if (ylogx < -149.0) return sgn * 0x1p-149f;
+  }
+  // exp2_inline: x = k/32 + r, 2^x = 2^(k/32) * 2^r
+  const double shift = 0x1.8p+52 / 32;
+  double kd = ylogx + shift;
+  const uint64_t ki = static_cast<uint64_t>(__double_as_longlong(kd));
+  kd -= shift;
+  const double rr = ylogx - kd;
+  uint64_t t = kGlibcExp2Tab[ki & 31ull];
+  t += (ki + sign_bias) << 47;
+  const double sc = __longlong_as_double(static_cast<long long>(t));
+  const double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
+  const double rr2 = rr * rr;
+  double e = __builtin_fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
+  e = __builtin_fma(zz, rr2, e);
+  return static_cast<float>(e * sc);
+}
+#endif
+// std::pow(float, int) promotes to double (C++11): glibc's double pow.  x*x is exact (24 + 24 bits), so (x*x)^2 is the
+// correctly rounded x^4; x^5 is formed from the exact (hi, lo) pair of x^4 and rounds once too (portable build: two
+// roundings, as round 1).  glibc's pow is not correctly rounded: it differs from these in the last bit of the DOUBLE for
+// 1e-3 of the arguments, which never survived the conversion to binary32 in 2e8 trials.
 __device__ __forceinline__ double Pow4(float x) { const double d = x; const double d2 = d * d; return d2 * d2; }
+#ifdef AMBER_BUILD_PORTABLE_MATH
 __device__ __forceinline__ double Pow5(float x) { const double d = x; const double d2 = d * d; return (d2 * d2) * d; }
+#else
+__device__ __forceinline__ double Pow5(float x) {
+  const double d = x, d2 = d * d;
+  const double h = d2 * d2, l = __builtin_fma(d2, d2, -h);
+  const double p = h * d, pl = __builtin_fma(h, d, -p);
+  return p + __builtin_fma(l, d, pl);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // closest hit -- List semantics (acceleration_list.h:51-68): scan objects in insertion order,

@@ -405,11 +405,56 @@ __global__ void kat_trace_kernel(const DevScene sc, uint64_t hashed_seed, uint32
   if (i < n) out_casts[i] = casts;
 }
 
+// Path signatures of the handle's band (amber_hip_kat_signatures): thread i traces the path of (band pixel i / n_samples,
+// sample first_sample + i % n_samples) with the render kernels' device functions and writes FNV-1a-32 over the object index
+// of every cast (low word; 0xffffffff = miss) and over the bits of every hit distance (high word).
+__device__ __forceinline__ uint32_t Fnv32(uint32_t h, uint32_t v) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) { h ^= (v >> (8 * k)) & 0xffu; h *= 16777619u; }
+  return h;
+}
+template <int kEngine>
+__global__ void kat_signature_kernel(const DevScene sc, uint64_t hashed_seed, uint64_t n, uint32_t first_sample, uint32_t n_samples,
+                                     uint32_t row_begin, uint32_t stripe_rows, uint32_t stripe_period, unsigned long long* out) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t k = i < n ? i : n - 1;      // keep the scene loops wave-uniform for every lane
+  constexpr bool kTwoPhase = kEngine == ENGINE_TWO_PHASE;
+  __shared__ DevObject lds_objects[kTwoPhase ? AMBER_MAX_LDS_OBJECTS : 1];
+  __shared__ int32_t lds_stack[kEngine == ENGINE_BVH ? AMBER_BVH_STACK * 256 : 1];
+  if (kTwoPhase) StageObjects(sc, lds_objects);
+  const uint32_t plocal = static_cast<uint32_t>(k / n_samples), smp = first_sample + static_cast<uint32_t>(k % n_samples);
+  const uint32_t lrow = plocal / sc.sensor.w, px = plocal - lrow * sc.sensor.w;
+  const uint32_t py = row_begin + (stripe_rows ? (lrow / stripe_rows) * stripe_period + lrow % stripe_rows : lrow);
+  uint64_t rng = XorShiftSeed(hashed_seed, px + py * sc.sensor.w, smp);
+  V3 o, d; float ew; int origin_slot;
+  GenerateEyeRay(sc, px, py, rng, o, d, ew, origin_slot);
+  V3 w = v3(ew, ew, ew), meas = v3(0.f, 0.f, 0.f);
+  uint32_t casts = 0, sig_obj = 2166136261u, sig_t = 2166136261u;
+  bool alive = true;
+  while (__any(alive)) {
+    if (alive) {
+      Bounce b;
+#ifdef AMBER_STAMPS
+      StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
+#endif
+      alive = PathStep<true, kEngine>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, origin_slot, &b AMBER_STAMP_ARG);
+      sig_obj = Fnv32(sig_obj, static_cast<uint32_t>(b.object));
+      if (b.object >= 0) sig_t = Fnv32(sig_t, __float_as_uint(b.t));
+    }
+  }
+  if (i < n) out[i] = static_cast<unsigned long long>(sig_obj) | (static_cast<unsigned long long>(sig_t) << 32);
+}
+
 __global__ void kat_math_kernel(int mode, uint32_t n, const float* x, float* out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (mode == 0) { float s, c; SinCos(x[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; }
-  else out[i] = Pow(x[2 * i], x[2 * i + 1]);
+  else if (mode == 1) out[i] = Pow(x[2 * i], x[2 * i + 1]);
+  else {                                                    // 2: Pow4, 3: Pow5 -- the double's two words
+    const double d = mode == 2 ? Pow4(x[i]) : Pow5(x[i]);
+    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(d));
+    out[2 * i] = __uint_as_float(static_cast<uint32_t>(b)); out[2 * i + 1] = __uint_as_float(static_cast<uint32_t>(b >> 32));
+  }
 }
 
 }  // namespace
@@ -506,6 +551,7 @@ extern "C" {
 
 const char* amber_hip_last_error(void) { return g_last_error.c_str(); }
 int amber_hip_abi_version(void) { return AMBER_HIP_ABI_VERSION; }
+int amber_hip_math_mode(void) { return AMBER_MATH_MODE; }
 int amber_hip_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1130,13 +1176,32 @@ int amber_hip_kat_trace(amber_hip_pt* h, uint32_t n, const uint32_t* pixel, cons
   return AMBER_OK;
 }
 
+int amber_hip_kat_signatures(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint64_t* out) {
+  if (!h || !out || n_samples == 0) return Fail(AMBER_EINVAL, "bad argument");
+  if (static_cast<uint64_t>(first_sample) + n_samples > 0xffffffffull) return Fail(AMBER_EINVAL, "sample index overflow");
+  const uint64_t n = static_cast<uint64_t>(h->local_rows) * h->scene.sensor.w * n_samples;
+  if (n == 0) return AMBER_OK;
+  if ((n + 255) / 256 > 0x7fffffffull) return Fail(AMBER_EINVAL, "too many paths for one call");
+  HIP_TRY(hipSetDevice(h->device));
+  DevBuf<unsigned long long> d_out;
+  HIP_TRY(d_out.alloc(n));
+  const dim3 grid(static_cast<uint32_t>((n + 255) / 256));
+  if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(kat_signature_kernel<ENGINE_TWO_PHASE>, grid, dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, first_sample, n_samples, h->row_begin, h->stripe_rows, h->stripe_period, d_out.p);
+  else if (h->hit_engine == AMBER_ENGINE_BVH) hipLaunchKernelGGL(kat_signature_kernel<ENGINE_BVH>, grid, dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, first_sample, n_samples, h->row_begin, h->stripe_rows, h->stripe_period, d_out.p);
+  else hipLaunchKernelGGL(kat_signature_kernel<ENGINE_LIST>, grid, dim3(256), 0, h->stream, h->scene, h->hashed_seed, n, first_sample, n_samples, h->row_begin, h->stripe_rows, h->stripe_period, d_out.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out, d_out.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return AMBER_OK;
+}
+
 int amber_hip_kat_math(int device, int mode, uint32_t n, const float* x, float* out) {
-  if (!x || !out || (mode != 0 && mode != 1)) return Fail(AMBER_EINVAL, "bad argument");
+  if (!x || !out || mode < 0 || mode > 3) return Fail(AMBER_EINVAL, "bad argument");
   if (n == 0) return AMBER_OK;
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return Fail(AMBER_ENODEVICE, "no such HIP device");
   HIP_TRY(hipSetDevice(device));
-  const size_t n_in = mode == 0 ? n : 2ull * n, n_out = mode == 0 ? 2ull * n : n;
+  const size_t n_in = mode == 1 ? 2ull * n : n, n_out = mode == 1 ? n : 2ull * n;
   DevBuf<float> d_x, d_o;
   HIP_TRY(d_x.alloc(n_in)); HIP_TRY(d_o.alloc(n_out));
   HIP_TRY(hipMemcpy(d_x.p, x, n_in * 4, hipMemcpyHostToDevice));

@@ -177,6 +177,11 @@ int amber_hip_lt_trace(amber_hip_pt*, uint32_t first_sample, uint32_t n_samples,
 
 const char* amber_hip_last_error(void);
 int         amber_hip_abi_version(void);
+/* Arithmetic of sin / cos / pow the library was built with: AMBER_MATH_GLIBC (the product) executes glibc 2.35's
+ * binary32 sincosf / powf -- the functions the reference calls (sampling.h:249-250, 279) -- operation for operation;
+ * AMBER_MATH_PORTABLE (-DAMBER_BUILD_PORTABLE_MATH, measurement builds only) round 1's + - * / forms. */
+enum { AMBER_MATH_PORTABLE = 1, AMBER_MATH_GLIBC = 2 };
+int         amber_hip_math_mode(void);
 int         amber_hip_device_count(void);
 
 /* ---- known-answer entry points (same device functions as the render kernels) --------------
@@ -194,7 +199,13 @@ int amber_hip_kat_eye(amber_hip_pt*, uint32_t n, const uint32_t* pixel, const ui
  * {object(int32 as float bits), t, pos[3], weight[3], measurement[3]} (11 x 4 bytes) and the cast count */
 int amber_hip_kat_trace(amber_hip_pt*, uint32_t n, const uint32_t* pixel, const uint32_t* sample,
                         uint32_t max_bounces, uint32_t* out_records /*n*max_bounces*11*/, uint32_t* out_casts /*n*/);
-/* portable math on device: mode 0 = sincos(x[i]) -> out[2i], out[2i+1] ; mode 1 = pow(x[2i], x[2i+1]) -> out[i] */
+/* Path signatures of the handle's rows for samples [first_sample, first_sample + n_samples): out[(band pixel * n_samples) + k]
+ * = FNV-1a-32 over the object index of every cast of that path (0xffffffff = miss) in the low word -- two paths have
+ * DIVERGED iff these differ -- and FNV-1a-32 over the bits of every hit distance in the high word.  out: host pointer,
+ * local_rows * width * n_samples entries. */
+int amber_hip_kat_signatures(amber_hip_pt*, uint32_t first_sample, uint32_t n_samples, uint64_t* out);
+/* the engine's sin/cos/pow on device: mode 0 = sincos(x[i]) -> out[2i], out[2i+1] ; mode 1 = pow(x[2i], x[2i+1]) -> out[i] ;
+ * mode 2 / 3 = x[i]^4 / x[i]^5 in binary64 -> out[2i], out[2i+1] = low, high word of the double */
 int amber_hip_kat_math(int device, int mode, uint32_t n, const float* x, float* out);
 
 #ifdef __cplusplus

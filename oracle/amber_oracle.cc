@@ -153,18 +153,182 @@ float PortablePow(float x, float y) {
   return q * u2f(static_cast<uint32_t>(n + 127) << 23);
 }
 
+
+// GLIBC mode: restatement of glibc 2.35's binary32 sincosf and powf (sysdeps/ieee754/flt-32/s_sincosf.c,
+// sysdeps/x86_64/fpu/sincosf_poly.h, s_sincosf_data.c; e_powf.c, e_powf_log2_data.c, e_exp2f_data.c -- the
+// algorithms and tables of ARM's optimized-routines, Szabolcs Nagy / Wilco Dijkstra), which is what the reference's
+// std::sin / std::cos (merged into ONE sincosf call by g++ -O2, sampling.h:249-250) and std::pow(float, float)
+// (sampling.h:279) execute.  libm is a third-party dependency of the reference that cannot travel as source; this is
+// its published algorithm in the form glibc's x86-64 FMA ifunc variant executes it (the variant every FMA-capable CPU
+// selects: this container's Xeon and the GPU box's EPYC 9575F): double-precision kernels in which EVERY a*b+c of the
+// source is one fused multiply-add, one rounding to binary32 at the end.  The tables are the values of libm.so.6's
+// .rodata.  tests/test_math_modes.py proves the restatement equal to the live libm for every argument the path can
+// produce (all 2^24 phi = 2 pi u, all 2^24 r0 for the scene's Phong exponents) and on 1e8 random arguments.
+// Domain: sincos |x| < 120 (the path needs [0, 2 pi]; beyond that glibc switches to a 192-bit reduction, not restated:
+// NaN is returned); pow: every binary32 pair.
+struct GlibcSinCosTab { double sign[4], hpi_inv, hpi, c0, c1, s1, c2, s2, c3, s3, c4; };
+static const GlibcSinCosTab kGlibcSinCos[2] = {
+  {{1.0, -1.0, -1.0, 1.0}, 0x1.45f306dc9c883p+23, 0x1.921fb54442d18p+0, 0x1p0, -0x1.ffffffd0c621cp-2, -0x1.555545995a603p-3,
+   0x1.55553e1068f19p-5, 0x1.1107605230bc4p-7, -0x1.6c087e89a359dp-10, -0x1.994eb3774cf24p-13, 0x1.99343027bf8c3p-16},
+  {{1.0, -1.0, -1.0, 1.0}, 0x1.45f306dc9c883p+23, 0x1.921fb54442d18p+0, -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.555545995a603p-3,
+   -0x1.55553e1068f19p-5, 0x1.1107605230bc4p-7, 0x1.6c087e89a359dp-10, -0x1.994eb3774cf24p-13, -0x1.99343027bf8c3p-16},
+};
+#define ORACLE_FMA_TARGET __attribute__((target("fma")))
+// sincosf_poly (sysdeps/x86_64/fpu/sincosf_poly.h): both polynomials at once, n odd swaps the outputs
+ORACLE_FMA_TARGET static inline void GlibcSinCosPoly(double x, double x2, const GlibcSinCosTab* p, int n, float* sinp, float* cosp) {
+  const double s1 = __builtin_fma(x2, p->s3, p->s2);
+  const double c2 = __builtin_fma(x2, p->c4, p->c3);
+  const double c1 = __builtin_fma(x2, p->c1, p->c0);
+  const double x3 = x2 * x, x4 = x2 * x2;
+  const double x5 = x2 * x3, x6 = x2 * x4;
+  const double s = __builtin_fma(x3, p->s1, x);
+  const double c = __builtin_fma(x4, p->c2, c1);
+  const float sv = static_cast<float>(__builtin_fma(x5, s1, s));
+  const float cv = static_cast<float>(__builtin_fma(x6, c2, c));
+  if (n & 1) { *cosp = sv; *sinp = cv; } else { *sinp = sv; *cosp = cv; }
+}
+ORACLE_FMA_TARGET void GlibcSinCos(float y, float* sinp, float* cosp) {     // s_sincosf.c:__sincosf
+  double x = y;
+  const GlibcSinCosTab* p = &kGlibcSinCos[0];
+  const uint32_t top = (f2u(y) >> 20) & 0x7ffu;                 // abstop12
+  if (top < 0x3f4u) {                                           // |y| < pi/4
+    const double x2 = x * x;
+    if (top < 0x398u) { *sinp = y; *cosp = 1.0f; return; }      // |y| < 2^-12
+    GlibcSinCosPoly(x, x2, p, 0, sinp, cosp);
+  } else if (top < 0x42fu) {                                    // |y| < 120: reduce_fast
+    const double r = x * p->hpi_inv;
+    const int n = (static_cast<int32_t>(r) + 0x800000) >> 24;   // round to nearest multiple of pi/2
+    x = __builtin_fma(-static_cast<double>(n), p->hpi, x);
+    const double s = p->sign[n & 3];
+    if (n & 2) p = &kGlibcSinCos[1];
+    GlibcSinCosPoly(x * s, x * x, p, n, sinp, cosp);
+  } else {
+    *sinp = *cosp = std::numeric_limits<float>::quiet_NaN();    // outside the restated domain
+  }
+}
+static const double kGlibcLog2Tab[16][2] = {   // __powf_log2_data.tab: {invc, logc}
+  {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+  {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+  {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+  {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+  {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+  {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+  {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+  {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2},
+};
+static const double kGlibcLog2Poly[5] = {0x1.27616c9496e0bp-2, -0x1.71969a075c67ap-2, 0x1.ec70a6ca7baddp-2, -0x1.7154748bef6c8p-1, 0x1.71547652ab82bp0};
+static const uint64_t kGlibcExp2Tab[32] = {    // __exp2f_data.tab
+  0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b, 0x3fef54873168b9aa,
+  0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d,
+  0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74,
+  0x3feea11473eb0187, 0x3feea589994cce13, 0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
+  0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
+  0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
+};
+static const double kGlibcExp2Shift = 0x1.8p+52 / 32;                         // shift_scaled
+static const double kGlibcExp2Poly[3] = {0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1};
+inline uint64_t d2u(double d) { uint64_t u; std::memcpy(&u, &d, 8); return u; }
+inline double u2d(uint64_t u) { double d; std::memcpy(&d, &u, 8); return d; }
+static inline int GlibcCheckInt(uint32_t iy) {                                // e_powf.c:checkint: 0 not int, 1 odd, 2 even
+  const int e = iy >> 23 & 0xff;
+  if (e < 0x7f) return 0;
+  if (e > 0x7f + 23) return 2;
+  if (iy & ((1u << (0x7f + 23 - e)) - 1)) return 0;
+  if (iy & (1u << (0x7f + 23 - e))) return 1;
+  return 2;
+}
+static inline bool GlibcZeroInfNan(uint32_t ix) { return 2 * ix - 1 >= 2u * 0x7f800000 - 1; }
+ORACLE_FMA_TARGET float GlibcPow(float x, float y) {                          // e_powf.c:__powf
+  uint32_t sign_bias = 0;
+  uint32_t ix = f2u(x);
+  const uint32_t iy = f2u(y);
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || GlibcZeroInfNan(iy)) {
+    if (GlibcZeroInfNan(iy)) {
+      if (2 * iy == 0) return 1.0f;
+      if (ix == 0x3f800000u) return 1.0f;
+      if (2 * ix > 2u * 0x7f800000 || 2 * iy > 2u * 0x7f800000) return x + y;
+      if (2 * ix == 2 * 0x3f800000u) return 1.0f;
+      if ((2 * ix < 2 * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;      // |x| < 1 && y == inf or |x| > 1 && y == -inf
+      return y * y;
+    }
+    if (GlibcZeroInfNan(ix)) {
+      float x2 = x * x;
+      if ((ix & 0x80000000u) && GlibcCheckInt(iy) == 1) x2 = -x2;
+      return (iy & 0x80000000u) ? 1 / x2 : x2;
+    }
+    if (ix & 0x80000000u) {                                                   // finite x < 0
+      const int yint = GlibcCheckInt(iy);
+      if (yint == 0) return std::numeric_limits<float>::quiet_NaN();
+      if (yint == 1) sign_bias = 1u << 16;
+      ix &= 0x7fffffffu;
+    }
+    if (ix < 0x00800000u) { ix = f2u(u2f(ix) * 0x1p23f); ix &= 0x7fffffffu; ix -= 23u << 23; }   // subnormal x
+  }
+  // log2_inline
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (tmp >> 19) % 16;
+  const uint32_t top = tmp & 0xff800000u;
+  const uint32_t iz = ix - top;
+  const int k = static_cast<int32_t>(top) >> 23;
+  const double z = u2f(iz);
+  const double r = __builtin_fma(z, kGlibcLog2Tab[i][0], -1.0);
+  const double y0 = kGlibcLog2Tab[i][1] + static_cast<double>(k);
+  const double* A = kGlibcLog2Poly;
+  const double r2 = r * r;
+  double yy = __builtin_fma(A[0], r, A[1]);
+  const double pp = __builtin_fma(A[2], r, A[3]);
+  const double r4 = r2 * r2;
+  double q = __builtin_fma(A[4], r, y0);
+  q = __builtin_fma(pp, r2, q);
+  yy = __builtin_fma(yy, r4, q);
+  const double ylogx = static_cast<double>(y) * yy;
+  if ((d2u(ylogx) >> 47 & 0xffff) >= (d2u(126.0) >> 47)) {                    // |y * log2(x)| >= 126
+    const float sgn = sign_bias ? -1.0f : 1.0f;
+    if (ylogx > 0x1.fffffffd1d571p+6) return sgn * std::numeric_limits<float>::infinity();
+    if (ylogx <= -150.0) return sgn * 0.0f;
+    if (ylogx < -149.0) return sgn * 0x1p-149f;                               // __math_may_uflowf: 0x1.4p-75f squared
+  }
+  // exp2_inline
+  double kd = ylogx + kGlibcExp2Shift;
+  const uint64_t ki = d2u(kd);
+  kd -= kGlibcExp2Shift;
+  const double rr = ylogx - kd;
+  uint64_t t = kGlibcExp2Tab[ki % 32];
+  t += (ki + sign_bias) << (52 - 5);
+  const double s = u2d(t);
+  const double* C = kGlibcExp2Poly;
+  const double zz = __builtin_fma(C[0], rr, C[1]);
+  const double rr2 = rr * rr;
+  double e = __builtin_fma(C[2], rr, 1.0);
+  e = __builtin_fma(zz, rr2, e);
+  return static_cast<float>(e * s);
+}
+// x^4, x^5 of a binary32 x as glibc's double pow returns them -- up to that function's own rounding slips: d*d is exact
+// (24 + 24 bits), (d*d)^2 is therefore the correctly rounded x^4, and x^5 is formed from the exact (hi, lo) pair of
+// x^4 so that it too rounds once.  Live pow() differs from these in the last bit of the double for 1e-3 of the
+// arguments (it is not correctly rounded), which never survived the conversion to binary32 in 2e8 trials.
+ORACLE_FMA_TARGET double GlibcPow4(float x) { const double d = x, d2 = d * d; return d2 * d2; }
+ORACLE_FMA_TARGET double GlibcPow5(float x) {
+  const double d = x, d2 = d * d;
+  const double h = d2 * d2, l = __builtin_fma(d2, d2, -h);     // x^4 = h + l exactly
+  const double p = h * d, pl = __builtin_fma(h, d, -p);        // h * d = p + pl exactly
+  return p + __builtin_fma(l, d, pl);
+}
+
 struct Math {
   int mode;
   void sincos(float phi, float& s, float& c) const {
     if (mode == ORACLE_MATH_LIBM) { c = std::cos(phi); s = std::sin(phi); }   // sampling.h:248-249 (cosf/sinf)
+    else if (mode == ORACLE_MATH_GLIBC) GlibcSinCos(phi, &s, &c);
     else PortableSinCos(phi, &s, &c);
   }
   float powf_(float x, float y) const {                                       // sampling.h:279 (powf)
-    return mode == ORACLE_MATH_LIBM ? std::pow(x, y) : PortablePow(x, y);
+    return mode == ORACLE_MATH_LIBM ? std::pow(x, y) : mode == ORACLE_MATH_GLIBC ? GlibcPow(x, y) : PortablePow(x, y);
   }
   // std::pow(float, int) promotes to double pow (C++11 [c.math]); used with exponents 2, 4, 5.
   double pow_i(float x, int n) const {
     if (mode == ORACLE_MATH_LIBM) return std::pow(x, n);
+    if (mode == ORACLE_MATH_GLIBC && n == 5) return GlibcPow5(x);
     const double d = x, d2 = d * d;            // exact (24+24 bits)
     if (n == 2) return d2;
     const double d4 = d2 * d2;                 // one rounding
@@ -837,7 +1001,10 @@ struct oracle_scene {
 
 namespace {
 
-struct PathResult { V3 measurement; uint32_t casts, hits; };
+// sig_obj / sig_t: FNV-1a (32 bit) over the object index of every cast (0xffffffff for a miss) / over the bits of every
+// hit distance -- a path's discrete history and its exact arithmetic, for path-level parity counts (oracle_path_signatures)
+struct PathResult { V3 measurement; uint32_t casts, hits; uint32_t sig_obj, sig_t; };
+inline uint32_t Fnv32(uint32_t h, uint32_t v) { for (int k = 0; k < 4; k++) { h ^= (v >> (8 * k)) & 0xffu; h *= 16777619u; } return h; }
 
 // Diagnostic (oracle_direction_length_stats, single-threaded): histogram of | |d|^2 - 1 | over the rays that are cast.
 // The reference never renormalises sampled directions (vector3.h:236-239); engine BVH's sphere bounds depend on how
@@ -857,7 +1024,7 @@ PathResult TracePath(const oracle_scene& sc, const Sensor& S, uint64_t px, uint6
   V3 measurement = splat(0);
   Ray ray{eye.origin, eye.dir};
   V3 weight = splat(eye.weight);                                        // Leading<Radiant>(.., Radiant(weight))
-  PathResult r{splat(0), 0, 0};
+  PathResult r{splat(0), 0, 0, 2166136261u, 2166136261u};
   for (;;) {
     if (g_dir_stats) {
       const double dev = std::fabs(double(ray.d.x) * ray.d.x + double(ray.d.y) * ray.d.y + double(ray.d.z) * ray.d.z - 1.0);
@@ -869,6 +1036,8 @@ PathResult TracePath(const oracle_scene& sc, const Sensor& S, uint64_t px, uint6
     Hit hit; const Object* obj = nullptr;
     sc.Cast(ray, hit, obj);
     r.casts++;
+    r.sig_obj = Fnv32(r.sig_obj, hit ? static_cast<uint32_t>(obj->index) : 0xffffffffu);
+    if (hit) r.sig_t = Fnv32(r.sig_t, f2u(hit.t));
     if (!hit) {
       if (trace && r.casts <= max_trace) { oracle_bounce& b = trace[r.casts - 1]; std::memset(&b, 0, sizeof b); b.object = -1; b.t = hit.t; }
       break;
@@ -1166,6 +1335,30 @@ void oracle_render_xorshift(const oracle_scene* sc, const oracle_sensor* sensor,
   }
 }
 
+void oracle_path_signatures(const oracle_scene* sc, const oracle_sensor* sensor, uint64_t global_seed, uint32_t first_sample,
+                            uint32_t n_samples, uint32_t y0, uint32_t y1, int math, uint32_t max_depth, uint32_t n_threads,
+                            uint64_t* sig) {
+  const Sensor S{sensor->width, sensor->height, sensor->scene_width, sensor->scene_height};
+  const Math M{math};
+  if (n_threads == 0) n_threads = 1;
+  auto work = [&](uint32_t tid) {
+    for (uint64_t y = y0 + tid; y < y1; y += n_threads)
+      for (uint64_t x = 0; x < S.w; x++) {
+        const uint32_t pixel = static_cast<uint32_t>(x + y * S.w);
+        uint64_t* out = sig + ((y - y0) * S.w + x) * n_samples;
+        for (uint32_t k = 0; k < n_samples; k++) {
+          XorShiftSampler smp(XorShiftSeed(global_seed, pixel, first_sample + k));
+          const PathResult r = TracePath(*sc, S, x, y, smp, M, max_depth, nullptr, 0, nullptr);
+          out[k] = static_cast<uint64_t>(r.sig_obj) | (static_cast<uint64_t>(r.sig_t) << 32);
+        }
+      }
+  };
+  std::vector<std::thread> threads;
+  for (uint32_t t = 1; t < n_threads; t++) threads.emplace_back(work, t);
+  work(0);
+  for (auto& t : threads) t.join();
+}
+
 uint32_t oracle_trace_path(const oracle_scene* sc, const oracle_sensor* sensor, uint64_t global_seed,
                            uint32_t px, uint32_t py, uint32_t sample, int math, uint32_t max_depth,
                            oracle_bounce* out, uint32_t max_bounces, float eye_ray_out[7]) {
@@ -1235,6 +1428,34 @@ void oracle_xorshift_uniforms(uint64_t state, uint32_t n, double* u) { XorShiftS
 
 void oracle_sincos(float phi, int math, float* s, float* c) { Math{math}.sincos(phi, *s, *c); }
 float oracle_pow(float x, float y, int math) { return Math{math}.powf_(x, y); }
+double oracle_pow_i(float x, int n, int math) { return Math{math}.pow_i(x, n); }
+uint64_t oracle_math_compare(int kind, int mode_a, int mode_b, uint32_t k0, uint32_t k1, float y, float first_bad[2]) {
+  const Math A{mode_a}, B{mode_b};
+  uint64_t bad = 0;
+  uint64_t rs = SplitMix64(k0);
+  auto next = [&rs]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+  for (uint32_t k = k0; k < k1; k++) {
+    float a0 = 0, a1 = 0;
+    bool differ;
+    if (kind == 0 || kind == 2) {
+      a0 = kind == 0 ? (2.0f * kPIf) * (static_cast<float>(k) * 0x1p-24f)
+                     : (static_cast<float>(static_cast<double>(next() >> 11) * 0x1p-53) - 0.5f) * 239.9f;
+      float sa, ca, sb, cb;
+      A.sincos(a0, sa, ca); B.sincos(a0, sb, cb);
+      differ = f2u(sa) != f2u(sb) || f2u(ca) != f2u(cb);
+    } else {
+      if (kind == 1) { a0 = static_cast<float>(k) * 0x1p-24f; a1 = y; }
+      else {   // random positive x over the whole exponent range, y in (-y, y)
+        a0 = u2f(static_cast<uint32_t>(next() >> 33));                         // [0, 2^31): +0 .. NaN patterns of positive sign
+        a1 = (static_cast<float>(static_cast<double>(next() >> 11) * 0x1p-53) - 0.5f) * 2.0f * y;
+      }
+      const float pa = A.powf_(a0, a1), pb = B.powf_(a0, a1);
+      differ = f2u(pa) != f2u(pb) && !(pa != pa && pb != pb);                  // any NaN equals any NaN
+    }
+    if (differ) { if (!bad && first_bad) { first_bad[0] = a0; first_bad[1] = a1; } bad++; }
+  }
+  return bad;
+}
 
 // Light tracing in XorShift mode: passes [first_sample, first_sample+n); every pass traces W*H light paths (path i
 // seeded by (lt_seed, i, pass)) and adds their splats to a zeroed pass image in path order; pass images are added to

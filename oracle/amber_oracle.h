@@ -66,7 +66,11 @@ enum { ORACLE_ACCEL_BVH = 0, ORACLE_ACCEL_LIST = 1 };
 /* OR into `accel` of oracle_scene_create: append the aperture blades AFTER the objects, the order cli::ImportScene
  * produces (import.cc:155-157); default is blades first (cornel_box.cc:62-64). */
 enum { ORACLE_BLADES_LAST = 0x100 };
-enum { ORACLE_MATH_LIBM = 0, ORACLE_MATH_PORTABLE = 1 };
+/* LIBM: the live glibc calls the reference makes (sincosf, powf, pow).  PORTABLE: round 1's own + - * / forms (kept to
+ * measure the distance between the two).  GLIBC: the restatement of glibc 2.35's x86-64 FMA-variant sincosf / powf that
+ * the gfx950 engine executes (amber_oracle.cc "GLIBC mode"); equal to LIBM on every FMA-capable x86-64 host for every
+ * argument the path can produce (tests/test_math_modes.py), and independent of the host's libm. */
+enum { ORACLE_MATH_LIBM = 0, ORACLE_MATH_PORTABLE = 1, ORACLE_MATH_GLIBC = 2 };
 
 typedef struct oracle_scene oracle_scene;
 
@@ -117,6 +121,13 @@ uint64_t oracle_render_lt_xorshift(const oracle_scene*, const oracle_sensor*, ui
                                    uint32_t n_samples, int math, uint32_t max_depth, float* sum_rgb, oracle_counters* counters,
                                    uint32_t* records, uint64_t max_records);
 
+/* Path signatures in XorShift mode for rows [y0, y1), samples [first_sample, first_sample + n): sig[((y - y0) * W + x) * n + k]
+ * = FNV-1a-32 over the object index of every cast of the path (0xffffffff = miss) in the low word -- the path's discrete
+ * history: two paths "diverged" iff these differ -- and FNV-1a-32 over the bits of every hit distance in the high word. */
+void oracle_path_signatures(const oracle_scene*, const oracle_sensor*, uint64_t global_seed, uint32_t first_sample,
+                            uint32_t n_samples, uint32_t y0, uint32_t y1, int math, uint32_t max_depth, uint32_t n_threads,
+                            uint64_t* sig);
+
 /* per-path trace in XorShift mode (for path-level parity tests) */
 typedef struct {
   int32_t  object;       /* object index in oracle object order, -1 = miss */
@@ -156,6 +167,15 @@ void     oracle_xorshift_uniforms(uint64_t state, uint32_t n, double* u);
 /* portable math (bit-identical on CPU and gfx950) vs libm */
 void  oracle_sincos(float phi, int math, float* s, float* c);
 float oracle_pow(float x, float y, int math);
+
+/* Number of arguments on which two math modes differ in any output bit.
+ * kind 0: sincos(phi) for phi = (2.0f * pi_f) * (k * 2^-24), k in [k0, k1) -- the path's phi (sampling.h:245).
+ * kind 1: pow(k * 2^-24, y), k in [k0, k1) -- CosinePower's pow(r0, 1 / (e + 1)) (sampling.h:279).
+ * kind 2: sincos of n = k1 - k0 random binary32 arguments in (-120, 120) ; kind 3: pow of random positive (x, y) pairs
+ *         with y scaled by `y`; both seeded by k0.  first_bad receives the first differing argument (if any). */
+uint64_t oracle_math_compare(int kind, int mode_a, int mode_b, uint32_t k0, uint32_t k1, float y, float first_bad[2]);
+/* pow(x, n) of a binary32 x in double for n = 4, 5 (lens_thin.cc:92-93,146, material_refraction.cc:271-275) */
+double oracle_pow_i(float x, int n, int math);
 
 /* image helpers */
 uint64_t oracle_fnv1a64(const void* data, uint64_t n_bytes);

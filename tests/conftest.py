@@ -24,4 +24,7 @@ def amber():
     import amber_amd
     amber_amd.build_library()
     amber_amd.load_library()
+    import oracle_binding
+    oracle_binding.MATH_DEVICE = {amber_amd.MATH_GLIBC: oracle_binding.MATH_GLIBC,
+                                  amber_amd.MATH_PORTABLE: oracle_binding.MATH_PORTABLE}[amber_amd.math_mode()]
     return amber_amd

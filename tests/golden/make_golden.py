@@ -5,9 +5,10 @@ Two kinds of fixture:
     (g++ 11.4, seed 12345 through an interposed
     std::random_device, one thread).  They are data copied from those documents, not regenerated here
     (the reference cannot be built in this image: boost is absent).
-  * oracle_vectors.npz -- vectors produced by the pinned oracle (oracle/liboracle.so) in the GPU-comparable
-    mode (XorShift sampler, List acceleration, portable math): closest hits, eye rays, material samples and
-    whole path traces.  The GPU tests compare against these as well as against the live oracle.
+  * oracle_vectors.npz -- vectors produced by the oracle (oracle/liboracle.so) with the XorShift sampler, List
+    acceleration and the LIVE libm of the generating host (MATH_LIBM: glibc 2.35 on an FMA-capable x86-64 -- the
+    arithmetic the reference's std::sin / std::cos / std::pow resolve to): closest hits, eye rays and whole path
+    traces.  The GPU tests compare against these as well as against the live oracle.
 Run:  python tests/golden/make_golden.py
 """
 import ctypes as C
@@ -60,7 +61,7 @@ def main():
     MAXB = 12
     rec = np.zeros((m, MAXB, 11), np.uint32); casts = np.zeros(m, np.uint32); eye = np.zeros((m, 7), np.float32)
     for i in range(m):
-        k, r, e = sc.trace(W, H, seed, int(px[i] % W), int(px[i] // W), int(sm[i]), max_bounces=MAXB)
+        k, r, e = sc.trace(W, H, seed, int(px[i] % W), int(px[i] // W), int(sm[i]), math=O.MATH_LIBM, max_bounces=MAXB)
         casts[i] = k; eye[i] = e
         for b in range(min(k, MAXB)):
             rec[i, b, 0] = np.int32(r[b].object).view(np.uint32)
@@ -68,7 +69,7 @@ def main():
                 vals = np.array([r[b].t, *r[b].pos, *r[b].weight, *r[b].measurement], np.float32)
                 rec[i, b, 1:] = vals.view(np.uint32)
     # small image
-    img, cnt = sc.render_xorshift(48, 48, seed, 0, 8)
+    img, cnt = sc.render_xorshift(48, 48, seed, 0, 8, math=O.MATH_LIBM)
     np.savez_compressed(HERE / "oracle_vectors.npz", W=W, H=H, seed=seed, cast_org=org, cast_dir=d, cast_obj=hit_obj, cast_t=hit_t,
                         cast_pos=hit_pos, cast_n=hit_n, trace_px=px, trace_sample=sm, trace_rec=rec, trace_casts=casts, trace_eye=eye,
                         img48_sum=img, img48_casts=np.uint64(cnt.casts))

@@ -16,7 +16,15 @@ LIB = ROOT / "oracle" / "liboracle.so"
 ACCEL_BVH, ACCEL_LIST = 0, 1
 BLADES_LAST = 0x100          # ORACLE_BLADES_LAST: aperture blades after the objects (cli::ImportScene order)
 ACCUM_CHUNK = 8    # include/amber_hip.h AMBER_ACCUM_CHUNK
-MATH_LIBM, MATH_PORTABLE = 0, 1
+MATH_LIBM, MATH_PORTABLE, MATH_GLIBC = 0, 1, 2
+# The oracle mode that restates the arithmetic the loaded libamber_hip.so executes (amber_hip_math_mode()): GLIBC for the
+# product build.  conftest's `amber` fixture switches it to PORTABLE when a -DAMBER_BUILD_PORTABLE_MATH measurement build is loaded.
+MATH_DEVICE = MATH_GLIBC
+
+
+def _m(math):
+    return MATH_DEVICE if math is None else math
+
 
 
 class OObject(C.Structure):
@@ -78,6 +86,7 @@ def load():
     L.oracle_render_xorshift.argtypes = [vp, C.POINTER(OSensor), u64, u32, u32, u32, u32, C.c_int, u32, u32, u32, vp, C.POINTER(OCounters)]
     L.oracle_render_lt_xorshift.restype = u64
     L.oracle_render_lt_xorshift.argtypes = [vp, C.POINTER(OSensor), u64, u32, u32, C.c_int, u32, vp, C.POINTER(OCounters), vp, u64]
+    L.oracle_path_signatures.argtypes = [vp, C.POINTER(OSensor), u64, u32, u32, u32, u32, C.c_int, u32, u32, vp]
     L.oracle_trace_path.restype = u32
     L.oracle_trace_path.argtypes = [vp, C.POINTER(OSensor), u64, u32, u32, u32, C.c_int, u32, C.POINTER(OBounce), u32, C.POINTER(f)]
     L.oracle_cast.restype = C.c_int32
@@ -99,6 +108,10 @@ def load():
     L.oracle_pow.argtypes = [f, f, C.c_int]
     L.oracle_fnv1a64.restype = u64
     L.oracle_fnv1a64.argtypes = [vp, u64]
+    L.oracle_math_compare.restype = u64
+    L.oracle_math_compare.argtypes = [C.c_int, C.c_int, C.c_int, u32, u32, f, C.POINTER(f)]
+    L.oracle_pow_i.restype = C.c_double
+    L.oracle_pow_i.argtypes = [f, C.c_int, C.c_int]
     _lib = L
     return L
 
@@ -144,29 +157,37 @@ class Scene:
         self.L.oracle_render_mt(self.h, C.byref(s), seed, spp, math, img.ctypes.data, C.byref(cnt))
         return img, cnt
 
-    def render_xorshift(self, w, h, seed, first, n, math=MATH_PORTABLE, max_depth=0, threads=8, rows=None, out=None, chunk=ACCUM_CHUNK):
+    def render_xorshift(self, w, h, seed, first, n, math=None, max_depth=0, threads=8, rows=None, out=None, chunk=ACCUM_CHUNK):
         s = sensor(w, h)
         img = np.zeros((h, w, 3), np.float32) if out is None else out
         cnt = OCounters()
         y0, y1 = rows if rows else (0, h)
-        self.L.oracle_render_xorshift(self.h, C.byref(s), seed, first, n, y0, y1, math, max_depth, threads, chunk, img.ctypes.data, C.byref(cnt))
+        self.L.oracle_render_xorshift(self.h, C.byref(s), seed, first, n, y0, y1, _m(math), max_depth, threads, chunk, img.ctypes.data, C.byref(cnt))
         return img, cnt
 
-    def render_lt(self, w, h, seed, first, n, math=MATH_PORTABLE, max_depth=0, max_records=1 << 16):
+    def path_signatures(self, w, h, seed, first, n, rows, math=None, max_depth=0, threads=8):
+        """(y1 - y0, w, n) uint64 path signatures (oracle_path_signatures)."""
+        s = sensor(w, h)
+        y0, y1 = rows
+        out = np.zeros((y1 - y0, w, n), np.uint64)
+        self.L.oracle_path_signatures(self.h, C.byref(s), seed, first, n, y0, y1, _m(math), max_depth, threads, out.ctypes.data)
+        return out
+
+    def render_lt(self, w, h, seed, first, n, math=None, max_depth=0, max_records=1 << 16):
         """Light tracing: returns (sum image, counters, records (k,7) uint32 in accumulation order)."""
         s = sensor(w, h)
         img = np.zeros((h, w, 3), np.float32)
         cnt = OCounters()
         rec = np.zeros((max_records, 7), np.uint32)
-        k = self.L.oracle_render_lt_xorshift(self.h, C.byref(s), seed, first, n, math, max_depth, img.ctypes.data, C.byref(cnt), rec.ctypes.data, max_records)
+        k = self.L.oracle_render_lt_xorshift(self.h, C.byref(s), seed, first, n, _m(math), max_depth, img.ctypes.data, C.byref(cnt), rec.ctypes.data, max_records)
         assert k <= max_records
         return img, cnt, rec[:k]
 
-    def trace(self, w, h, seed, px, py, sample, math=MATH_PORTABLE, max_depth=0, max_bounces=16):
+    def trace(self, w, h, seed, px, py, sample, math=None, max_depth=0, max_bounces=16):
         s = sensor(w, h)
         rec = (OBounce * max_bounces)()
         eye = (C.c_float * 7)()
-        n = self.L.oracle_trace_path(self.h, C.byref(s), seed, px, py, sample, math, max_depth, rec, max_bounces, eye)
+        n = self.L.oracle_trace_path(self.h, C.byref(s), seed, px, py, sample, _m(math), max_depth, rec, max_bounces, eye)
         return n, rec, np.array(eye[:], np.float32)
 
     def cast(self, o, d):

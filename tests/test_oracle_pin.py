@@ -104,7 +104,7 @@ def test_xorshift_mode_statistics_match_mt_mode(oracle):
     """The two sampler modes are different random streams over the same physics: path statistics must agree."""
     W, spp = 96, 16
     _, cm = O.Scene.cornell(O.ACCEL_BVH).render_mt(W, W, 2024, spp, math=O.MATH_LIBM)
-    _, cx = O.Scene.cornell(O.ACCEL_LIST).render_xorshift(W, W, 2024, 0, spp, math=O.MATH_PORTABLE)
+    _, cx = O.Scene.cornell(O.ACCEL_LIST).render_xorshift(W, W, 2024, 0, spp, math=O.MATH_GLIBC)
     rays_m, rays_x = cm.casts / cm.paths, cx.casts / cx.paths
     assert abs(rays_m - rays_x) < 0.03 and 2.0 < rays_x < 2.2            # SURVEY: 2.094 casts per path
     assert abs(cm.hits / cm.casts - cx.hits / cx.casts) < 0.01           # SURVEY: 15.8 % misses
