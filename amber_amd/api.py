@@ -75,7 +75,7 @@ ENGINE_AUTO, ENGINE_LIST, ENGINE_TWO_PHASE, ENGINE_BVH, ENGINE_WAVEFRONT = 0, 1,
 # every symbol include/amber_hip.h and include/amber_host.h declare
 ABI_SYMBOLS = [
     "amber_hip_pt_create", "amber_hip_pt_render_pass", "amber_hip_pt_clear", "amber_hip_pt_sync",
-    "amber_hip_pt_download", "amber_hip_pt_device_framebuffer", "amber_hip_pt_local_rows", "amber_hip_pt_kernel_time", "amber_hip_pt_destroy",
+    "amber_hip_pt_download", "amber_hip_pt_device_framebuffer", "amber_hip_pt_stream", "amber_hip_pt_local_rows", "amber_hip_pt_kernel_time", "amber_hip_pt_destroy",
     "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_math_mode", "amber_hip_device_count", "amber_hip_lt_trace",
     "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math", "amber_hip_kat_signatures",
     "amber_host_cornell_box", "amber_host_scene_import", "amber_host_scene_create", "amber_host_scene_destroy", "amber_host_scene_flatten",
@@ -116,6 +116,7 @@ def load_library() -> C.CDLL:
     lib.amber_hip_pt_download.argtypes = [vp, vp, C.POINTER(u64)]
     lib.amber_hip_pt_device_framebuffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     lib.amber_hip_pt_local_rows.argtypes = [vp, C.POINTER(u32)]
+    lib.amber_hip_pt_stream.argtypes = [vp, C.POINTER(vp)]
     lib.amber_hip_pt_kernel_time.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_double)]
     lib.amber_hip_pt_destroy.argtypes = [vp]
     lib.amber_hip_pt_destroy.restype = None
@@ -289,6 +290,13 @@ class PathTracer:
         rays = C.c_uint64()
         _check(load_library().amber_hip_pt_download(self._h, None, C.byref(rays)))
         return rays.value
+
+    def stream(self) -> int:
+        """hipStream_t (as an integer) the handle's work is enqueued on; wrap it with torch.cuda.ExternalStream to order
+        collectives after the render."""
+        p = C.c_void_p()
+        _check(load_library().amber_hip_pt_stream(self._h, C.byref(p)))
+        return p.value or 0
 
     def device_framebuffer(self):
         p, n = C.c_void_p(), C.c_uint64()

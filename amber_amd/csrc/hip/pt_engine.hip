@@ -569,7 +569,9 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   if (params->device < 0 || params->device >= n_dev) return Fail(AMBER_ENODEVICE, "device ordinal out of range");
   uint32_t rb = params->row_begin, re = params->row_end;
   if (rb == 0 && re == 0) re = sensor->height;
-  if (rb >= re || re > sensor->height) return Fail(AMBER_EINVAL, "bad row band");
+  // rb == re (other than 0,0) is an EMPTY band: a rank beyond the number of stripes (distributed.stripe_partition) still
+  // creates a handle, whose render_pass / clear / download are no-ops, so that it can take part in the gather
+  if (rb > re || re > sensor->height) return Fail(AMBER_EINVAL, "bad row band");
   uint32_t local_rows = re - rb;
   if (params->stripe_rows) {
     if (params->stripe_period < params->stripe_rows) return Fail(AMBER_EINVAL, "stripe_period must be >= stripe_rows");
@@ -588,6 +590,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   h->seed = params->seed; h->hashed_seed = HostSplitMix64(params->seed);
   h->hashed_seed_lt = HostSplitMix64(params->seed + 0x6C74ull);     // light paths use streams of their own
   if (params->stream) { h->stream = static_cast<hipStream_t>(params->stream); }
+  else if (params->reserved & AMBER_PT_FLAG_NULL_STREAM) { h->stream = nullptr; }     // the legacy default stream, on request
   else {
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return Fail(AMBER_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
@@ -638,7 +641,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   amber_bvh::FlatBvh bvh;
   if (h->hit_engine == AMBER_ENGINE_BVH) {
     bvh = amber_bvh::BuildBvh(objs);
-    if (bvh.depth > static_cast<uint32_t>(amber_bvh::kMaxDepth)) { delete h; return Fail(AMBER_EINVAL, "BVH deeper than the device stack"); }
+    if (bvh.depth > static_cast<uint32_t>(amber_bvh::kMaxDepth)) { amber_hip_pt_destroy(h); return Fail(AMBER_EINVAL, "BVH deeper than the device stack"); }
     h->bvh_depth = bvh.depth;
   }
   amber_filter::FilterProgram fprog;
@@ -712,7 +715,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMemcpy(h->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_blades, blades.data(), blades.size() * sizeof(DevBlade), hipMemcpyHostToDevice));
   const size_t fb_floats = static_cast<size_t>(local_rows) * sensor->width * 3;
-  HIP_TRY_H(hipMalloc(&h->d_fb, fb_floats * sizeof(float)));
+  HIP_TRY_H(hipMalloc(&h->d_fb, (fb_floats ? fb_floats : 1) * sizeof(float)));
   HIP_TRY_H(hipMalloc(&h->d_rays, sizeof(unsigned long long)));
   HIP_TRY_H(hipMalloc(&h->d_next, sizeof(unsigned int)));
 #ifdef AMBER_STAMPS
@@ -887,8 +890,9 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
   if (n_samples == 0) return AMBER_OK;
   if (static_cast<uint64_t>(first_sample) + n_samples > 0xffffffffull) return Fail(AMBER_EINVAL, "sample index overflow");
   HIP_TRY(hipSetDevice(h->device));
-  if (h->engine == AMBER_ENGINE_WAVEFRONT) return RenderPassWavefront(h, first_sample, n_samples);
   const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
+  if (n_pixels == 0) return AMBER_OK;                    // empty band
+  if (h->engine == AMBER_ENGINE_WAVEFRONT) return RenderPassWavefront(h, first_sample, n_samples);
   // a launch covers at most kMaxPartialFloats of per-item sums and < 2^31 items; longer passes are split on
   // chunk boundaries, which leaves the summation order (chunks in order) unchanged
   const uint64_t kMaxPartialFloats = 768ull << 20;    // 3 GiB
@@ -1031,6 +1035,12 @@ int amber_hip_pt_device_framebuffer(amber_hip_pt* h, void** dptr, uint64_t* n_fl
   if (!h || !dptr) return Fail(AMBER_EINVAL, "null argument");
   *dptr = h->d_fb;
   if (n_floats) *n_floats = static_cast<uint64_t>(h->local_rows) * h->scene.sensor.w * 3;
+  return AMBER_OK;
+}
+
+int amber_hip_pt_stream(amber_hip_pt* h, void** stream) {
+  if (!h || !stream) return Fail(AMBER_EINVAL, "null argument");
+  *stream = h->stream;
   return AMBER_OK;
 }
 

@@ -110,4 +110,6 @@ def band_tensor(tracer, device: str = "cuda"):
     ptr, n = tracer.device_framebuffer()
     shape = tracer.band_shape
     assert n == int(np.prod(shape))
+    if n == 0:                                   # empty band (more ranks than stripes): nothing to alias
+        return torch.empty(shape, dtype=torch.float32, device=device)
     return torch.as_tensor(DeviceArray(ptr, shape), device=device)

@@ -5,7 +5,10 @@ A "step" is one complete render of BASELINE.json's configs[1]: Cornell box, 1024
 pixel (1.07e9 paths, ~2.25e9 rays), i.e. one pass of the hot path over the whole job.  For N > 1 the
 framebuffer rows are dealt to the N ranks in interleaved 8-row stripes (strong scaling: the job is fixed), every
 rank renders its rows with its own scene replica, and each step ends with the single gather of the row sums
-to rank 0 (RCCL).
+to rank 0 (RCCL), enqueued on the stream the render runs on.
+
+`python bench.py --gpus N` starts its own N ranks (a torch.distributed.run child process) when it was not itself
+started by a launcher; under a launcher (RANK / WORLD_SIZE in the environment) it is one of the ranks.
 
 Prints ONE JSON line on rank 0.  `value` = rays of all ranks / max-over-ranks wall time of the K timed
 steps (inputs resident in HBM; barrier + synchronize on both sides).
@@ -15,6 +18,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -45,36 +50,106 @@ def measured_copy_bandwidth(torch, device) -> float:
     return 2.0 * 4.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def cpu_baseline(width: int, seed: int, budget_s: float = 15.0):
-    """The CPU restatement (oracle, kind "port") on the host cores, reference threading model (rows of whole-image
-    1-spp passes pulled by T threads), on a bounded sample of the SAME workload: full 1024x1024 frame, few spp."""
-    sys.path.insert(0, str(ROOT / "tests"))
-    import numpy as np
-    import oracle_binding as O
-
+def host_cores():
+    """(cores this process may run on, cores its cgroup's CPU quota lets it use at once)."""
     try:
-        cores = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("AMBER_BENCH_CPU_THREADS", "16"))))   # a 1-GPU box's CPU share is 16 cores
+        n = os.cpu_count() or 1
+    quota = n
+    try:
+        q, p = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]            # cgroup v2
+        if q != "max":
+            quota = max(1, -(-int(q) // int(p)))
+    except Exception:
+        try:                                                                         # cgroup v1
+            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            p = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0:
+                quota = max(1, -(-q // p))
+        except Exception:
+            pass
+    return n, min(n, quota)
+
+
+def cpu_baseline(amber_amd, width: int, spp_job: int, seed: int, many_s: float = 5.0, one_s: float = 2.5):
+    """The CPU leg (the only place bench.py touches oracle/): (1) the CPU restatement (oracle, kind "port") timed on the
+    host cores with the reference's threading model (rows of whole-image 1-spp passes pulled by T threads,
+    parallel.h:50-54), reference BVH and the host's libm, on a bounded sample of the SAME workload -- the full frame at a
+    few spp -- with T = every core this process may use and with T = 1; (2) the same oracle as the CHECKER of the
+    GPU's output: 16 full-width rows of the job at ALL its samples, images / ray counts / per-path signatures
+    (tests/parity_rows.py).  Returns (cpu_baseline, parity)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_binding as O
+    from parity_rows import compare_rows
+
+    nproc, usable = host_cores()
+    cores = max(1, min(usable, int(os.environ.get("AMBER_BENCH_CPU_THREADS", "256"))))
     sc = O.Scene.cornell(O.ACCEL_BVH)          # the reference's own acceleration structure
-    t0 = time.perf_counter()
-    _, cnt = sc.render_xorshift(width, width, seed, 0, 1, math=O.MATH_LIBM, threads=cores)
-    dt1 = time.perf_counter() - t0
-    spp = max(1, min(512, int(budget_s / max(dt1, 1e-3))))
-    t0 = time.perf_counter()
-    _, cnt = sc.render_xorshift(width, width, seed, 1, spp, math=O.MATH_LIBM, threads=cores)
-    dt = time.perf_counter() - t0
-    out = {"value": round(cnt.casts / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-           "sample": f"Cornell {width}x{width} @ {spp} spp of the 1024 ({cnt.casts} rays in {dt:.2f} s), oracle in BVH/libm mode, "
-                     f"{cores} threads; scale linearly in spp"}
-    if cores > 1:                                # SURVEY.md 8(d): also one thread (a quarter of the frame's rows, 1 spp)
+
+    def timed(first, n, threads, rows=None):
         t0 = time.perf_counter()
-        _, c1 = sc.render_xorshift(width, width, seed, 0, 1, math=O.MATH_LIBM, threads=1, rows=(0, max(1, width // 4)))
-        d1 = time.perf_counter() - t0
-        out["single_thread_value"] = round(c1.casts / d1 / 1e6, 3)
-        out["sample"] += f"; 1 thread: rows 0..{max(1, width // 4)} @ 1 spp ({c1.casts} rays in {d1:.2f} s)"
-    return out
+        _, c = sc.render_xorshift(width, width, seed, first, n, math=O.MATH_LIBM, threads=threads, rows=rows)
+        return c.casts, time.perf_counter() - t0
+
+    timed(0, 1, cores)                                                    # warms the pages
+    _, dt1 = timed(1, 4, cores)                                           # calibration (4 spp: long enough to see a CPU quota bite)
+    spp = max(1, min(spp_job, int(many_s / max(dt1 / 4, 1e-3))))
+    casts, dt = timed(5, spp, cores)
+    out = {"value": round(casts / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "nproc": nproc,
+           "sample": f"Cornell {width}x{width} @ {spp} spp of the {spp_job} ({casts} rays in {dt:.2f} s), oracle: XorShift sampler, "
+                     f"reference BVH, host libm, {cores} threads (nproc {nproc}, cgroup CPU quota {usable}); scale linearly in spp"}
+    if cores > 1:                                                         # SURVEY.md 8(d): also ONE thread, >= 2 s of it
+        rows1 = (0, width)
+        c0, d0 = timed(0, 1, 1, rows=(0, max(1, width // 8)))             # calibration on an eighth of the frame
+        spp1 = max(1, int(one_s / max(d0 * 8, 1e-3)))
+        c1, d1 = timed(1, spp1, 1, rows=rows1)
+        out["single_thread_value"] = round(c1 / d1 / 1e6, 3)
+        out["sample"] += f"; 1 thread: full frame @ {spp1} spp ({c1} rays in {d1:.2f} s)"
+    parity = compare_rows(amber_amd, width, spp_job, seed, threads=cores, math=O.MATH_LIBM, accel=O.ACCEL_BVH)
+    return out, parity
+
+
+def latest_profile_summary():
+    """VALU-side figures of the dominant kernel from the newest committed rocprofv3 PMC summary (profiles/rNN*_summary.json,
+    written by tools/summarize_profile.py): the kernel is VALU-issue-bound, not HBM-bound, and the line says so."""
+    best = None
+    for p in sorted((ROOT / "profiles").glob("r*_summary.json")):
+        try:
+            d = json.loads(p.read_text())
+        except Exception:
+            continue
+        if isinstance(d, dict) and "valu" in d:
+            best = (p.name, d)
+    return best
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (never exec: nothing here has
+    touched the GPU yet, and nothing will in this parent), relay rank 0's JSON line, propagate the exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            lines.append(line)
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if lines:
+        sys.stdout.write(lines[-1])
+        sys.stdout.flush()
+    return rc if rc else (0 if lines else 1)
 
 
 def main():
@@ -92,6 +167,9 @@ def main():
     ap.add_argument("--engine", default="auto", choices=["auto", "list", "two_phase", "bvh", "wavefront"],
                     help="closest-hit / scheduling engine (default: auto = the fastest valid one; others for comparison)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -112,8 +190,9 @@ def main():
     dist = None
     force_collective = world == 1 and os.environ.get("AMBER_BENCH_FORCE_COLLECTIVE") == "1"   # one-rank RCCL rehearsal of the N > 1 code path
     if force_collective:
-        os.environ.setdefault("MASTER_PORT", "29571")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
     json_fd = 1
+    backend = None
     if world > 1 or force_collective:
         # RCCL prints a version banner on STDOUT when the communicator is created; the contract is ONE JSON line on
         # stdout, so everything else written to fd 1 from here on goes to stderr and the JSON line to the saved fd
@@ -122,7 +201,8 @@ def main():
         os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_on_one_gpu:
+        backend = "gloo" if args.rehearse_on_one_gpu else "nccl"
+        if backend == "gloo":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -132,9 +212,11 @@ def main():
     scene = amber_amd.HostScene.cornell_box()                      # etude::CornelBox(0.050, 0.050, 6), application.cc:68-73
     parts = stripe_partition(H, world)                             # interleaved 8-row stripes: equal work per rank
     mine = parts[rank]
-    stream = torch.cuda.current_stream().cuda_stream              # launch on torch's stream: ordered with the gather
+    # The handle renders on a stream of its own; the gather is enqueued on THAT stream (torch sees it as an external
+    # stream), so the collective is ordered after the render without a host synchronisation in between.
     tracer = amber_amd.PathTracer(scene, sensor, seed=args.seed, device=local_rank, rows=mine["rows"], stripe=mine["stripe"],
-                                  stream=stream, engine={"auto": 0, "list": 1, "two_phase": 2, "bvh": 3, "wavefront": 4}[args.engine])
+                                  engine={"auto": 0, "list": 1, "two_phase": 2, "bvh": 3, "wavefront": 4}[args.engine])
+    render_stream = torch.cuda.ExternalStream(tracer.stream(), device=torch.device("cuda", local_rank))
     fb = band_tensor(tracer, f"cuda:{local_rank}")
     launches = [(s, min(args.spp_per_launch, args.spp - s)) for s in range(0, args.spp, args.spp_per_launch)]
     gather = RowGatherer(parts, W, rank, world, "cpu" if (args.rehearse_on_one_gpu and world > 1) else fb.device, force_collective=force_collective)   # buffers allocated once
@@ -144,9 +226,10 @@ def main():
         for first, n in launches:
             tracer.render_pass(first, n)
         if args.rehearse_on_one_gpu and world > 1:
-            torch.cuda.synchronize()
+            tracer.sync()
             return gather(fb.cpu())                                # gloo: host tensors
-        return gather(fb)                                          # the single collective of the job
+        with torch.cuda.stream(render_stream):
+            return gather(fb)                                      # the single collective of the job
 
     def fence():
         torch.cuda.synchronize()
@@ -157,9 +240,9 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    rays_before = tracer.ray_count()                               # clear() in step() resets it; take the last step's count below
     t0 = time.perf_counter()
     total_rays_local, kernel_ms, n_launch = 0, 0.0, 0
+    img = None
     for _ in range(args.steps):
         img = step()
         # ray counter and kernel times are read after the step's work is enqueued; download syncs the stream
@@ -179,7 +262,8 @@ def main():
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
     dt_max, rays, kern_ms = float(t.item()), int(r.item()), float(k.item())
 
-    if rank == 0 and os.environ.get("AMBER_BENCH_SAVE_IMAGE"):
+    if rank == 0 and os.environ.get("AMBER_BENCH_SAVE_IMAGE") and img is not None:
+        torch.cuda.synchronize()
         np.save(os.environ["AMBER_BENCH_SAVE_IMAGE"], img.detach().cpu().numpy())
     if rank == 0:
         rays_per_launch_local = total_rays_local / max(n_launch, 1)
@@ -198,19 +282,30 @@ def main():
             "config": {"workload": f"Cornell box (etude::CornelBox(0.050,0.050,6)) {W}x{H} @ {args.spp} spp, RR-only path tracing, "
                                    f"per-(pixel,sample) XorShift seed {args.seed}", "rays_per_step": rays // args.steps,
                        "paths_per_step": W * H * args.spp, "wall_s_per_step": round(dt_max / args.steps, 4),
-                       "parallelism": f"stripes{world}x8rows", "launches_per_step": len(launches), "engine": "work-queue megakernel, two-phase closest hit" if args.engine == "auto" else args.engine},
+                       "parallelism": f"stripes{world}x8rows", "launches_per_step": len(launches), "engine": "work-queue megakernel, two-phase closest hit" if args.engine == "auto" else args.engine,
+                       "math": {amber_amd.MATH_GLIBC: "glibc 2.35 sincosf/powf kernels (the reference's libm)", amber_amd.MATH_PORTABLE: "portable (measurement build)"}[amber_amd.math_mode()]},
+            "ranks": world, "collective_backend": ("rccl" if backend == "nccl" else backend),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel": "pt_megakernel" if args.engine != "wavefront" else "wf_generate + wf_bounce launches of one batch", "kernel_ms": round(kern_ms, 3),
-                         "note": "achieved = rays per launch (rank 0) x 96 B algorithmic ray-state bytes / mean launch duration (hipEvents)"},
+                         "note": "contractual figure (SURVEY 8(d)): achieved = rays per launch (rank 0) x 96 B algorithmic ray-state bytes / mean launch "
+                                 "duration (hipEvents). The kernel keeps ray state in VGPRs: its measured HBM traffic is `traffic` bytes per launch and the "
+                                 "resource that binds it is VALU issue -- see `valu`"},
         }
+        if backend == "nccl":
+            out["rccl_ranks"] = world
         profs = sorted((ROOT / "profiles").glob("r*_hbm_traffic.json"))      # latest committed rocprofv3 PMC summary
         if profs:
             try:
                 out["roofline"]["traffic"] = json.loads(profs[-1].read_text()).get("hbm_bytes_per_launch")
                 out["roofline"]["traffic_source"] = f"profiles/{profs[-1].name}"
+                if out["roofline"]["traffic"] and kern_ms > 0:
+                    out["roofline"]["measured_hbm_gbs"] = round(out["roofline"]["traffic"] / (kern_ms * 1e-3) / 1e9, 1)
             except Exception:
                 pass
+        summ = latest_profile_summary()
+        if summ:
+            out["roofline"]["valu"] = dict(summ[1]["valu"], source=f"profiles/{summ[0]}")
         if world == 1:
             try:
                 bw = measured_copy_bandwidth(torch, f"cuda:{local_rank}")
@@ -220,7 +315,7 @@ def main():
                 out["roofline"]["measured_copy_bw"] = None
                 out["roofline"]["measured_copy_bw_error"] = str(e)[:120]
         if not args.no_cpu_baseline and world == 1:                    # reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(W, args.seed)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(amber_amd, W, args.spp, args.seed)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

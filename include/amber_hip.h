@@ -124,12 +124,16 @@ typedef struct {
   int32_t  device;      /* HIP device ordinal */
   uint32_t row_begin;   /* this handle renders framebuffer rows [row_begin, row_end) -- multi-GPU sharding */
   uint32_t row_end;     /* 0,0 = all rows */
-  void*    stream;      /* hipStream_t to launch on; NULL = a stream owned by the handle */
+  void*    stream;      /* hipStream_t to launch on; NULL = a NON-BLOCKING stream owned by the handle (it does not synchronise
+                           with the legacy default stream: order other work after it with amber_hip_pt_sync or by enqueueing
+                           on amber_hip_pt_stream); NULL + AMBER_PT_FLAG_NULL_STREAM in `reserved` = the legacy default stream */
   uint32_t engine;      /* AMBER_ENGINE_* */
   uint32_t stripe_rows; /* 0: every row of [row_begin,row_end).  S > 0: only the rows y with                */
   uint32_t stripe_period; /* (y - row_begin) % stripe_period < S  (interleaved stripes: rank r of N uses     */
-  uint32_t reserved;    /* row_begin = r*S, row_end = height, stripe_period = N*S).  Local rows are compact. */
+  uint32_t reserved;    /* row_begin = r*S, row_end = height, stripe_period = N*S).  Local rows are compact.      */
+                        /* `reserved` carries AMBER_PT_FLAG_* bits (0 = none). row_begin == row_end != 0: empty band.   */
 } AmberPtParams;
+enum { AMBER_PT_FLAG_NULL_STREAM = 1u };
 
 /* All engines are the same persistent work-queue kernel; they differ in how a lane finds its closest hit.
  * Every engine returns the List-semantics answer (closest finite hit, ties to the lower object index). */
@@ -159,6 +163,9 @@ int  amber_hip_pt_sync(amber_hip_pt*);
 int  amber_hip_pt_download(amber_hip_pt*, float* rgb_sum, uint64_t* ray_count);
 /* Device pointer of the band framebuffer (float, rows*width*3) for zero-copy hand-off to RCCL. */
 int  amber_hip_pt_device_framebuffer(amber_hip_pt*, void** dptr, uint64_t* n_floats);
+/* The hipStream_t every launch and copy of this handle is enqueued on (NULL = the legacy default stream): work that
+ * consumes the device framebuffer (an RCCL gather, a peer copy) is ordered after the render by enqueueing it there. */
+int  amber_hip_pt_stream(amber_hip_pt*, void** stream);
 /* Number of framebuffer rows this handle owns (after striping). */
 int  amber_hip_pt_local_rows(amber_hip_pt*, uint32_t* n_rows);
 /* Per-launch timing of the dominant kernel, measured with hipEvents on the handle's stream:

@@ -26,8 +26,20 @@ import oracle_binding as O
 DEFAULT_BANDS = ((250, 254), (508, 512), (700, 704), (900, 904))      # wall / back wall + light row / spheres / floor + water
 
 
-def compare_rows(amber, width: int = 1024, spp: int = 1024, seed: int = 12345, bands=DEFAULT_BANDS, threads: int = 8,
+def bands_for(height: int):
+    """DEFAULT_BANDS scaled to another frame height (4 rows each, clipped)."""
+    if height == 1024:
+        return DEFAULT_BANDS
+    out = []
+    for y0, _ in DEFAULT_BANDS:
+        a = min(max(0, y0 * height // 1024), max(0, height - 1))
+        out.append((a, min(height, a + 4)))
+    return tuple(out)
+
+
+def compare_rows(amber, width: int = 1024, spp: int = 1024, seed: int = 12345, bands=None, threads: int = 8,
                  math: int = O.MATH_LIBM, accel: int = O.ACCEL_BVH, signatures: bool = True, tol: float = 1e-4) -> dict:
+    bands = bands_for(width) if bands is None else bands
     hs = amber.HostScene.cornell_box()
     sensor = amber.Sensor.default(width, width)
     osc = O.Scene.cornell(accel)

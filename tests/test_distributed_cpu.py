@@ -22,7 +22,7 @@ import oracle_binding as O
 from amber_amd.distributed import stripe_partition, gather_rows
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-W, H, spp, seed = 40, 52, 3, 31
+W, H, spp, seed = 40, {height}, 3, 31
 parts = stripe_partition(H, world, 4)
 idx = parts[rank]["index"]
 sc = O.Scene.cornell(O.ACCEL_LIST)
@@ -39,17 +39,17 @@ dist.barrier(); dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_band_sharding_gloo(tmp_path, world):
+@pytest.mark.parametrize("world,height", [(2, 52), (3, 52), (3, 8)])       # (3, 8): two 4-row stripes, rank 2 owns an EMPTY band
+def test_band_sharding_gloo(tmp_path, world, height):
     import subprocess
     import oracle_binding as O
     out = str(tmp_path / "img.npy")
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=str(ROOT), out=out))
+    script.write_text(WORKER.format(root=str(ROOT), out=out, height=height))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + world + os.getpid() % 200))
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                     "--master-port", env["MASTER_PORT"], str(script)], check=True, env=env, timeout=300)
     got = np.load(out)
-    ref, cnt = O.Scene.cornell(O.ACCEL_LIST).render_xorshift(40, 52, 31, 0, 3)
+    ref, cnt = O.Scene.cornell(O.ACCEL_LIST).render_xorshift(40, height, 31, 0, 3)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     assert int(np.load(out + ".rays.npy")[0]) == cnt.casts

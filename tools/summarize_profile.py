@@ -45,5 +45,15 @@ if {"SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU"} <= pmc.keys():
     summary["valu_lane_utilisation"] = pmc["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / (pmc["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 64)
 if "GRBM_GUI_ACTIVE" in pmc and "kernel_trace" in summary:
     summary["effective_clock_ghz"] = pmc["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8 / summary["kernel_trace"]["average_ns"]
+if "SQ_INSTS_VALU" in pmc and "effective_clock_ghz" in summary:
+    # VALU-issue view of the kernel (bench.py copies this object into roofline.valu): SIMD cycles available per VALU
+    # wave-instruction against the measured issue floor of 2.04 cycles (tools/ifetch_rate.hip, profiles/r01_ifetch_rate.txt)
+    simd_cycles = summary["kernel_trace"]["average_ns"] * summary["effective_clock_ghz"] * 1024
+    cpv = simd_cycles / pmc["SQ_INSTS_VALU"]["mean_per_launch"]
+    summary["valu"] = {"valu_wave_instructions": pmc["SQ_INSTS_VALU"]["mean_per_launch"], "cycles_per_valu": round(cpv, 3),
+                       "issue_floor_cycles": 2.04, "issue_frac": round(2.04 / cpv, 4),
+                       "lane_util": round(summary.get("valu_lane_utilisation", 0.0), 4), "clock_ghz": round(summary["effective_clock_ghz"], 3),
+                       "wait_inst_any_frac": round(pmc["SQ_WAIT_INST_ANY"]["mean_per_launch"] / pmc["SQ_WAVE_CYCLES"]["mean_per_launch"], 4) if {"SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"} <= pmc.keys() else None,
+                       "wait_any_frac": round(pmc["SQ_WAIT_ANY"]["mean_per_launch"] / pmc["SQ_WAVE_CYCLES"]["mean_per_launch"], 4) if {"SQ_WAIT_ANY", "SQ_WAVE_CYCLES"} <= pmc.keys() else None}
 (dst / f"{tag}_summary.json").write_text(json.dumps(summary, indent=2) + "\n")
 print(json.dumps({k: v for k, v in summary.items() if k != "pmc"}, indent=2))
