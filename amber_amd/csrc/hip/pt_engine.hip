@@ -43,7 +43,9 @@ int Fail(int code, const std::string& msg) { g_last_error = msg; return code; }
 // ------------------------------------------------------------------------------------------------
 struct RenderArgs {
   DevScene scene;
-  float* partial;            // [n_chunks][n_pixels][3] per-item sums of this launch
+  float* partial;            // pt_bvh_megakernel: [n_chunks][n_pixels][3] per-item sums of this launch
+  uint32_t* flags;           // pt_megakernel: bit q set = path q of this launch ended with a non-zero measurement ...
+  float* values;             // ... stored in values[3q .. 3q+2]
   unsigned long long* ray_count;
   unsigned int* next_item;   // work-queue head (zeroed before every launch)
   unsigned long long* stamps; // diagnostic build only (AMBER_STAMPS): 8 section sums
@@ -55,34 +57,55 @@ struct RenderArgs {
   uint32_t stripe_rows, stripe_period;   // 0,0 = contiguous rows
   uint32_t n_pixels;         // pixels of the band
   uint32_t first_sample, n_samples;
-  uint32_t n_chunks, n_items;
+  uint32_t n_chunks, n_items;   // pt_bvh_megakernel: items = (pixel, chunk); pt_megakernel: n_items = paths of the launch
 };
 
-// Work item = (pixel of the band, chunk of AMBER_ACCUM_CHUNK consecutive samples).  Waves are persistent
-// workers: a wave claims 64 items at a time from the global queue head with ONE atomic, and hands them to
-// its lanes with a ballot + prefix count (mbcnt) whenever lanes run dry, so no lane idles until the queue is
-// empty.  A lane walks the samples of its item in order (sum += measurement), regenerating the eye ray in
-// place when a path ends, and stores the item's sum to partial[chunk][pixel]; reduce_partials_kernel adds the
-// chunks to the framebuffer in chunk order.  The summation order is therefore fixed.
+// pt_megakernel: persistent waves, work unit = ONE PATH, lanes decoupled from pixels.
+//
+//  * Paths of a launch are numbered q = plocal * n_samples + k (band pixel, sample offset): 64 consecutive paths are 64
+//    samples of one pixel (coherent eye rays, first hits and materials).  A wave claims 64 paths with ONE atomicAdd on
+//    the global queue head.
+//  * Eye rays are generated 64 at a time, by ALL lanes of the wave, into the wave's pool in LDS (SoA, 64 slots); a lane
+//    whose path has ended pops the next ray from the pool (ballot + mbcnt rank), whichever path that is.  Round 1's
+//    kernel regenerated in place, i.e. the whole wave executed the eye-ray code for the half of its lanes whose paths had
+//    just ended -- 16 % of the kernel at 48 % lane utilisation; here that code runs once per 64 paths with every lane
+//    busy, and no lane ever waits: a generation round happens only when the pool cannot serve a lane.
+//  * Accumulation.  Lanes no longer own pixels, so a path that ends with a non-zero measurement (it reached a light:
+//    2e-5 of the Cornell paths) stores it to values[q] and sets bit q of a bitmap; reduce_flagged_kernel then forms, per
+//    pixel, exactly the sums of the numerical contract -- samples of a chunk of AMBER_ACCUM_CHUNK in order, chunk sums
+//    added to the framebuffer in chunk order -- skipping the +0 terms, which is exact: a running
+//    binary32 sum that starts at +0 never becomes -0, and x + (+0) = x for every other x.  HBM traffic per launch: the
+//    bitmap (n_paths / 8 bytes, cleared and read once) and the few values -- round 1 wrote 12 B per (pixel, chunk), 5.5 GB
+//    per config-2 launch after write amplification; values[] is address space that is touched only where a bit is set.
+//  * kLight: the same worker loop traces LIGHT paths (algorithm_lt.cc:112-163): path q = (light path index, pass),
+//    nothing is stored at a path's end, Eye hits append splat records instead.
 #ifndef AMBER_MEGAKERNEL_WAVES_PER_SIMD
-#define AMBER_MEGAKERNEL_WAVES_PER_SIMD 6   // 80 VGPRs, no scratch; in-process A/B on config 2 at 512 spp: 5 waves (87 VGPRs) 48.8 ms, 6: 47.9, 7: 48.2, 8: 49.5
+#define AMBER_MEGAKERNEL_WAVES_PER_SIMD 6
 #endif
-// kLight: the same worker loop traces LIGHT paths (algorithm_lt.cc:112-163): an item is (light path index, chunk of
-// passes), nothing is summed per item, Eye hits append splat records instead.
+// Paths a wave claims from the global queue head with one atomicAdd.  One L2 word retires ~88 returning atomics per
+// microsecond (MI355X_MICROARCH.md, "dequeue"): claiming 64 paths at a time (1.7e7 atomics per config-2 launch) made the
+// queue head the bottleneck -- 190 ms per launch; 1024 paths (16 generation rounds) is 15 atomics per microsecond, and the
+// tail it can leave on one wave is ~35 iterations (80 us).
+#define AMBER_CLAIM_PATHS 1024u
+template <bool kLight> struct PoolLayout { static constexpr int kFields = kLight ? 13 : 11; };   // o3 d3 w(1|3) origin_slot rng2 q
+
 template <int kEngine, bool kLight = false>
-__global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 1 : AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megakernel(const RenderArgs a) {
+__global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megakernel(const RenderArgs a) {
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
   constexpr bool kTwoPhase = kEngine == ENGINE_TWO_PHASE;
+  constexpr int kFields = PoolLayout<kLight>::kFields;
   __shared__ DevObject lds_objects[kTwoPhase ? AMBER_MAX_LDS_OBJECTS : 1];
-  __shared__ int32_t lds_stack[kEngine == ENGINE_BVH ? AMBER_BVH_STACK * 256 : 1];
+  __shared__ uint32_t lds_pool[4][kFields][64];               // [wave][field][slot]
   if (kTwoPhase) StageObjects(sc, lds_objects);
+  uint32_t (*pool)[64] = lds_pool[threadIdx.x >> 6];
 
-  uint32_t pool_next = 0, pool_end = 0;      // wave-uniform: items claimed by this wave, not yet handed out
+  uint32_t claim_next = 0, claim_end = 0;    // wave-uniform: paths claimed from the global queue, not yet generated
+  uint32_t pool_count = 0;                   // wave-uniform: rays in the pool (slots [0, pool_count))
   bool exhausted = false;                    // wave-uniform: the global queue is empty
-  bool lane_done = false, have_item = false, alive = false;
-  uint32_t s = 0, s_end = 0, pixel = 0, slot = 0;          // the pixel's x, y are recomputed where a path starts: two registers less
-  V3 sum = v3(0.f, 0.f, 0.f), meas = v3(0.f, 0.f, 0.f);
+  bool retired = false, alive = false;
+  uint32_t q = 0;                            // path of this lane
+  V3 meas = v3(0.f, 0.f, 0.f);
   V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), w = v3(0.f, 0.f, 0.f);
   uint64_t rng = 1;
   uint32_t casts = 0;
@@ -95,77 +118,91 @@ __global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 1 : AMBER_MEGAKER
 
   for (;;) {
     AMBER_STAMP(6);
-    bool need = !alive && s >= s_end && !lane_done;
-    if (need && have_item) {                                // item finished: publish its sum
-      if (!kLight) {
-        float* p = a.partial + static_cast<size_t>(slot) * 3u;
-        p[0] = sum.x; p[1] = sum.y; p[2] = sum.z;
+    const bool need = !alive && !retired;
+    const unsigned long long mask = __ballot(need);
+    if (mask) {                                               // wave-uniform
+      const uint32_t n_need = static_cast<uint32_t>(__popcll(mask));
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+      uint32_t served = 0;
+#pragma unroll 1
+      for (int round = 0; round < 2; ++round) {
+        if (round == 1) {                                     // the pool ran dry with lanes still waiting: generate 64 paths
+          if (exhausted) break;
+          AMBER_STAMP(0);
+          if (claim_next == claim_end) {                      // claim the next block of paths from the global queue
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(a.next_item, AMBER_CLAIM_PATHS);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= a.n_items) { exhausted = true; break; }
+            claim_next = base;
+            claim_end = a.n_items - base < AMBER_CLAIM_PATHS ? a.n_items : base + AMBER_CLAIM_PATHS;
+          }
+          const uint32_t n_new = claim_end - claim_next < 64u ? claim_end - claim_next : 64u;
+          const uint32_t gbase = claim_next;
+          claim_next += n_new;
+          if (lane < n_new) {
+            const uint32_t gq = gbase + lane;
+            const uint32_t plocal = gq / a.n_samples, k = gq - plocal * a.n_samples;
+            uint64_t grng; V3 go, gd, gw; int gslot;
+            if (kLight) {
+              grng = XorShiftSeed(a.hashed_seed, plocal, a.first_sample + k);
+              GenerateLightRay(sc, grng, go, gd, gw, gslot);
+            } else {
+              const uint32_t lrow = plocal / sc.sensor.w;
+              const uint32_t px = plocal - lrow * sc.sensor.w;
+              const uint32_t py = a.row_begin + (a.stripe_rows ? (lrow / a.stripe_rows) * a.stripe_period + lrow % a.stripe_rows : lrow);
+              grng = XorShiftSeed(a.hashed_seed, px + py * sc.sensor.w, a.first_sample + k);   // Image index x + y*W (image.h:116-124)
+              float ew;
+              GenerateEyeRay(sc, px, py, grng, go, gd, ew, gslot);
+              gw = v3(ew, ew, ew);                            // Leading<RGB>(.., Radiant(weight)) lens_basic.h:139-144
+            }
+            pool[0][lane] = __float_as_uint(go.x); pool[1][lane] = __float_as_uint(go.y); pool[2][lane] = __float_as_uint(go.z);
+            pool[3][lane] = __float_as_uint(gd.x); pool[4][lane] = __float_as_uint(gd.y); pool[5][lane] = __float_as_uint(gd.z);
+            pool[6][lane] = static_cast<uint32_t>(gslot);
+            pool[7][lane] = static_cast<uint32_t>(grng); pool[8][lane] = static_cast<uint32_t>(grng >> 32);
+            pool[9][lane] = gq;
+            pool[10][lane] = __float_as_uint(gw.x);
+            if (kLight) { pool[11][lane] = __float_as_uint(gw.y); pool[12][lane] = __float_as_uint(gw.z); }
+          }
+          pool_count = n_new;
+          AMBER_STAMP(1);
+        }
+        const uint32_t left = n_need - served;
+        const uint32_t take = pool_count < left ? pool_count : left;
+        if (need && !alive && rank >= served && rank < served + take) {      // pop: the wave's own LDS writes are in order, no barrier
+          const uint32_t sl = pool_count - 1u - (rank - served);
+          o = v3(__uint_as_float(pool[0][sl]), __uint_as_float(pool[1][sl]), __uint_as_float(pool[2][sl]));
+          d = v3(__uint_as_float(pool[3][sl]), __uint_as_float(pool[4][sl]), __uint_as_float(pool[5][sl]));
+          origin_slot = static_cast<int>(pool[6][sl]);
+          rng = static_cast<uint64_t>(pool[7][sl]) | (static_cast<uint64_t>(pool[8][sl]) << 32);
+          q = pool[9][sl];
+          const float wx = __uint_as_float(pool[10][sl]);
+          w = kLight ? v3(wx, __uint_as_float(pool[11][sl]), __uint_as_float(pool[12][sl])) : v3(wx, wx, wx);
+          meas = v3(0.f, 0.f, 0.f);
+          casts = 0;
+          alive = true;
+        }
+        pool_count -= take; served += take;
+        if (served == n_need) break;
       }
-      have_item = false;
+      if (!alive && !retired) retired = true;                 // queue and pool empty: this lane retires
+      if (__ballot(!retired) == 0ull) break;
     }
-    unsigned long long mask = __ballot(need);
-    while (mask) {                                          // wave-uniform loop (usually one trip)
-      const uint32_t avail = pool_end - pool_next;
-      if (avail == 0) {
-        if (exhausted) break;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(a.next_item, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= a.n_items) { exhausted = true; break; }
-        pool_next = base;
-        pool_end = base + 64u < a.n_items ? base + 64u : a.n_items;
-        continue;
-      }
-      const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
-      if (need && rank < avail) {
-        const uint32_t item = pool_next + rank;
-        const uint32_t plocal = item / a.n_chunks, chunk = item - plocal * a.n_chunks;
-        const uint32_t lrow = plocal / sc.sensor.w;
-        const uint32_t px = plocal - lrow * sc.sensor.w;
-        const uint32_t py = a.row_begin + (a.stripe_rows ? (lrow / a.stripe_rows) * a.stripe_period + lrow % a.stripe_rows : lrow);
-        pixel = px + py * sc.sensor.w;                      // Image index x + y*W (image.h:116-124)
-        slot = chunk * a.n_pixels + plocal;
-        s = a.first_sample + chunk * AMBER_ACCUM_CHUNK;
-        const uint32_t left = a.first_sample + a.n_samples - s;            // >= 1; no 32-bit wrap near the top of the range
-        s_end = s + (left < AMBER_ACCUM_CHUNK ? left : AMBER_ACCUM_CHUNK);
-        sum = v3(0.f, 0.f, 0.f);
-        have_item = true;
-        need = false;
-      }
-      const uint32_t wanted = static_cast<uint32_t>(__popcll(mask));
-      pool_next += wanted < avail ? wanted : avail;
-      mask = __ballot(need);
-    }
-    if (need) lane_done = true;                             // queue empty: this lane retires
-    if (__ballot(!lane_done) == 0ull) break;
 
-    AMBER_STAMP(0);
-    if (!alive && !lane_done) {                             // regenerate: next sample of the item
-      rng = XorShiftSeed(a.hashed_seed, pixel, s);
-      if (kLight) {
-        GenerateLightRay(sc, rng, o, d, w, origin_slot);
-      } else {
-        float ew;
-        const uint32_t py = pixel / sc.sensor.w;
-        GenerateEyeRay(sc, pixel - py * sc.sensor.w, py, rng, o, d, ew, origin_slot);
-        w = v3(ew, ew, ew);                                 // Leading<RGB>(.., Radiant(weight)) lens_basic.h:139-144
-      }
-      meas = v3(0.f, 0.f, 0.f);
-      casts = 0;
-      alive = true;
-      ++s;
-    }
-    AMBER_STAMP(1);
     rays_wave += static_cast<uint32_t>(__popcll(__ballot(alive)));
     if (alive) {
       if (kLight) {
-        const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, pixel, s - 1u, sc.sensor.size_f};
-        alive = PathStep<false, kEngine, true>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, &sink);
+        const uint32_t plocal = q / a.n_samples;
+        const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, plocal, a.first_sample + (q - plocal * a.n_samples), sc.sensor.size_f};
+        alive = PathStep<false, kEngine, true>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, &sink);
       } else {
-        alive = PathStep<false, kEngine>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG);
+        alive = PathStep<false, kEngine>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG);
+        if (!alive && ((__float_as_uint(meas.x) | __float_as_uint(meas.y) | __float_as_uint(meas.z)) != 0u)) {   // anything but +0 (RGB)
+          float* v = a.values + static_cast<size_t>(q) * 3u;
+          v[0] = meas.x; v[1] = meas.y; v[2] = meas.z;
+          atomicOr(a.flags + (q >> 5), 1u << (q & 31u));
+        }
       }
-      if (!alive) sum = sum + meas;                         // sequential sum over the item's samples
     }
   }
 
@@ -174,6 +211,37 @@ __global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 1 : AMBER_MEGAKER
 #endif
   // one atomic per wave for the ray counter
   if (lane == 0 && rays_wave) atomicAdd(a.ray_count, static_cast<unsigned long long>(rays_wave));
+}
+
+// fb[pixel] += the measurements of the launch's paths, in the order of the numerical contract: within a chunk of
+// AMBER_ACCUM_CHUNK consecutive samples (counted from the launch's first sample) a sequential binary32 sum, chunk sums
+// added to the framebuffer value in chunk order.  Only paths whose bit is set contribute a term; every other term is +0,
+// and both the chunk sum (starts at +0) and the framebuffer value (cleared to +0) can never be -0, so leaving the +0
+// terms out changes no bit.  One thread per band pixel; the pixel's bits are words [q0 / 32, (q0 + n_samples - 1) / 32].
+__global__ void reduce_flagged_kernel(float* __restrict__ fb, const uint32_t* __restrict__ flags, const float* __restrict__ values,
+                                      uint32_t n_pixels, uint32_t n_samples) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pixels) return;
+  const uint32_t q0 = p * n_samples, q1 = q0 + n_samples;      // n_pixels * n_samples < 2^32 (render_pass splits launches)
+  bool any = false;
+  for (uint32_t wd = q0 >> 5; wd <= (q1 - 1u) >> 5; ++wd) any |= flags[wd] != 0u;   // neighbours' bits may share the edge words: harmless
+  if (!any) return;
+  float v0 = fb[3u * p], v1 = fb[3u * p + 1u], v2 = fb[3u * p + 2u];
+  for (uint32_t c0 = 0; c0 < n_samples; c0 += AMBER_ACCUM_CHUNK) {
+    const uint32_t c1 = c0 + AMBER_ACCUM_CHUNK < n_samples ? c0 + AMBER_ACCUM_CHUNK : n_samples;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    bool hit = false;
+    for (uint32_t k = c0; k < c1; ++k) {
+      const uint32_t q = q0 + k;
+      if ((flags[q >> 5] >> (q & 31u)) & 1u) {
+        const float* m = values + static_cast<size_t>(q) * 3u;
+        s0 = s0 + m[0]; s1 = s1 + m[1]; s2 = s2 + m[2];
+        hit = true;
+      }
+    }
+    if (hit) { v0 = v0 + s0; v1 = v1 + s1; v2 = v2 + s2; }
+  }
+  fb[3u * p] = v0; fb[3u * p + 1u] = v1; fb[3u * p + 2u] = v2;
 }
 
 // Engine BVH worker.  Same work queue, item walk and accumulation order as pt_megakernel, but the closest-hit query
@@ -489,8 +557,11 @@ struct amber_hip_pt {
   unsigned int* d_splat_count = nullptr;
   uint32_t splat_capacity = 0;
   uint64_t hashed_seed_lt = 0;
-  float* d_partial = nullptr;
+  float* d_partial = nullptr;               // engine BVH: per-item sums
   size_t partial_floats = 0;
+  uint32_t* d_flags = nullptr;              // pt_megakernel: bitmap + values of the paths with a non-zero measurement
+  float* d_values = nullptr;
+  uint64_t pool_paths = 0;                  // paths the two buffers are sized for
   int n_cus = 256;
   uint32_t row_begin = 0, row_end = 0, stripe_rows = 0, stripe_period = 0, local_rows = 0;
   uint64_t seed = 0, hashed_seed = 0;
@@ -885,6 +956,54 @@ int RenderPassWavefront(amber_hip_pt* h, uint32_t first_sample, uint32_t n_sampl
 
 }  // namespace
 
+namespace {
+// pt_megakernel (engines LIST / TWO_PHASE): a launch covers at most kMaxPathsPerLaunch paths (bitmap n/8 bytes, values 12 B
+// of address space per path, touched only where a path reached a light); longer passes are split on chunk boundaries.
+int RenderPassPool(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint32_t n_pixels) {
+  const uint64_t kMaxPathsPerLaunch = 1ull << 30;
+  uint64_t max_samples = kMaxPathsPerLaunch / n_pixels / AMBER_ACCUM_CHUNK * AMBER_ACCUM_CHUNK;
+  if (max_samples == 0) return Fail(AMBER_EINVAL, "band too large for one launch");
+  uint32_t done = 0;
+  while (done < n_samples) {
+    uint32_t n = n_samples - done;
+    if (n > max_samples) n = static_cast<uint32_t>(max_samples);
+    const uint64_t n_paths = static_cast<uint64_t>(n_pixels) * n;
+    const size_t need_words = static_cast<size_t>((n_paths + 31u) / 32u) + 1u;
+    if (n_paths > h->pool_paths) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (h->d_flags) { HIP_TRY(hipFree(h->d_flags)); h->d_flags = nullptr; }
+      if (h->d_values) { HIP_TRY(hipFree(h->d_values)); h->d_values = nullptr; }
+      h->pool_paths = 0;
+      hipError_t e = hipMalloc(&h->d_flags, need_words * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipMalloc(&h->d_values, static_cast<size_t>(n_paths) * 3u * sizeof(float));
+      if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(path measurements): ") + hipGetErrorString(e));
+      h->pool_paths = n_paths;
+    }
+    RenderArgs a{};
+    a.scene = h->scene; a.flags = h->d_flags; a.values = h->d_values; a.ray_count = h->d_rays; a.next_item = h->d_next; a.stamps = h->d_stamps; a.hashed_seed = h->hashed_seed;
+    a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first_sample + done; a.n_samples = n;
+    a.n_chunks = (n + AMBER_ACCUM_CHUNK - 1) / AMBER_ACCUM_CHUNK; a.n_items = static_cast<uint32_t>(n_paths);
+    uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth);
+    const uint32_t by_work = static_cast<uint32_t>((n_paths + 255u) / 256u);
+    if (by_work < n_blocks) n_blocks = by_work;
+    HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_flags, 0, need_words * sizeof(uint32_t), h->stream));
+    std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
+    { const int rc = AcquireEventPair(h, &evp); if (rc != AMBER_OK) return rc; }
+    auto& ev = *evp;
+    HIP_TRY(hipEventRecord(ev.first, h->stream));
+    if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(pt_megakernel<ENGINE_TWO_PHASE>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL(pt_megakernel<ENGINE_LIST>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.second, h->stream));
+    hipLaunchKernelGGL(reduce_flagged_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, h->stream, h->d_fb, h->d_flags, h->d_values, n_pixels, n);
+    HIP_TRY(hipGetLastError());
+    done += n;
+  }
+  return AMBER_OK;
+}
+}  // namespace
+
 extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples) {
   if (!h) return Fail(AMBER_EINVAL, "null handle");
   if (n_samples == 0) return AMBER_OK;
@@ -893,8 +1012,9 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
   const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
   if (n_pixels == 0) return AMBER_OK;                    // empty band
   if (h->engine == AMBER_ENGINE_WAVEFRONT) return RenderPassWavefront(h, first_sample, n_samples);
-  // a launch covers at most kMaxPartialFloats of per-item sums and < 2^31 items; longer passes are split on
-  // chunk boundaries, which leaves the summation order (chunks in order) unchanged
+  if (h->hit_engine != AMBER_ENGINE_BVH) return RenderPassPool(h, first_sample, n_samples, n_pixels);
+  // engine BVH (pt_bvh_megakernel): a launch covers at most kMaxPartialFloats of per-item sums and < 2^31 items; longer
+  // passes are split on chunk boundaries, which leaves the summation order (chunks in order) unchanged
   const uint64_t kMaxPartialFloats = 768ull << 20;    // 3 GiB
   uint64_t max_chunks = kMaxPartialFloats / (static_cast<uint64_t>(n_pixels) * 3u);
   const uint64_t by_items = 0x7fffffffull / n_pixels;
@@ -914,8 +1034,8 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
       if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(partial sums): ") + hipGetErrorString(e));
       h->partial_floats = need;
     }
-    RenderArgs a;
-    a.scene = h->scene; a.partial = h->d_partial; a.ray_count = h->d_rays; a.next_item = h->d_next; a.stamps = h->d_stamps; a.splats = nullptr; a.splat_count = nullptr; a.splat_capacity = 0; a.hashed_seed = h->hashed_seed;
+    RenderArgs a{};
+    a.scene = h->scene; a.partial = h->d_partial; a.ray_count = h->d_rays; a.next_item = h->d_next; a.stamps = h->d_stamps; a.hashed_seed = h->hashed_seed;
     a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first_sample + done; a.n_samples = n;
     a.n_chunks = n_chunks; a.n_items = n_pixels * n_chunks;
     // persistent workers: one workgroup of 4 waves per CU and resident wave slot, fewer if the queue is short
@@ -927,12 +1047,8 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
     { const int rc = AcquireEventPair(h, &evp); if (rc != AMBER_OK) return rc; }
     auto& ev = *evp;
     HIP_TRY(hipEventRecord(ev.first, h->stream));
-    if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(pt_megakernel<ENGINE_TWO_PHASE>, dim3(n_blocks), dim3(256), 0, h->stream, a);
-    else if (h->hit_engine == AMBER_ENGINE_BVH) {
-      if (h->bvh_depth <= 24) hipLaunchKernelGGL((pt_bvh_megakernel<false, 24>), dim3(n_blocks), dim3(256), 0, h->stream, a);
-      else hipLaunchKernelGGL((pt_bvh_megakernel<false, AMBER_BVH_STACK>), dim3(n_blocks), dim3(256), 0, h->stream, a);
-    }
-    else hipLaunchKernelGGL(pt_megakernel<ENGINE_LIST>, dim3(n_blocks), dim3(256), 0, h->stream, a);
+    if (h->bvh_depth <= 24) hipLaunchKernelGGL((pt_bvh_megakernel<false, 24>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL((pt_bvh_megakernel<false, AMBER_BVH_STACK>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, h->stream));
     const uint32_t n_elems = n_pixels * 3u;
@@ -953,7 +1069,10 @@ int amber_hip_lt_trace(amber_hip_pt* h, uint32_t first_sample, uint32_t n_sample
   HIP_TRY(hipSetDevice(h->device));
   const uint32_t n_paths = h->scene.sensor.w * h->scene.sensor.h;           // image.Size() light paths per pass
   const uint32_t n_chunks = (n_samples + AMBER_ACCUM_CHUNK - 1) / AMBER_ACCUM_CHUNK;
-  if (static_cast<uint64_t>(n_paths) * n_chunks > 0x7fffffffull) return Fail(AMBER_EINVAL, "too many light paths for one call");
+  const bool bvh = h->hit_engine == AMBER_ENGINE_BVH;
+  // pt_megakernel numbers (light path, pass) pairs; pt_bvh_megakernel walks items = (light path, chunk of passes)
+  const uint64_t n_work = bvh ? static_cast<uint64_t>(n_paths) * n_chunks : static_cast<uint64_t>(n_paths) * n_samples;
+  if (n_work > 0x7fffffffull) return Fail(AMBER_EINVAL, "too many light paths for one call");
   const uint32_t dev_capacity = capacity ? capacity : 1u;
   if (dev_capacity > h->splat_capacity) {
     if (h->d_splats) { HIP_TRY(hipFree(h->d_splats)); h->d_splats = nullptr; h->splat_capacity = 0; }
@@ -966,16 +1085,16 @@ int amber_hip_lt_trace(amber_hip_pt* h, uint32_t first_sample, uint32_t n_sample
   HIP_TRY(hipMemcpyAsync(&rays_before, h->d_rays, sizeof rays_before, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemsetAsync(h->d_splat_count, 0, sizeof(unsigned int), h->stream));
   HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
-  RenderArgs a;
-  a.scene = h->scene; a.partial = nullptr; a.ray_count = h->d_rays; a.next_item = h->d_next; a.stamps = nullptr;
+  RenderArgs a{};
+  a.scene = h->scene; a.ray_count = h->d_rays; a.next_item = h->d_next;
   a.splats = h->d_splats; a.splat_count = h->d_splat_count; a.splat_capacity = dev_capacity; a.hashed_seed = h->hashed_seed_lt;
-  a.row_begin = 0; a.stripe_rows = 0; a.stripe_period = 0; a.n_pixels = n_paths; a.first_sample = first_sample; a.n_samples = n_samples;
-  a.n_chunks = n_chunks; a.n_items = n_paths * n_chunks;
+  a.n_pixels = n_paths; a.first_sample = first_sample; a.n_samples = n_samples;
+  a.n_chunks = n_chunks; a.n_items = static_cast<uint32_t>(n_work);
   uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth);
   const uint32_t by_work = (a.n_items + 255u) / 256u;
   if (by_work < n_blocks) n_blocks = by_work;
   if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
-  else if (h->hit_engine == AMBER_ENGINE_BVH) {
+  else if (bvh) {
     if (h->bvh_depth <= 24) hipLaunchKernelGGL((pt_bvh_megakernel<true, 24>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL((pt_bvh_megakernel<true, AMBER_BVH_STACK>), dim3(n_blocks), dim3(256), 0, h->stream, a);
   }
@@ -1098,6 +1217,8 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_splats) (void)hipFree(h->d_splats);
   if (h->d_splat_count) (void)hipFree(h->d_splat_count);
   if (h->d_partial) (void)hipFree(h->d_partial);
+  if (h->d_flags) (void)hipFree(h->d_flags);
+  if (h->d_values) (void)hipFree(h->d_values);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
