@@ -119,10 +119,39 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, const float c
   auto record = [](const Tri& t, int row_a, int row_b) {          // rows = vertex whose coordinate function is evaluated
     DevTriFilter f;
     std::memset(&f, 0, sizeof f);
-    for (int k = 0; k < 3; k++) { f.A[k] = static_cast<float>(t.coef[row_a][k]); f.B[k] = static_cast<float>(t.coef[row_b][k]); }
-    f.a0 = static_cast<float>(t.coef[row_a][3]); f.b0 = static_cast<float>(t.coef[row_b][3]);
+    for (int k = 0; k < 4; k++) { f.c[k][0] = static_cast<float>(t.coef[row_a][k]); f.c[k][1] = static_cast<float>(t.coef[row_b][k]); }
     return f;
   };
+  // Program order.  Phase A prunes by distance ONE-SIDEDLY (ClosestHitTwoPhase): a certain hit only removes candidates
+  // that are evaluated after it, so occluders should come first.  Spheres are evaluated before all planes; planes are
+  // sorted by the distance of their triangles' centroid from the area-weighted centroid of all triangles -- inner
+  // surfaces (the water surface, the light just under the ceiling) before the enclosing walls, the far-away aperture
+  // last.  Any order is correct; this one only makes the pruning effective.
+  {
+    double cw[3] = {0, 0, 0}, wsum = 0;
+    std::vector<double> gc(groups.size() * 3, 0.0);
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+      double gw = 0;
+      for (const Tri& t : groups[gi].tris) {
+        const double e1[3] = {t.v[1][0] - t.v[0][0], t.v[1][1] - t.v[0][1], t.v[1][2] - t.v[0][2]};
+        const double e2[3] = {t.v[2][0] - t.v[0][0], t.v[2][1] - t.v[0][1], t.v[2][2] - t.v[0][2]};
+        const double cr[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double area = 0.5 * len3(cr);
+        for (int k = 0; k < 3; k++) gc[gi * 3 + k] += area * (t.v[0][k] + t.v[1][k] + t.v[2][k]) / 3.0;
+        gw += area;
+      }
+      for (int k = 0; k < 3; k++) { cw[k] += gc[gi * 3 + k]; if (gw > 0) gc[gi * 3 + k] /= gw; }
+      wsum += gw;
+    }
+    if (wsum > 0) for (int k = 0; k < 3; k++) cw[k] /= wsum;
+    std::vector<size_t> perm(groups.size());
+    for (size_t gi = 0; gi < perm.size(); gi++) perm[gi] = gi;
+    auto dist2 = [&](size_t gi) { double d2 = 0; for (int k = 0; k < 3; k++) d2 += (gc[gi * 3 + k] - cw[k]) * (gc[gi * 3 + k] - cw[k]); return d2; };
+    std::stable_sort(perm.begin(), perm.end(), [&](size_t x, size_t y) { return dist2(x) < dist2(y); });
+    std::vector<Group> sorted;
+    for (size_t gi : perm) sorted.push_back(groups[gi]);
+    groups.swap(sorted);
+  }
   for (const Group& g : groups) {
     // Parallelogram pairs: triangle j shares two corners with triangle i and its third corner is D = A + C - B
     // (B = i's unshared corner), everything up to 1e-6 of the scene diameter; the actual mismatch (corners are

@@ -68,9 +68,9 @@ struct alignas(16) DevPlane {       // 32 B: one s_load_dwordx8
 // corner B, row B the coordinate "alpha" of a shared corner; with gamma = 1 - alpha - beta the second triangle's
 // coordinates are (1 - gamma, -beta, 1 - alpha), so both minima come from one pair of affine evaluations.
 struct alignas(16) DevTriFilter {   // 32 B: one s_load_dwordx8.  Candidate bits follow the program order.
-  float A[3]; float a0;             // u = A.P + a0 for P on the plane
-  float B[3]; float b0;             // v = B.P + b0
-};
+  float c[4][2];                    // (u, v) = c[0] P.x + c[1] P.y + c[2] P.z + c[3] for P on the plane, the two rows interleaved.
+};                                  // (Evaluating the pair with three v_pk_fma_f32 on the SGPR pairs was measured: 6 fewer VALU
+                                    //  instructions per record, 1.3 % SLOWER -- as the packed forms tried in round 1.)
 struct alignas(16) DevSphereFilter { // 32 B
   float c[3]; float r2;
   float ktol; uint32_t pad[3];
@@ -131,6 +131,7 @@ struct DevScene {
   int32_t bvh_root;                             // child reference of the whole scene
   float fp_center[3];                           // two-phase filter: rays whose origin is farther than fp_reach (max norm) from here,
   float fp_reach;                               // or with |d| > 2, bypass the filter (all objects become candidates)
+  float fp_tmax;                                // no ray of the model hits anything beyond t = fp_tmax / |d| (Phase-A distance pruning)
   float bvh_center[3];                          // centre and half diagonal of the scene bounds (per-ray box margin, BvhBegin)
   float bvh_half_diag;
   float bvh_inv_rmin;                           // 1 / smallest sphere radius ; 0 when the scene has no spheres
@@ -156,7 +157,9 @@ __device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]};
 // Wave-uniform reads of scene records go through the constant address space: hipcc then emits scalar loads
 // (s_load_dwordx4/x8/x16, operands in SGPRs) even though the kernel also stores to global memory in its loop.
 typedef const uint32_t __attribute__((address_space(4)))* ConstWords;
+typedef float F2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float cw_f(ConstWords w, int k) { return __uint_as_float(w[k]); }
+__device__ __forceinline__ F2 cw_f2(ConstWords w, int k) { return F2{cw_f(w, k), cw_f(w, k + 1)}; }
 __device__ __forceinline__ V3 cw_v3(ConstWords w, int k) { return V3{cw_f(w, k), cw_f(w, k + 1), cw_f(w, k + 2)}; }
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -548,6 +551,18 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
   uint32_t cand = sc.always_mask;
   {
     const V3 o = v3(o_world.x - sc.fp_center[0], o_world.y - sc.fp_center[1], o_world.z - sc.fp_center[2]);   // Phase A runs in centred coordinates (filter_build.h)
+    // Pruning by distance.  A triangle that the filter finds hit with a MARGIN -- inside by the same tolerance that
+    // otherwise widens it, beyond kEPS by the distance tolerance, not grazing -- is certain to pass the reference's exact
+    // test at a distance below t' + tolerance; `t_upper` is the least such bound seen so far, and a later triangle whose
+    // distance is certainly larger (t' - tolerance > t_upper) cannot be the closest hit and is not made a candidate.
+    // One-sided (nothing is remembered per object), so the program evaluates likely occluders first (filter_build.h).
+    // t_upper starts at the largest distance at which a ray of the model (origin and objects inside the model box,
+    // checked below) can hit anything: that bound also removes the planes a ray runs nearly PARALLEL to -- their plane
+    // point lies hundreds of scene sizes away -- which used to be kept with all their triangles whatever the distance
+    // (1e-3 of the rays per plane: one lane in most waves, and every lane of the wave waited for its extra exact tests).
+    // Every comparison is false on NaN: nothing is pruned and nothing is certain.
+    float t_upper = sc.fp_tmax * __builtin_amdgcn_rsqf(d.x * d.x + d.y * d.y + d.z * d.z);
+    if (!(t_upper == t_upper)) t_upper = 3.402823466e+38f;
     ConstWords pl = (ConstWords)(sc.planes);
     ConstWords tr = (ConstWords)(sc.tri_filters);
     const int n_planes = static_cast<int>(sc.n_planes);
@@ -559,29 +574,39 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
       const float tp = (cw_f(pl, 3) - no) * rc;
       const float rho = Abs(rc);
       const float Px = __builtin_fmaf(tp, d.x, o.x), Py = __builtin_fmaf(tp, d.y, o.y), Pz = __builtin_fmaf(tp, d.z, o.z);
-      const bool t_ok = tp >= AMBER_KEPS - cw_f(pl, 4) * rho;
-      const bool grazing = !(Abs(nd) >= AMBER_GRAZING);     // true for NaN
-      const float mtol = -cw_f(pl, 5) * rho;
+      const float kr = cw_f(pl, 4) * rho;                   // distance tolerance of this plane for this ray
+      const bool t_ok = (tp >= AMBER_KEPS - kr) && !(tp - kr > t_upper);                  // beyond kEPS, and not certainly behind a certain hit
+      // nearly parallel: the in-plane coordinates are not trusted (every triangle of the plane stays a candidate), the
+      // distance still is, down to |n.d| = 1e-6; below that, or NaN, everything is kept
+      const bool degenerate = !(Abs(nd) >= 1e-6f);
+      const bool grazing = !(Abs(nd) >= AMBER_GRAZING);
+      const bool t_sure = (tp - kr > AMBER_KEPS) && !grazing;
+      const float ptol = cw_f(pl, 5) * rho;
+      const float mtol = grazing ? -3.402823466e+38f : -ptol;                             // grazing: any in-plane position passes
+      bool plane_hit = false;
       const int nt = static_cast<int>(pl[6]), np = static_cast<int>(pl[7]);
       for (int k = 0; k < np; ++k, tr += 8, bit <<= 2) {    // parallelogram pairs: one record, two candidate bits
-        const float b = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 1), Py, __builtin_fmaf(cw_f(tr, 2), Pz, cw_f(tr, 3))));
-        const float a = __builtin_fmaf(cw_f(tr, 4), Px, __builtin_fmaf(cw_f(tr, 5), Py, __builtin_fmaf(cw_f(tr, 6), Pz, cw_f(tr, 7))));
+        const float b = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 2), Py, __builtin_fmaf(cw_f(tr, 4), Pz, cw_f(tr, 6))));
+        const float a = __builtin_fmaf(cw_f(tr, 1), Px, __builtin_fmaf(cw_f(tr, 3), Py, __builtin_fmaf(cw_f(tr, 5), Pz, cw_f(tr, 7))));
         const float g = 1.0f - b - a;
         const float m1 = __builtin_fminf(__builtin_fminf(b, a), g);
         const float m2 = __builtin_fminf(__builtin_fminf(-b, 1.0f - a), 1.0f - g);
-        const bool keep1 = ((m1 >= mtol) && t_ok) || grazing;
-        const bool keep2 = ((m2 >= mtol) && t_ok) || grazing;
+        const bool keep1 = (!(m1 < mtol) && t_ok) || degenerate;                          // NaN coordinates -> keep
+        const bool keep2 = (!(m2 < mtol) && t_ok) || degenerate;
         cand |= keep1 ? bit : 0u;
         cand |= keep2 ? (bit << 1) : 0u;
+        plane_hit |= __builtin_fmaxf(m1, m2) >= ptol;
       }
       for (int k = 0; k < nt; ++k, tr += 8, bit <<= 1) {    // DevTriFilter = 8 dwords
-        const float u = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 1), Py, __builtin_fmaf(cw_f(tr, 2), Pz, cw_f(tr, 3))));
-        const float v = __builtin_fmaf(cw_f(tr, 4), Px, __builtin_fmaf(cw_f(tr, 5), Py, __builtin_fmaf(cw_f(tr, 6), Pz, cw_f(tr, 7))));
+        const float u = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 2), Py, __builtin_fmaf(cw_f(tr, 4), Pz, cw_f(tr, 6))));
+        const float v = __builtin_fmaf(cw_f(tr, 1), Px, __builtin_fmaf(cw_f(tr, 3), Py, __builtin_fmaf(cw_f(tr, 5), Pz, cw_f(tr, 7))));
         const float w = 1.0f - u - v;
         const float m = __builtin_fminf(__builtin_fminf(u, v), w);
-        const bool keep = ((m >= mtol) && t_ok) || grazing;
+        const bool keep = (!(m < mtol) && t_ok) || degenerate;
         cand |= keep ? bit : 0u;
+        plane_hit |= m >= ptol;
       }
+      if (plane_hit && t_sure) t_upper = __builtin_fminf(t_upper, tp + kr);
     }
     ConstWords sp = (ConstWords)(sc.sphere_filters);
     const int ns = static_cast<int>(sc.n_sphere_filters);

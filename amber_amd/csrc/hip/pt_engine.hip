@@ -815,6 +815,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   }
   for (int c = 0; c < 3; c++) sc.fp_center[c] = fp_center[c];
   sc.fp_reach = fp_reach;
+  // origin within fp_reach (max norm) of the centre, objects within half of that: no two such points are farther apart than
+  sc.fp_tmax = static_cast<float>(std::min(3.0e38, 1.7320508 * 1.5 * 1.01 * static_cast<double>(fp_reach)));
   sc.lights = h->d_lights; sc.n_lights = s->n_lights; sc.total_power = s->n_lights ? s->lights[s->n_lights - 1].cum_power : 0.0f;
   sc.n_prog_tris = fprog.n_prog_tris; sc.always_mask = fprog.always_mask; sc.prog_objects = h->d_prog_objects;
   sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;
