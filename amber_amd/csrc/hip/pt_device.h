@@ -595,7 +595,9 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
         const bool keep2 = (!(m2 < mtol) && t_ok) || degenerate;
         cand |= keep1 ? bit : 0u;
         cand |= keep2 ? (bit << 1) : 0u;
+#ifndef AMBER_NO_CERTAIN_HITS
         plane_hit |= __builtin_fmaxf(m1, m2) >= ptol;
+#endif
       }
       for (int k = 0; k < nt; ++k, tr += 8, bit <<= 1) {    // DevTriFilter = 8 dwords
         const float u = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 2), Py, __builtin_fmaf(cw_f(tr, 4), Pz, cw_f(tr, 6))));
@@ -604,7 +606,9 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
         const float m = __builtin_fminf(__builtin_fminf(u, v), w);
         const bool keep = (!(m < mtol) && t_ok) || degenerate;
         cand |= keep ? bit : 0u;
+#ifndef AMBER_NO_CERTAIN_HITS
         plane_hit |= m >= ptol;
+#endif
       }
       if (plane_hit && t_sure) t_upper = __builtin_fminf(t_upper, tp + kr);
     }
