@@ -79,7 +79,7 @@ ABI_SYMBOLS = [
     "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_math_mode", "amber_hip_device_count", "amber_hip_lt_trace",
     "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math", "amber_hip_kat_signatures",
     "amber_host_cornell_box", "amber_host_scene_import", "amber_host_scene_create", "amber_host_scene_destroy", "amber_host_scene_flatten",
-    "amber_host_pt_create", "amber_host_render", "amber_host_last_error", "amber_host_tonemap", "amber_host_export",
+    "amber_host_pt_create", "amber_host_render", "amber_host_render_devices", "amber_host_last_error", "amber_host_tonemap", "amber_host_export",
 ]
 
 
@@ -141,6 +141,7 @@ def load_library() -> C.CDLL:
                                              C.POINTER(FlatThinLens)]
     lib.amber_host_pt_create.argtypes = [vp, C.POINTER(Sensor), C.POINTER(PtParams), C.POINTER(vp)]
     lib.amber_host_render.argtypes = [vp, C.c_char_p, C.POINTER(Sensor), u32, u64, u32, C.c_int, u32, vp, C.POINTER(HostStats)]
+    lib.amber_host_render_devices.argtypes = [vp, C.c_char_p, C.POINTER(Sensor), u32, u64, u32, C.POINTER(C.c_int), u32, u32, vp, C.POINTER(HostStats)]
     lib.amber_host_tonemap.argtypes = [vp, u32, u32, vp]
     lib.amber_host_export.argtypes = [vp, u32, u32, C.c_char_p, C.c_char_p]
     _lib = lib
@@ -227,12 +228,15 @@ class HostScene:
         return objs, mats, lens
 
     def render(self, sensor: Sensor, spp: int, seed: int = 12345, max_depth: int = 0, device: int = 0,
-               samples_per_launch: int = 0, algorithm: str = "pt"):
-        """Algorithm<RGB>::Render through cli::MakeAlgorithm(algorithm) and cli::Context(1, spp)."""
+               samples_per_launch: int = 0, algorithm: str = "pt", devices=None):
+        """Algorithm<RGB>::Render through cli::MakeAlgorithm(algorithm) and cli::Context(1, spp).
+        devices: list of HIP ordinals -> one engine handle per entry inside the one Render() call (HipPathTracingOptions.devices)."""
         out = np.empty((sensor.height, sensor.width, 3), np.float32)
         st = HostStats()
-        _check(load_library().amber_host_render(self._h, algorithm.encode(), C.byref(sensor), spp, seed, max_depth, device,
-                                                samples_per_launch, out.ctypes.data, C.byref(st)), host=True)
+        devs = list(devices) if devices else [device]
+        arr = (C.c_int * len(devs))(*devs)
+        _check(load_library().amber_host_render_devices(self._h, algorithm.encode(), C.byref(sensor), spp, seed, max_depth, arr, len(devs),
+                                                        samples_per_launch, out.ctypes.data, C.byref(st)), host=True)
         return out, {"rays": st.rays, "passes": st.passes, "launches": st.launches, "kernel_ms": st.kernel_ms}
 
     def close(self):

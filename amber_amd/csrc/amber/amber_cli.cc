@@ -4,7 +4,8 @@
 // cli::ParseCommandLineOption (option.cc:40-100) as far as they concern the path tracer:
 //   --algorithm pt|lt   --spp N (0 = until --time / SIGINT)   --width --height   --time SECONDS
 //   --output BASENAME (writes BASENAME.png tone-mapped and BASENAME.exr raw)   --threads (accepted, ignored)
-// plus --seed, --device, --max-depth, --engine of this implementation.  The scene is etude::CornelBox(0.050,
+// plus --seed, --device, --max-depth, --engine of this implementation, and --devices N / --device-list a,b,c: N GPUs inside
+// the one Render() call (rendering.h HipPathTracingOptions.devices), where the reference uses --threads.  The scene is etude::CornelBox(0.050,
 // 0.050, 6) as in application.cc:68-73, or --scene FILE through cli::ImportScene (import.h: OBJ + MTL subset, the
 // reference reads it through assimp) built with the BVH acceleration (application.cc:74-87).
 // Render runs on a std::async thread while the main thread prints the reference's progress line every 500 ms;
@@ -19,6 +20,7 @@
 #include <iostream>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "postprocess.h"
 #include "rendering.h"
@@ -40,6 +42,7 @@ struct Option {
   std::size_t spp = 0, threads = 1, width = 512, height = 512, time = 0;
   std::uint64_t seed = 12345;
   int device = 0;
+  std::vector<int> devices;          // --devices N = ordinals 0..N-1, --device-list a,b,c = exactly those (repeats allowed)
   std::uint32_t max_depth = 0, engine = 0, samples_per_launch = 32;
   bool help = false;
 };
@@ -62,6 +65,18 @@ bool Parse(int argc, char** argv, Option& o) {
     else if (a == "--time") o.time = std::strtoull(value("--time"), nullptr, 10);
     else if (a == "--seed") o.seed = std::strtoull(value("--seed"), nullptr, 10);
     else if (a == "--device") o.device = std::atoi(value("--device"));
+    else if (a == "--devices") { const int n = std::atoi(value("--devices")); o.devices.clear(); for (int k = 0; k < n; k++) o.devices.push_back(k); }
+    else if (a == "--device-list") {
+      o.devices.clear();
+      std::string list = value("--device-list");
+      for (size_t pos = 0; pos <= list.size();) {
+        const size_t comma = list.find(',', pos);
+        const std::string item = list.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+        if (!item.empty()) o.devices.push_back(std::atoi(item.c_str()));
+        if (comma == std::string::npos) break;
+        pos = comma + 1;
+      }
+    }
     else if (a == "--max-depth") o.max_depth = static_cast<std::uint32_t>(std::strtoul(value("--max-depth"), nullptr, 10));
     else if (a == "--engine") o.engine = static_cast<std::uint32_t>(std::strtoul(value("--engine"), nullptr, 10));
     else if (a == "--samples-per-launch") o.samples_per_launch = static_cast<std::uint32_t>(std::strtoul(value("--samples-per-launch"), nullptr, 10));
@@ -78,7 +93,7 @@ int main(int argc, char** argv) {
   if (!Parse(argc, argv, option) || option.help) {
     std::cerr << "amber: a global illumination renderer (MI355X path tracer)\n"
                  "  --algorithm pt  --spp N  --width W  --height H  --time S  --output NAME  [--threads N]  [--scene FILE.obj]\n"
-                 "  [--seed N] [--device N] [--max-depth N] [--engine 0..4] [--samples-per-launch N]" << std::endl;
+                 "  [--seed N] [--device N | --devices N | --device-list a,b,..] [--max-depth N] [--engine 0..4] [--samples-per-launch N]" << std::endl;
     return option.help ? 0 : -1;
   }
   if (option.spp == 0 && option.time == 0) std::cerr << "note: --spp 0 without --time renders until SIGINT" << std::endl;
@@ -86,6 +101,7 @@ int main(int argc, char** argv) {
   rendering::HipPathTracingOptions hip;
   hip.seed = option.seed; hip.device = option.device; hip.max_depth = option.max_depth; hip.engine = option.engine;
   hip.samples_per_launch = option.samples_per_launch;
+  hip.devices = option.devices;                                        // one engine handle per device inside Render()
   std::unique_ptr<rendering::Algorithm<rendering::RGB>> algorithm;
   try {
     algorithm = cli::MakeAlgorithm(option.algorithm, hip);            // algorithm_factory.cc:35-79

@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <cstring>
 #include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
 #include <type_traits>
 
 #include "rendering.h"
@@ -381,40 +384,77 @@ const Image<RGB> HipPathTracing::Render(const Scene<RGB>& scene, const Sensor& s
   stats_ = HipPathTracingStats();
   const scene::FlatScene fs = scene.Flatten();
   AmberSensor s{static_cast<uint32_t>(sensor.Width()), static_cast<uint32_t>(sensor.Height()), sensor.SceneWidth(), sensor.SceneHeight()};
-  AmberPtParams p{};
-  p.seed = options_.seed; p.max_depth = options_.max_depth; p.device = options_.device;
-  p.row_begin = options_.row_begin; p.row_end = options_.row_end; p.engine = options_.engine;
-  Handle handle;
-  Check(amber_hip_pt_create(&fs.flat, &s, &p, &handle.h), "amber_hip_pt_create");
+  const uint32_t rb = options_.row_begin, re = (options_.row_begin == 0 && options_.row_end == 0) ? s.height : options_.row_end;
+  if (rb > re || re > s.height) throw std::runtime_error("HipPathTracing: bad row band");
+
+  // One engine handle per device.  With N > 1 handles the band's rows are dealt in interleaved stripes of kStripe rows
+  // (handle r renders the rows y with ((y - rb) / kStripe) % N == r): contiguous bands of the Cornell image differ by
+  // 1.5x in work, stripes give equal shares.  The handles are created concurrently -- the scene
+  // upload and, for large scenes, the BVH build happen per handle.
+  const std::vector<int> devices = options_.devices.empty() ? std::vector<int>{options_.device} : options_.devices;
+  const uint32_t n_dev = static_cast<uint32_t>(devices.size());
+  constexpr uint32_t kStripe = 8;
+  std::vector<Handle> handles(n_dev);
+  std::vector<std::string> errors(n_dev);
+  {
+    std::vector<std::thread> workers;
+    for (uint32_t r = 0; r < n_dev; r++)
+      workers.emplace_back([&, r] {
+        AmberPtParams p{};
+        p.seed = options_.seed; p.max_depth = options_.max_depth; p.device = devices[r]; p.engine = options_.engine;
+        p.row_begin = rb; p.row_end = re;
+        if (n_dev > 1) {
+          p.row_begin = std::min(rb + r * kStripe, re); p.row_end = re;
+          p.stripe_rows = kStripe; p.stripe_period = kStripe * n_dev;
+          if (p.row_begin == p.row_end && p.row_begin == 0) return;       // empty image: nothing to create (0,0 would mean "all rows")
+        }
+        if (amber_hip_pt_create(&fs.flat, &s, &p, &handles[r].h) != AMBER_OK) errors[r] = amber_hip_last_error();   // thread-local message
+      });
+    for (auto& w : workers) w.join();
+  }
+  for (uint32_t r = 0; r < n_dev; r++)
+    if (!errors[r].empty()) throw std::runtime_error("amber_hip_pt_create (device " + std::to_string(devices[r]) + "): " + errors[r]);
 
   // Context contract (context.cc:48-60): each successful Iterate() is one whole-image sample.
-  // Claim up to samples_per_launch passes, render them in one launch, repeat until Iterate() fails.
+  // Claim up to samples_per_launch passes, render them on every handle (launches are asynchronous: the devices run
+  // concurrently), wait for all, repeat until Iterate() fails.
   const uint32_t batch = options_.samples_per_launch ? options_.samples_per_launch : 1;
   uint32_t first = 0;
   for (;;) {
     uint32_t n = 0;
     while (n < batch && context.Iterate()) n++;
     if (n == 0) break;
-    Check(amber_hip_pt_render_pass(handle.h, first, n), "amber_hip_pt_render_pass");
-    Check(amber_hip_pt_sync(handle.h), "amber_hip_pt_sync");   // bounded run-ahead: progress polling stays truthful
+    for (auto& hd : handles) if (hd.h) Check(amber_hip_pt_render_pass(hd.h, first, n), "amber_hip_pt_render_pass");
+    for (auto& hd : handles) if (hd.h) Check(amber_hip_pt_sync(hd.h), "amber_hip_pt_sync");   // bounded run-ahead: progress polling stays truthful
     first += n;
     stats_.passes += n;
     if (n < batch) break;
   }
 
-  const uint32_t rb = options_.row_begin, re = (options_.row_begin == 0 && options_.row_end == 0) ? s.height : options_.row_end;
-  std::vector<float> band(static_cast<std::size_t>(re - rb) * s.width * 3);
-  uint64_t rays = 0;
-  Check(amber_hip_pt_download(handle.h, band.data(), &rays), "amber_hip_pt_download");
-  stats_.rays = rays;
-  Check(amber_hip_pt_kernel_time(handle.h, &stats_.launches, &stats_.kernel_ms), "amber_hip_pt_kernel_time");
-
   auto image = sensor.CreateImage<RGB>();
-  for (uint32_t y = rb; y < re; y++)
-    for (uint32_t x = 0; x < s.width; x++) {
-      const float* v = &band[(static_cast<std::size_t>(y - rb) * s.width + x) * 3];
-      image[Pixel(x, y)] = RGB(v[0], v[1], v[2]);
+  std::vector<float> band;
+  for (uint32_t r = 0; r < n_dev; r++) {
+    if (!handles[r].h) continue;
+    uint32_t local_rows = 0;
+    Check(amber_hip_pt_local_rows(handles[r].h, &local_rows), "amber_hip_pt_local_rows");
+    band.resize(static_cast<std::size_t>(local_rows) * s.width * 3);
+    uint64_t rays = 0;
+    Check(amber_hip_pt_download(handles[r].h, band.data(), &rays), "amber_hip_pt_download");
+    stats_.rays += rays;
+    uint32_t launches = 0; double ms = 0;
+    Check(amber_hip_pt_kernel_time(handles[r].h, &launches, &ms), "amber_hip_pt_kernel_time");
+    stats_.launches += launches;
+    stats_.kernel_ms = std::max(stats_.kernel_ms, ms);           // the devices run side by side
+    // local row l of handle r is global row y: contiguous band, or the l-th row of its stripes
+    const uint32_t y0 = n_dev > 1 ? std::min(rb + r * kStripe, re) : rb;
+    for (uint32_t l = 0; l < local_rows; l++) {
+      const uint32_t y = n_dev > 1 ? y0 + (l / kStripe) * kStripe * n_dev + l % kStripe : y0 + l;
+      for (uint32_t x = 0; x < s.width; x++) {
+        const float* v = &band[(static_cast<std::size_t>(l) * s.width + x) * 3];
+        image[Pixel(x, y)] = RGB(v[0], v[1], v[2]);
+      }
     }
+  }
   // Accumulator::Mean (accumulator.h:88-95): Sum() / size_ -- component-wise binary32 division
   if (stats_.passes) image /= RGB(static_cast<real_type>(stats_.passes));
   return image;

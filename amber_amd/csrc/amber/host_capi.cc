@@ -118,13 +118,14 @@ int amber_host_pt_create(const amber_host_scene* s, const AmberSensor* sensor, c
   } catch (const std::exception& e) { return Fail(AMBER_EINVAL, e.what()); }
 }
 
-int amber_host_render(const amber_host_scene* s, const char* algorithm, const AmberSensor* sensor, uint32_t spp,
-                      uint64_t seed, uint32_t max_depth, int device, uint32_t samples_per_launch,
-                      float* out_rgb, AmberHostStats* stats) {
-  if (!s || !algorithm || !sensor || !out_rgb) return Fail(AMBER_EINVAL, "null argument");
+int amber_host_render_devices(const amber_host_scene* s, const char* algorithm, const AmberSensor* sensor, uint32_t spp,
+                              uint64_t seed, uint32_t max_depth, const int* devices, uint32_t n_devices, uint32_t samples_per_launch,
+                              float* out_rgb, AmberHostStats* stats) {
+  if (!s || !algorithm || !sensor || !out_rgb || (n_devices && !devices)) return Fail(AMBER_EINVAL, "null argument");
   try {
     rendering::HipPathTracingOptions opt;
-    opt.seed = seed; opt.max_depth = max_depth; opt.device = device;
+    opt.seed = seed; opt.max_depth = max_depth;
+    if (devices && n_devices) { opt.device = devices[0]; opt.devices.assign(devices, devices + n_devices); }
     if (samples_per_launch) opt.samples_per_launch = samples_per_launch;
     auto algo = cli::MakeAlgorithm(algorithm, opt);
     const rendering::Sensor sn(sensor->width, sensor->height, sensor->scene_width, sensor->scene_height);
@@ -140,6 +141,12 @@ int amber_host_render(const amber_host_scene* s, const char* algorithm, const Am
     return AMBER_OK;
   } catch (const cli::UnknownAlgorithmError& e) { return Fail(AMBER_EINVAL, e.what()); }
   catch (const std::exception& e) { return Fail(AMBER_EHIP, e.what()); }
+}
+
+int amber_host_render(const amber_host_scene* s, const char* algorithm, const AmberSensor* sensor, uint32_t spp,
+                      uint64_t seed, uint32_t max_depth, int device, uint32_t samples_per_launch,
+                      float* out_rgb, AmberHostStats* stats) {
+  return amber_host_render_devices(s, algorithm, sensor, spp, seed, max_depth, &device, 1, samples_per_launch, out_rgb, stats);
 }
 
 extern "C++" {

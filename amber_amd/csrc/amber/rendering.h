@@ -15,6 +15,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "prelude.h"
 #include "scene.h"
@@ -65,7 +66,13 @@ class Algorithm {
 struct HipPathTracingOptions {
   std::uint64_t seed = 12345;       // global seed of the per-(pixel,sample) XorShift sampler
   std::uint32_t max_depth = 0;      // 0 = Russian roulette only
-  int device = 0;                   // HIP device ordinal
+  int device = 0;                   // HIP device ordinal (used when `devices` is empty)
+  // Multi-GPU inside ONE Render() call -- the counterpart of the reference's thread fan-out (prelude/parallel.cc:29-40,
+  // rendering/parallel.h:57-68), which parallelises inside Render too: one engine handle per listed device (an ordinal
+  // may repeat), the framebuffer rows dealt to the handles in interleaved 8-row stripes, every handle renders ALL samples
+  // of ITS rows, the row sums are copied straight to the host image.  Pixels are independent under the per-(pixel,sample)
+  // sampler, so the image is bit-identical to a single-device render.
+  std::vector<int> devices;
   std::uint32_t samples_per_launch = 64;   // Context::Iterate() calls claimed per kernel launch (upper bound)
   std::uint32_t row_begin = 0, row_end = 0;   // framebuffer band; 0,0 = whole image
   std::uint32_t engine = 0;         // AMBER_ENGINE_*

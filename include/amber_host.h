@@ -52,6 +52,13 @@ int amber_host_render(const amber_host_scene*, const char* algorithm, const Ambe
                       uint64_t seed, uint32_t max_depth, int device, uint32_t samples_per_launch,
                       float* out_rgb, AmberHostStats* stats);
 
+/* The same with one engine handle per listed HIP device inside the ONE Render() call (an ordinal may repeat: N handles on
+ * one GPU): rows dealt in interleaved 8-row stripes, image bit-identical to the single-device render.  The reference
+ * parallelises inside Render as well (prelude/parallel.cc:29-40). */
+int amber_host_render_devices(const amber_host_scene*, const char* algorithm, const AmberSensor* sensor, uint32_t spp,
+                              uint64_t seed, uint32_t max_depth, const int* devices, uint32_t n_devices,
+                              uint32_t samples_per_launch, float* out_rgb, AmberHostStats* stats);
+
 /* Output stage (application.cc:98-115): Filmic -> Gamma -> 8-bit RGB (out_rgb8: w*h*3, Image layout, NOT mirrored). */
 int amber_host_tonemap(const float* rgb, uint32_t width, uint32_t height, uint8_t* out_rgb8);
 /* cli::ExportPNG / cli::ExportEXR (cli/image.cc:45-71): x-mirrored files.  rgb: float image; png is tone-mapped first. */

@@ -1494,6 +1494,29 @@ uint64_t oracle_render_lt_xorshift(const oracle_scene* sc, const oracle_sensor* 
   return n_rec;
 }
 
+// Output stage (application.cc:98-108): postprocess::Filmic (filmic.cc:30-66) then postprocess::Gamma(2.2) (gamma.cc:36-52).
+// hdr_value_type = float_t = float (postprocess/forward.h:33): every operation below is one binary32 operation in the
+// reference's order (Vector3 op scalar is component-wise, vector3.h; the constant products kB*kC, kD*kE, kD*kF and kE/kF
+// are binary32 constant expressions); std::pow(float, float) is glibc's powf; std::min<float>(1, x) returns 1 for a NaN x;
+// the LDR constructor converts float -> uint_fast8_t by truncation (255 * [0, 1] is always in range).
+void oracle_tonemap(const float* rgb, uint32_t width, uint32_t height, uint8_t* out_rgb8) {
+  const float kA = 0.22f, kB = 0.30f, kC = 0.10f, kD = 0.20f, kE = 0.01f, kF = 0.30f, kW = 0.70f, kExposure = 16.0f;
+  const float bc = kB * kC, de = kD * kE, df = kD * kF, ef = kE / kF;
+  auto map = [&](float h) {                                             // Filmic::Map filmic.cc:59-66
+    const float num = h * (h * kA + bc) + de;
+    const float den = h * (h * kA + kB) + df;
+    return num / den - ef;
+  };
+  const float white = map(kW);
+  const float inv_gamma = 1 / 2.2f;                                      // 1 / gamma_ (gamma.cc:47-49)
+  const std::size_t n = static_cast<std::size_t>(width) * height * 3;
+  for (std::size_t k = 0; k < n; k++) {
+    const float mapped = map(rgb[k] * kExposure) / white;               // filmic.cc:52
+    const float v = 255 * std::min<float>(1, std::pow(mapped, inv_gamma));
+    out_rgb8[k] = v >= 0 ? static_cast<uint8_t>(v) : 0;
+  }
+}
+
 uint64_t oracle_fnv1a64(const void* data, uint64_t n_bytes) {
   const unsigned char* p = static_cast<const unsigned char*>(data);
   uint64_t h = 14695981039346656037ull;

@@ -177,6 +177,10 @@ uint64_t oracle_math_compare(int kind, int mode_a, int mode_b, uint32_t k0, uint
 /* pow(x, n) of a binary32 x in double for n = 4, 5 (lens_thin.cc:92-93,146, material_refraction.cc:271-275) */
 double oracle_pow_i(float x, int n, int math);
 
+/* Output stage: Filmic -> Gamma(2.2) -> 8-bit, postprocess/filmic.cc:30-66 + gamma.cc:36-52 as application.cc:98-108 chains
+ * them, with the host's powf.  rgb: w*h*3 floats in Image order; out: w*h*3 bytes, same order (NOT mirrored). */
+void oracle_tonemap(const float* rgb, uint32_t width, uint32_t height, uint8_t* out_rgb8);
+
 /* image helpers */
 uint64_t oracle_fnv1a64(const void* data, uint64_t n_bytes);
 

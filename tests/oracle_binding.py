@@ -108,12 +108,21 @@ def load():
     L.oracle_pow.argtypes = [f, f, C.c_int]
     L.oracle_fnv1a64.restype = u64
     L.oracle_fnv1a64.argtypes = [vp, u64]
+    L.oracle_tonemap.argtypes = [vp, u32, u32, vp]
     L.oracle_math_compare.restype = u64
     L.oracle_math_compare.argtypes = [C.c_int, C.c_int, C.c_int, u32, u32, f, C.POINTER(f)]
     L.oracle_pow_i.restype = C.c_double
     L.oracle_pow_i.argtypes = [f, C.c_int, C.c_int]
     _lib = L
     return L
+
+
+def tonemap(img):
+    """oracle_tonemap: Filmic -> Gamma -> 8-bit of an (H, W, 3) float32 image."""
+    img = np.ascontiguousarray(img, np.float32)
+    out = np.empty(img.shape, np.uint8)
+    load().oracle_tonemap(img.ctypes.data, img.shape[1], img.shape[0], out.ctypes.data)
+    return out
 
 
 def sensor(width, height):
