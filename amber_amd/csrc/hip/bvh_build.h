@@ -28,12 +28,14 @@
 namespace amber_bvh {
 
 using amber_dev::DevBvhNode;
+using amber_dev::DevBvhNodeQ;
 using amber_dev::DevObject;
 
 #ifndef AMBER_BVH_LEAF_SIZE
 #define AMBER_BVH_LEAF_SIZE 3   // config 3 at 128 spp: 2 -> 151.5 ms, 3 -> 151.1, 4 -> 157.9, 6 -> 173.6
 #endif
-constexpr int kLeafSize = AMBER_BVH_LEAF_SIZE;   // <= 7 (leaf references hold a 3-bit count)
+constexpr int kLeafSize = AMBER_BVH_LEAF_SIZE;   // <= 3 (quantised leaf references: 2-bit count + the spheres-only flag)
+static_assert(kLeafSize >= 1 && kLeafSize <= 3, "DevBvhNodeQ leaf references hold a 2-bit count");
 constexpr int kMaxDepth = 30;     // device stack holds 32 entries
 constexpr int kBins = 16;
 
@@ -217,6 +219,75 @@ struct FlatBvh {
   int32_t root_ref = -1;             // >= 0: inner node 0 ; < 0: the whole scene is one leaf
   uint32_t depth = 0;
 };
+
+// The tree the device traverses (DevBvhNodeQ): child boxes on a 16-bit grid over the bounds of all node boxes, min planes
+// rounded down and max planes up (checked in exact arithmetic: gmin and step are binary32, q * step and the sum are exact
+// in binary64), leaf references re-encoded as first*8 + all_spheres*4 + count.
+struct QuantizedBvh {
+  std::vector<DevBvhNodeQ> nodes;
+  float gmin[3] = {0, 0, 0}, step[3] = {1, 1, 1}, reach[3] = {0, 0, 0};
+  int32_t root_ref = -1;
+};
+template <typename IsSphere>
+inline int32_t QuantizedLeafRef(int32_t ref, IsSphere is_sphere_slot) {
+  if (ref >= 0) return ref;
+  const uint32_t r = static_cast<uint32_t>(-(ref + 1));
+  const uint32_t first = r >> 3, count = r & 7u;
+  bool all = count > 0;
+  for (uint32_t k = 0; k < count; k++) all = all && is_sphere_slot(first + k);
+  return -static_cast<int32_t>(first * 8u + (all ? 4u : 0u) + count) - 1;
+}
+template <typename IsSphere>
+inline QuantizedBvh QuantizeBvh(const std::vector<DevBvhNode>& bin, int32_t root_ref, IsSphere is_sphere_slot) {
+  QuantizedBvh out;
+  out.root_ref = QuantizedLeafRef(root_ref, is_sphere_slot);
+  if (bin.empty()) return out;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  auto child_box = [](const DevBvhNode& nd, int side, float mn[3], float mx[3]) {
+    const float* xy = side ? nd.rxy : nd.lxy;
+    mn[0] = xy[0]; mn[1] = xy[1]; mx[0] = xy[2]; mx[1] = xy[3];
+    mn[2] = nd.z[side ? 2 : 0]; mx[2] = nd.z[side ? 3 : 1];
+  };
+  for (const DevBvhNode& nd : bin)
+    for (int side = 0; side < 2; side++) {
+      float mn[3], mx[3]; child_box(nd, side, mn, mx);
+      for (int c = 0; c < 3; c++) { lo[c] = std::min<double>(lo[c], mn[c]); hi[c] = std::max<double>(hi[c], mx[c]); }
+    }
+  for (int c = 0; c < 3; c++) {
+    out.gmin[c] = std::nextafter(static_cast<float>(lo[c]), -3.0e38f);                    // <= lo
+    double st = (hi[c] - double(out.gmin[c])) / 65535.0;
+    float stf = static_cast<float>(st);
+    while (!(double(out.gmin[c]) + 65535.0 * double(stf) >= hi[c])) stf = std::nextafter(stf, 3.0e38f);
+    if (!(stf > 0.0f)) stf = 1e-30f;
+    out.step[c] = stf;
+    out.reach[c] = static_cast<float>(65535.0 * double(stf) * 1.0001);
+  }
+  out.nodes.resize(bin.size());
+  for (size_t i = 0; i < bin.size(); i++) {
+    const DevBvhNode& nd = bin[i];
+    uint16_t ql[2][3], qh[2][3];
+    for (int side = 0; side < 2; side++) {
+      float mn[3], mx[3]; child_box(nd, side, mn, mx);
+      for (int c = 0; c < 3; c++) {
+        const double g = out.gmin[c], st = out.step[c];
+        double a = std::floor((double(mn[c]) - g) / st), b = std::ceil((double(mx[c]) - g) / st);
+        a = std::min(65535.0, std::max(0.0, a)); b = std::min(65535.0, std::max(0.0, b));
+        while (a > 0 && g + a * st > mn[c]) a -= 1;                                        // exact: conservative in every case
+        while (b < 65535 && g + b * st < mx[c]) b += 1;
+        ql[side][c] = static_cast<uint16_t>(a); qh[side][c] = static_cast<uint16_t>(b);
+      }
+    }
+    DevBvhNodeQ& q = out.nodes[i];
+    for (int side = 0; side < 2; side++) {
+      q.w[3 * side + 0] = uint32_t(ql[side][0]) | (uint32_t(ql[side][1]) << 16);
+      q.w[3 * side + 1] = uint32_t(ql[side][2]) | (uint32_t(qh[side][0]) << 16);
+      q.w[3 * side + 2] = uint32_t(qh[side][1]) | (uint32_t(qh[side][2]) << 16);
+    }
+    q.left = QuantizedLeafRef(nd.left, is_sphere_slot);
+    q.right = QuantizedLeafRef(nd.right, is_sphere_slot);
+  }
+  return out;
+}
 
 // Runs fn(k) for k in [0, n) on `threads` threads (work handed out by an atomic counter).
 template <typename Fn>

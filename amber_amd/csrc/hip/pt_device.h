@@ -85,6 +85,16 @@ struct alignas(16) DevBvhNode {   // 64 B
   float z[4];                     // left min.z, left max.z, right min.z, right max.z
   int32_t left, right, pad0, pad1;
 };
+// The node the DEVICE traverses: the same 2-wide tree with both children's boxes quantised to 16 bits per plane on one
+// grid over the scene bounds (plane = bvh_gmin + q * bvh_step, min planes rounded down, max planes up), 32 bytes = two
+// 16-byte loads per visit instead of four.  The traversal of the 1M-sphere scene is bound by the per-CU rate at which the
+// vector L1 looks up the distinct lines a wave's lanes ask for (rocprofv3: TCP busy 92 %, TA busy 70 %, VALU issue 41 %:
+// profiles/r02_config3_memory_counters.txt), so bytes -- i.e. load instructions -- per visit are what counts.
+// The grid step is 1 / 65535 of the scene extent: 3e-5 of it, 0.3 % of the smallest sphere of config 3.
+struct alignas(16) DevBvhNodeQ {  // 32 B
+  uint32_t w[6];                  // 16-bit planes: L.min.x|L.min.y<<16, L.min.z|L.max.x<<16, L.max.y|L.max.z<<16, then the same for R
+  int32_t left, right;            // >= 0 inner node index; < 0 leaf: -(ref+1) = first*8 + all_spheres*4 + count (count <= 3)
+};
 // Light-tracing source record: one per DiffuseLight object, sorted by power (scene/light_set.h:61-82).
 struct alignas(16) DevLight {     // 96 B
   uint32_t kind; int32_t slot;      // primitive kind ; filter-program slot of a light triangle (-1 otherwise)
@@ -125,7 +135,10 @@ struct DevScene {
   uint32_t always_mask;        // program slots that are always candidates (disks, cylinders, degenerate triangles)
   uint32_t n_prog_tris;        // program slots [0, n_prog_tris) are filtered triangles, then spheres, then the rest
   const DevObject* __restrict__ prog_objects;   // objects in program order, kind |= scene index << 8 (staged to LDS)
-  const DevBvhNode* __restrict__ bvh_nodes;     // engine BVH
+  const DevBvhNodeQ* __restrict__ bvh_nodes;    // engine BVH: quantised 2-wide nodes
+  float bvh_gmin[3], bvh_step[3];               // quantisation grid: plane = bvh_gmin + q * bvh_step
+  float bvh_reach[3];                           // max(|bounds_min - x|, |bounds_max - x|) over x in the bounds, per axis = extent (slab rounding slack)
+  const float4* __restrict__ bvh_spheres;       // (centre, radius) of every object in leaf order (zeros for non-spheres): leaves of spheres only test from here
   const uint32_t* __restrict__ bvh_prims;       // leaf order -> object index
   const DevObject* __restrict__ bvh_objects;    // the object records in leaf order (HitRec.slot of engine BVH indexes this array)
   int32_t bvh_root;                             // child reference of the whole scene
@@ -711,10 +724,13 @@ __device__ __forceinline__ void ClosestHitLeafList(const DevScene& sc, V3 o, V3 
 
 // Traversal state of one ray.  It lives in registers (+ the lane's LDS stack) so that a traversal can be suspended
 // while other lanes of the wave are shaded (pt_bvh_megakernel) and resumed afterwards.
+// Slab parameter of a quantised plane q on axis c:  t = (gmin + q*step - o) / d  is evaluated as ONE fma, q * A + B, with
+// A = step / d and B = (gmin - o) / d per ray; the per-ray margin E that widens every box (direction-length drift, below)
+// lives in two B vectors: min planes use o + E, max planes o - E.
 struct BvhTrav {
-  V3 inv;              // 1/d
-  V3 oi_mn, oi_mx;     // o/d + E/d and o/d - E/d: offsets of the min and max planes of boxes widened by the per-ray margin E
-  float slack_abs;     // absolute widening of [t_in, t_out] for this ray (BvhBegin)
+  V3 A;                // step / d
+  V3 b_mn, b_mx;       // (gmin - (o + E)) / d for the min planes, (gmin - (o - E)) / d for the max planes
+  float slack_abs;     // absolute widening of [t_in, t_out] for this ray (BvhOperands)
   int32_t cur;         // >= 0 inner node, < 0 leaf reference, AMBER_BVH_DONE finished
   int sp;              // entries on the lane's stack
   bool overflow;       // the stack was too small (cannot happen with the builder's depth cap): fall back to the list scan
@@ -724,20 +740,6 @@ struct BvhTrav {
 // Slab-test operands of a ray.
 __device__ __forceinline__ void BvhOperands(const DevScene& sc, V3 o, V3 d, BvhTrav& tr) {
   V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  V3 oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
-  // An axis whose 1/d or o/d is not finite (d component 0 or denormal, huge origin) is taken OUT of the slab test by
-  // making both operands NaN: fma(plane, NaN, NaN) = NaN, which min/max skip.  Leaving +-inf in would not be
-  // conservative in the one-FMA form: for a box that contains the origin, plane*inf - o*inf is -inf for one plane
-  // and inf - inf = NaN for the other, and max(-inf, NaN) = -inf would cull the box.  (An infinite o/d must not
-  // reach the slack either: an infinite slack makes every box "hit", and an axis-parallel ray then walks the whole
-  // tree -- 2 M nodes, 0.75 s for one lane, found on config 3.)
-  const float kNaN = __builtin_nanf("");
-  if (!(Abs(inv.x) < 3.0e38f) || !(Abs(oi.x) < 3.0e38f)) { inv.x = kNaN; oi.x = kNaN; }
-  if (!(Abs(inv.y) < 3.0e38f) || !(Abs(oi.y) < 3.0e38f)) { inv.y = kNaN; oi.y = kNaN; }
-  if (!(Abs(inv.z) < 3.0e38f) || !(Abs(oi.z) < 3.0e38f)) { inv.z = kNaN; oi.z = kNaN; }
-  float mag = __builtin_fmaxf(__builtin_fmaxf(Abs(oi.x), Abs(oi.y)), Abs(oi.z));    // fmax skips the NaN axes
-  if (!(mag == mag)) mag = 0.0f;                                                      // no axis takes part
-  float slack = AMBER_BVH_REL_SLACK * mag;
   // Direction length.  The reference never renormalises sampled directions (vector3.h:236-239) and its sphere test
   // assumes |d| = 1 (a = 1 in SolveQuadratic, primitive_sphere.cc:80-83): with |d|^2 = 1 + delta it accepts a ray whose
   // closest approach p to the centre, at distance s along the ray, satisfies p^2 <= r^2 + delta * s^2 (+ rounding, which
@@ -745,31 +747,38 @@ __device__ __forceinline__ void BvhOperands(const DevScene& sc, V3 o, V3 d, BvhT
   // anything at all in scenes with non-unit disk normals.  The ray must therefore be allowed to miss a sphere's box by
   // E = sqrt(r^2 + delta s^2) - r <= min(delta * S^2 / r_min, sqrt(delta) * S), where S = |o - scene centre| + half the
   // scene diagonal bounds s (no point of the scene is farther from the origin) and r_min is the smallest sphere radius
-  // (no spheres: E = 0).  (Shrinking S to the best hit distance as the traversal goes was tried: the recomputation in
-  // the leaf loop costs 50 B of scratch and 35 % of the speed.)
-  // Widening every box by E costs nothing per node: (mn - E) * inv - o * inv = mn * inv - (o * inv + E * inv), so the
-  // margin moves into two offset vectors, one for the min planes and one for the max planes (adding E * max|1/d| to
-  // the slack instead needs no registers, but a ray with one tiny direction component then gets an enormous slack
-  // and walks the whole tree -- measured: config 3 four times slower).
+  // (no spheres: E = 0).  Widening every box by E costs nothing per node: it moves into the two offset vectors.
   // t itself is measured in units of |d|: the reference's sphere distance and the geometric entry into the sphere's
   // box differ by a relative |delta|, which joins the slack as the absolute term 2 |delta| * S / |d|.
   const float len2 = d.x * d.x + d.y * d.y + d.z * d.z;
   const float delta = len2 - 1.0f;
-  V3 omn = oi, omx = oi;
+  float E = 0.0f, slack_len = 0.0f;
   if (sc.bvh_inv_rmin > 0.0f && !(Abs(delta) <= 2.0e-8f)) {                          // NaN delta: nan_ray in BvhBegin
     const float cx = o.x - sc.bvh_center[0], cy = o.y - sc.bvh_center[1], cz = o.z - sc.bvh_center[2];
     const float S = 1.001f * (__builtin_amdgcn_sqrtf(cx * cx + cy * cy + cz * cz) + sc.bvh_half_diag);
     const float dpos = delta > 0.0f ? delta : 0.0f;
-    const float E = 1.001f * __builtin_fminf(dpos * S * S * sc.bvh_inv_rmin, __builtin_amdgcn_sqrtf(dpos) * S);
-    const V3 ei = v3(E * inv.x, E * inv.y, E * inv.z);                                // NaN on axes taken out above: stays NaN
-    omn = v3(oi.x + ei.x, oi.y + ei.y, oi.z + ei.z); omx = v3(oi.x - ei.x, oi.y - ei.y, oi.z - ei.z);
-    if (!(Abs(omn.x) < 3.0e38f) || !(Abs(omx.x) < 3.0e38f)) { inv.x = kNaN; omn.x = kNaN; omx.x = kNaN; }
-    if (!(Abs(omn.y) < 3.0e38f) || !(Abs(omx.y) < 3.0e38f)) { inv.y = kNaN; omn.y = kNaN; omx.y = kNaN; }
-    if (!(Abs(omn.z) < 3.0e38f) || !(Abs(omx.z) < 3.0e38f)) { inv.z = kNaN; omn.z = kNaN; omx.z = kNaN; }
-    slack += 2.0f * Abs(delta) * S * __builtin_amdgcn_rsqf(__builtin_fminf(len2, 1.0f));   // t <= S / |d|
+    E = 1.001f * __builtin_fminf(dpos * S * S * sc.bvh_inv_rmin, __builtin_amdgcn_sqrtf(dpos) * S);
+    slack_len = 2.0f * Abs(delta) * S * __builtin_amdgcn_rsqf(__builtin_fminf(len2, 1.0f));   // t <= S / |d|
   }
-  tr.slack_abs = slack;
-  tr.inv = inv; tr.oi_mn = omn; tr.oi_mx = omx;
+  V3 A = v3(sc.bvh_step[0] * inv.x, sc.bvh_step[1] * inv.y, sc.bvh_step[2] * inv.z);
+  V3 bmn = v3((sc.bvh_gmin[0] - (o.x + E)) * inv.x, (sc.bvh_gmin[1] - (o.y + E)) * inv.y, (sc.bvh_gmin[2] - (o.z + E)) * inv.z);
+  V3 bmx = v3((sc.bvh_gmin[0] - (o.x - E)) * inv.x, (sc.bvh_gmin[1] - (o.y - E)) * inv.y, (sc.bvh_gmin[2] - (o.z - E)) * inv.z);
+  // Rounding of q * A + B: A and B carry three roundings each and the fma one more -- at most 2^-22 of
+  // (|gmin - o| + E + scene extent) / |d| on the axis; the slack takes 2^-20 of that (per ray, max over the axes).
+  V3 mg = v3((Abs(sc.bvh_gmin[0] - o.x) + E + sc.bvh_reach[0]) * Abs(inv.x), (Abs(sc.bvh_gmin[1] - o.y) + E + sc.bvh_reach[1]) * Abs(inv.y),
+             (Abs(sc.bvh_gmin[2] - o.z) + E + sc.bvh_reach[2]) * Abs(inv.z));
+  // An axis whose operands are not finite (d component 0 or denormal, huge origin) is taken OUT of the slab test by making
+  // them NaN: fma(q, NaN, NaN) = NaN, which min/max skip.  Leaving +-inf in would not be conservative (inf - inf), and an
+  // infinite value must not reach the slack either: an infinite slack makes every box "hit", and an axis-parallel ray
+  // then walks the whole tree -- 2 M nodes, 0.75 s for one lane, found on config 3.
+  const float kNaN = __builtin_nanf("");
+  if (!(Abs(A.x) < 3.0e38f) || !(Abs(bmn.x) < 3.0e38f) || !(Abs(bmx.x) < 3.0e38f) || !(mg.x < 3.0e38f)) { A.x = kNaN; bmn.x = kNaN; bmx.x = kNaN; mg.x = kNaN; }
+  if (!(Abs(A.y) < 3.0e38f) || !(Abs(bmn.y) < 3.0e38f) || !(Abs(bmx.y) < 3.0e38f) || !(mg.y < 3.0e38f)) { A.y = kNaN; bmn.y = kNaN; bmx.y = kNaN; mg.y = kNaN; }
+  if (!(Abs(A.z) < 3.0e38f) || !(Abs(bmn.z) < 3.0e38f) || !(Abs(bmx.z) < 3.0e38f) || !(mg.z < 3.0e38f)) { A.z = kNaN; bmn.z = kNaN; bmx.z = kNaN; mg.z = kNaN; }
+  float mag = __builtin_fmaxf(__builtin_fmaxf(mg.x, mg.y), mg.z);                     // fmax skips the NaN axes
+  if (!(mag == mag)) mag = 0.0f;                                                      // no axis takes part
+  tr.slack_abs = AMBER_BVH_REL_SLACK * mag + slack_len;
+  tr.A = A; tr.b_mn = bmn; tr.b_mx = bmx;
 }
 
 __device__ __forceinline__ void BvhBegin(const DevScene& sc, V3 o, V3 d, BvhTrav& tr, HitRec& best) {
@@ -781,11 +790,29 @@ __device__ __forceinline__ void BvhBegin(const DevScene& sc, V3 o, V3 d, BvhTrav
   tr.cur = nan_ray ? AMBER_BVH_DONE : sc.bvh_root; tr.sp = 0; tr.overflow = false;
 }
 
+// primitive_sphere.cc:75-107 from the compact (centre, radius) record: the same operations as IntersectSphere; the object
+// index (tie rule, reported hit) is fetched only when the distance can win.
+__device__ __forceinline__ void IntersectSphereLeaf(const DevScene& sc, float4 s, uint32_t slot, V3 o, V3 d, HitRec& best) {
+  const V3 co = v3(s.x, s.y, s.z) - o;
+  const float b = -2.0f * Dot(co, d);
+  const float c = SquaredLength(co) - s.w * s.w;
+  float alpha, beta;
+  if (SolveQuadratic(1.0f, b, c, alpha, beta)) {
+    float t;
+    bool ok = true;
+    if (alpha > AMBER_KEPS) t = alpha; else if (beta > AMBER_KEPS) t = beta; else { ok = false; t = 0.f; }
+    if (ok && IsFinite(t) && !(t > best.t)) {
+      const int i = static_cast<int>(sc.bvh_prims[slot]);
+      if (Closer<true>(t, i, best)) { best.t = t; best.idx = i; best.slot = static_cast<int>(slot); }
+    }
+  }
+}
+
 // One round for this lane: descend through at most AMBER_BVH_DESCENT_BUDGET inner nodes; if that reached a leaf, test
 // its objects exactly and pop the next subtree.  Returns false when the traversal is complete.  Unbounded descent
 // ("while-while") makes every lane that already holds a leaf wait for the slowest descent of the wave, one node per
-// round ("if-if") interleaves the expensive exact tests with other lanes' box tests; config 3 at 128 spp:
-// budget 2 -> 195 ms, 3 -> 175, 4 -> 169, 5 -> 164, 6 -> 165, 8 -> 173, unbounded -> 189.
+// round ("if-if") interleaves the expensive exact tests with other lanes' box tests; config 3 at 128 spp (round 1's
+// 64-byte nodes): budget 2 -> 195 ms, 3 -> 175, 4 -> 169, 5 -> 164, 6 -> 165, 8 -> 173, unbounded -> 189.
 #ifndef AMBER_BVH_DESCENT_BUDGET
 #define AMBER_BVH_DESCENT_BUDGET 5
 #endif
@@ -796,15 +823,17 @@ __device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack,
   int sp = tr.sp;
   int budget = AMBER_BVH_DESCENT_BUDGET;
   while (cur >= 0 && cur != AMBER_BVH_DONE && budget-- > 0) {
-    const DevBvhNode* nd = sc.bvh_nodes + cur;
-    const float4 a = *reinterpret_cast<const float4*>(nd->lxy), b = *reinterpret_cast<const float4*>(nd->rxy);
-    const float4 c = *reinterpret_cast<const float4*>(nd->z);
-    const int2 kids = *reinterpret_cast<const int2*>(&nd->left);
-    const int32_t left = kids.x, right = kids.y;
-    // child planes: lxy = (min.x, min.y, max.x, max.y), z = (left min.z, left max.z, right min.z, right max.z)
-    const float lx0 = __builtin_fmaf(a.x, tr.inv.x, -tr.oi_mn.x), ly0 = __builtin_fmaf(a.y, tr.inv.y, -tr.oi_mn.y), lx1 = __builtin_fmaf(a.z, tr.inv.x, -tr.oi_mx.x), ly1 = __builtin_fmaf(a.w, tr.inv.y, -tr.oi_mx.y);
-    const float rx0 = __builtin_fmaf(b.x, tr.inv.x, -tr.oi_mn.x), ry0 = __builtin_fmaf(b.y, tr.inv.y, -tr.oi_mn.y), rx1 = __builtin_fmaf(b.z, tr.inv.x, -tr.oi_mx.x), ry1 = __builtin_fmaf(b.w, tr.inv.y, -tr.oi_mx.y);
-    const float lz0 = __builtin_fmaf(c.x, tr.inv.z, -tr.oi_mn.z), lz1 = __builtin_fmaf(c.y, tr.inv.z, -tr.oi_mx.z), rz0 = __builtin_fmaf(c.z, tr.inv.z, -tr.oi_mn.z), rz1 = __builtin_fmaf(c.w, tr.inv.z, -tr.oi_mx.z);
+    const uint4* nd = reinterpret_cast<const uint4*>(sc.bvh_nodes + cur);
+    const uint4 p = nd[0], q = nd[1];
+    const int32_t left = static_cast<int32_t>(q.z), right = static_cast<int32_t>(q.w);
+#define AMBER_QLO(wd) static_cast<float>((wd) & 0xffffu)
+#define AMBER_QHI(wd) static_cast<float>((wd) >> 16)
+    const float lx0 = __builtin_fmaf(AMBER_QLO(p.x), tr.A.x, tr.b_mn.x), ly0 = __builtin_fmaf(AMBER_QHI(p.x), tr.A.y, tr.b_mn.y), lz0 = __builtin_fmaf(AMBER_QLO(p.y), tr.A.z, tr.b_mn.z);
+    const float lx1 = __builtin_fmaf(AMBER_QHI(p.y), tr.A.x, tr.b_mx.x), ly1 = __builtin_fmaf(AMBER_QLO(p.z), tr.A.y, tr.b_mx.y), lz1 = __builtin_fmaf(AMBER_QHI(p.z), tr.A.z, tr.b_mx.z);
+    const float rx0 = __builtin_fmaf(AMBER_QLO(p.w), tr.A.x, tr.b_mn.x), ry0 = __builtin_fmaf(AMBER_QHI(p.w), tr.A.y, tr.b_mn.y), rz0 = __builtin_fmaf(AMBER_QLO(q.x), tr.A.z, tr.b_mn.z);
+    const float rx1 = __builtin_fmaf(AMBER_QHI(q.x), tr.A.x, tr.b_mx.x), ry1 = __builtin_fmaf(AMBER_QLO(q.y), tr.A.y, tr.b_mx.y), rz1 = __builtin_fmaf(AMBER_QHI(q.y), tr.A.z, tr.b_mx.z);
+#undef AMBER_QLO
+#undef AMBER_QHI
     bool hl, hr; float tl, tr_;
     SlabDecide(lx0, lx1, ly0, ly1, lz0, lz1, tr.slack_abs, best.t, hl, tl);
     SlabDecide(rx0, rx1, ry0, ry1, rz0, rz1, tr.slack_abs, best.t, hr, tr_);
@@ -828,11 +857,15 @@ __device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack,
   if (cur >= 0 && cur != AMBER_BVH_DONE) more = true;   // budget used up: keep descending next round
   else if (cur != AMBER_BVH_DONE) {                         // cur < 0: a leaf
     const uint32_t ref = static_cast<uint32_t>(-(cur + 1));
-    const uint32_t first = ref >> 3, count = ref & 7u;
-    for (uint32_t k = 0; k < count; ++k) {
-      const uint32_t oi = sc.bvh_prims[first + k];                 // scene index (tie rule, reported hit); independent of ...
-      const DevObject& ob = sc.bvh_objects[first + k];             // ... the record itself, stored in leaf order: no dependent load
-      IntersectObject<true>(ob, ob.kind, static_cast<int>(oi), static_cast<int>(first + k), o, d, best);
+    const uint32_t first = ref >> 3, count = ref & 3u;
+    if (ref & 4u) {                                         // spheres only: one 16-byte record each
+      for (uint32_t k = 0; k < count; ++k) IntersectSphereLeaf(sc, sc.bvh_spheres[first + k], first + k, o, d, best);
+    } else {
+      for (uint32_t k = 0; k < count; ++k) {
+        const uint32_t oi = sc.bvh_prims[first + k];                 // scene index (tie rule, reported hit); independent of ...
+        const DevObject& ob = sc.bvh_objects[first + k];             // ... the record itself, stored in leaf order: no dependent load
+        IntersectObject<true>(ob, ob.kind, static_cast<int>(oi), static_cast<int>(first + k), o, d, best);
+      }
     }
     if (sp > 0) { --sp; cur = stack[sp * stride]; more = true; }
     else cur = AMBER_BVH_DONE;

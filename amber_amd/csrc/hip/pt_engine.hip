@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? 5 : 4) pt_bvh_megakernel(c
   uint32_t casts = 0;
   uint32_t rays_wave = 0;                                   // wave-uniform (SGPR): rays shaded by this wave
   int origin_slot = -1;
-  BvhTrav tr; tr.inv = v3(0.f, 0.f, 0.f); tr.oi_mn = v3(0.f, 0.f, 0.f); tr.oi_mx = v3(0.f, 0.f, 0.f); tr.slack_abs = 0.f;
+  BvhTrav tr; tr.A = v3(0.f, 0.f, 0.f); tr.b_mn = v3(0.f, 0.f, 0.f); tr.b_mx = v3(0.f, 0.f, 0.f); tr.slack_abs = 0.f;
   tr.cur = AMBER_BVH_DONE; tr.sp = 0; tr.overflow = false;
   HitRec hit; hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.idx = -1; hit.slot = -1;
 #ifdef AMBER_STAMPS
@@ -542,7 +542,8 @@ struct amber_hip_pt {
   DevTriFilter* d_tri_filters = nullptr;
   DevSphereFilter* d_sphere_filters = nullptr;
   DevObject* d_prog_objects = nullptr;
-  DevBvhNode* d_bvh_nodes = nullptr;
+  DevBvhNodeQ* d_bvh_nodes = nullptr;
+  float4* d_bvh_spheres = nullptr;
   uint32_t* d_bvh_prims = nullptr;
   DevObject* d_bvh_objects = nullptr;
   bool two_phase = false;
@@ -771,15 +772,24 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   }
   HIP_TRY_H(hipMalloc(&h->d_lights, (lights.size() + 1) * sizeof(DevLight)));
   if (!lights.empty()) HIP_TRY_H(hipMemcpy(h->d_lights, lights.data(), lights.size() * sizeof(DevLight), hipMemcpyHostToDevice));
-  HIP_TRY_H(hipMalloc(&h->d_bvh_nodes, (bvh.nodes.size() + 1) * sizeof(DevBvhNode)));
+  // engine BVH: quantised nodes, leaf-order permutation, object records and compact sphere records in leaf order
+  amber_bvh::QuantizedBvh qbvh = amber_bvh::QuantizeBvh(bvh.nodes, bvh.root_ref, [&](uint32_t slot) { return (objs[bvh.prim_index[slot]].kind & 0xffu) == AMBER_PRIM_SPHERE; });
+  HIP_TRY_H(hipMalloc(&h->d_bvh_nodes, (qbvh.nodes.size() + 1) * sizeof(DevBvhNodeQ)));
   HIP_TRY_H(hipMalloc(&h->d_bvh_prims, (bvh.prim_index.size() + 1) * sizeof(uint32_t)));
-  if (!bvh.nodes.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(DevBvhNode), hipMemcpyHostToDevice));
+  if (!qbvh.nodes.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_nodes, qbvh.nodes.data(), qbvh.nodes.size() * sizeof(DevBvhNodeQ), hipMemcpyHostToDevice));
   if (!bvh.prim_index.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_prims, bvh.prim_index.data(), bvh.prim_index.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   {
     std::vector<DevObject> leaf_order(bvh.prim_index.size());
-    for (size_t k = 0; k < leaf_order.size(); k++) leaf_order[k] = objs[bvh.prim_index[k]];
+    std::vector<float4> leaf_spheres(bvh.prim_index.size());
+    for (size_t k = 0; k < leaf_order.size(); k++) {
+      const DevObject& ob = objs[bvh.prim_index[k]];
+      leaf_order[k] = ob;
+      leaf_spheres[k] = (ob.kind & 0xffu) == AMBER_PRIM_SPHERE ? make_float4(ob.a[0], ob.a[1], ob.a[2], ob.radius) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     HIP_TRY_H(hipMalloc(&h->d_bvh_objects, (leaf_order.size() + 1) * sizeof(DevObject)));
+    HIP_TRY_H(hipMalloc(&h->d_bvh_spheres, (leaf_spheres.size() + 1) * sizeof(float4)));
     if (!leaf_order.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_objects, leaf_order.data(), leaf_order.size() * sizeof(DevObject), hipMemcpyHostToDevice));
+    if (!leaf_spheres.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_spheres, leaf_spheres.data(), leaf_spheres.size() * sizeof(float4), hipMemcpyHostToDevice));
   }
   if (!fprog.spheres.empty()) HIP_TRY_H(hipMemcpy(h->d_sphere_filters, fprog.spheres.data(), fprog.spheres.size() * sizeof(DevSphereFilter), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_objects, objs.data(), objs.size() * sizeof(DevObject), hipMemcpyHostToDevice));
@@ -801,7 +811,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades;
   sc.planes = h->d_planes; sc.tri_filters = h->d_tri_filters; sc.sphere_filters = h->d_sphere_filters;
   sc.n_planes = static_cast<uint32_t>(fprog.planes.size()); sc.n_sphere_filters = static_cast<uint32_t>(fprog.spheres.size());
-  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_root = bvh.root_ref;
+  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_spheres = h->d_bvh_spheres; sc.bvh_root = qbvh.root_ref;
+  for (int c = 0; c < 3; c++) { sc.bvh_gmin[c] = qbvh.gmin[c]; sc.bvh_step[c] = qbvh.step[c]; sc.bvh_reach[c] = qbvh.reach[c]; }
   {
     // per-ray box margin of engine BVH (BvhBegin): centre and half diagonal of the scene bounds, 1 / smallest sphere radius
     double d2 = 0;
@@ -1207,6 +1218,7 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_sphere_filters) (void)hipFree(h->d_sphere_filters);
   if (h->d_prog_objects) (void)hipFree(h->d_prog_objects);
   if (h->d_bvh_nodes) (void)hipFree(h->d_bvh_nodes);
+  if (h->d_bvh_spheres) (void)hipFree(h->d_bvh_spheres);
   if (h->d_bvh_prims) (void)hipFree(h->d_bvh_prims);
   if (h->d_bvh_objects) (void)hipFree(h->d_bvh_objects);
   if (h->d_wf) (void)hipFree(h->d_wf);
