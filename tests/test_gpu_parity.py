@@ -466,6 +466,55 @@ def test_million_spheres_bvh_properties(amber):
     print(f"\\n1M spheres: scene+BVH build {t_build:.1f} s, {W}x{H}@{spp}: {ms:.1f} ms, {rays / ms / 1e3:.1f} Mrays/s, {rpp:.2f} rays/path")
 
 
+def test_million_spheres_closest_hits_against_the_oracle_list(amber):
+    """BASELINE config 3's own scene (1M spheres): closest hits of engine BVH against the oracle's List acceleration
+    (acceleration_list.h:51-68: every sphere tested, 6e8 exact sphere tests on the CPU) -- object, distance, position, normal."""
+    from amber_amd import scenes
+    k = scenes.random_spheres(1_000_000, 7)
+    hs = amber.HostScene.create_arrays(**k)
+    osc = O.Scene.create_arrays(**k, accel=O.ACCEL_LIST)
+    pt = amber.PathTracer(hs, amber.Sensor.default(64, 64), seed=3)
+    rng = np.random.default_rng(77)
+    n = 600
+    org = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32)
+    org[: n // 3] = [0.0, 0.0, 4.0]                                             # camera rays: long traversals through the whole cloud
+    d = rng.normal(size=(n, 3)); d[: n // 3] = [0, 0, -1] + rng.normal(0, 0.12, (n // 3, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[-40:-20, 1] = 0.0; d[-20:] = np.sign(d[-20:]) * [1, 0, 0]                  # zero components / axis-parallel rays
+    nz = np.linalg.norm(d, axis=1) > 0
+    d[nz] = (d[nz] / np.linalg.norm(d[nz], axis=1, keepdims=True)).astype(np.float32)
+    obj = _check_casts(pt, osc, org, d)
+    assert (obj >= 0).mean() > 0.9
+    # whole paths too: 120 (pixel, sample) pairs, every bounce
+    px = rng.integers(0, 64 * 64, 120).astype(np.uint32); sm = rng.integers(0, 256, 120).astype(np.uint32)
+    casts = _compare_traces(pt, osc, 64, 64, 3, px, sm)
+    assert casts.max() >= 4
+
+
+def test_million_spheres_at_full_size(amber):
+    """BASELINE config 3 at its real size, 1920x1080 @ 256 spp: deterministic, finite, and the path statistics of the scene."""
+    from amber_amd import scenes
+    hs = amber.HostScene.create_arrays(**scenes.random_spheres(1_000_000, 7))
+    W, H, spp = 1920, 1080, 256
+    pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=1)
+    pt.render_pass(0, spp)
+    img, rays = pt.download()
+    n, ms = pt.kernel_time()
+    pt.clear(); pt.render_pass(0, spp)
+    img2, rays2 = pt.download()
+    assert rays == rays2 and np.array_equal(bits(img), bits(img2))
+    assert np.isfinite(img).all() and (img >= 0).all() and (img > 0).mean() > 0.5
+    rpp = rays / (W * H * spp)
+    assert 2.4 < rpp < 2.8                                                       # 2.59 rays per path (profiles/r01_config3_bvh.txt)
+    # half the resolution at a quarter of the samples estimates the same sensor: the total power (a pixel's value scales
+    # with its area, lens_thin.cc:138-148) agrees within 2 %
+    small = amber.PathTracer(hs, amber.Sensor.default(W // 2, H // 2), seed=1)
+    small.render_pass(0, 64)
+    simg, _ = small.download()
+    assert abs((img.astype(np.float64).sum() / spp) / (simg.astype(np.float64).sum() / 64) - 1) < 0.02
+    print(f"\nconfig 3 full size: {ms / n:.1f} ms per launch, {rays / (ms / n) / 1e3:.1f} Mrays/s, {rpp:.3f} rays/path")
+
+
 def test_wavefront_engine_is_bit_identical(amber, cornell, generic):
     """Engine WAVEFRONT (SoA ray queues in HBM, one launch per bounce, ballot/prefix-sum compaction) == default engine."""
     for (hs, osc), (W, H, passes) in ((cornell, (96, 80, [(0, 40), (40, 7)])), (generic, (64, 64, [(5, 33)]))):
