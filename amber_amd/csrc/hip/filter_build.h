@@ -61,7 +61,7 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, const float c
   const double c = 32.0 * eps * (diam + 1.5 * e_max);
   // per triangle of a group: the three affine coordinate functions (of v0, v1, v2) in double, for pairing
   struct Tri { uint32_t index; double v[3][3]; double coef[3][4]; double g; };   // coef[k] = (gradient, constant) of the coordinate of vertex k
-  struct Group { double n[3], d0, kt, ktol; std::vector<Tri> tris; };
+  struct Group { double n[3], d0, kt, ktol; std::vector<Tri> tris; bool flip = false, same_normal = false; };
   std::vector<Group> groups;
   std::vector<uint32_t> sphere_index, always_index;
   for (size_t i = 0; i < objs.size() && i < 32; i++) {
@@ -99,7 +99,7 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, const float c
       const double ktol = (c + dist) * g * 1.0001 + 1e-7;
       const double kt = 2.0 * (c + dist) * std::max(1.0, inv_sin) + 1e-7;
       if (!std::isfinite(ktol) || !std::isfinite(static_cast<float>(a0)) || !std::isfinite(static_cast<float>(b0)) || !std::isfinite(kt)) { always_index.push_back(idx); continue; }
-      if (!grp) { groups.push_back(Group{{n[0], n[1], n[2]}, d0, 0.0, 0.0, {}}); grp = &groups.back(); }
+      if (!grp) { groups.push_back(Group{{n[0], n[1], n[2]}, d0, 0.0, 0.0, {}, false, false}); grp = &groups.back(); }
       grp->kt = std::max(grp->kt, kt);
       grp->ktol = std::max(grp->ktol, ktol);
       grp->tris.push_back(t);
@@ -144,12 +144,40 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, const float c
       wsum += gw;
     }
     if (wsum > 0) for (int k = 0; k < 3; k++) cw[k] /= wsum;
+    // Parallel planes are kept adjacent (they share n.d, n.o and the reciprocal on the device): planes are classed by
+    // normal direction up to sign; classes are ordered by their innermost member, members by distance.  A member whose
+    // normal is the negative of its class's first normal is stored with normal and offset negated (the same plane).
+    std::vector<int> cls(groups.size(), -1);
+    std::vector<size_t> cls_first;
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+      for (size_t c = 0; c < cls_first.size() && cls[gi] < 0; c++) {
+        const Group& f = groups[cls_first[c]];
+        const double dot = f.n[0] * groups[gi].n[0] + f.n[1] * groups[gi].n[1] + f.n[2] * groups[gi].n[2];
+        if (std::fabs(std::fabs(dot) - 1.0) <= 1e-12) {       // numerically the same direction: the float normals are then made identical
+          cls[gi] = static_cast<int>(c);
+          const double sgn = dot < 0 ? -1.0 : 1.0;
+          for (int k = 0; k < 3; k++) groups[gi].n[k] = sgn * f.n[k];
+          groups[gi].flip = dot < 0;
+        }
+      }
+      if (cls[gi] < 0) { cls[gi] = static_cast<int>(cls_first.size()); cls_first.push_back(gi); }
+    }
+    auto dist2 = [&](size_t gi) { double d2 = 0; for (int k = 0; k < 3; k++) d2 += (gc[gi * 3 + k] - cw[k]) * (gc[gi * 3 + k] - cw[k]); return d2; };
+    std::vector<double> cls_min(cls_first.size(), 1e300);
+    for (size_t gi = 0; gi < groups.size(); gi++) cls_min[cls[gi]] = std::min(cls_min[cls[gi]], dist2(gi));
     std::vector<size_t> perm(groups.size());
     for (size_t gi = 0; gi < perm.size(); gi++) perm[gi] = gi;
-    auto dist2 = [&](size_t gi) { double d2 = 0; for (int k = 0; k < 3; k++) d2 += (gc[gi * 3 + k] - cw[k]) * (gc[gi * 3 + k] - cw[k]); return d2; };
-    std::stable_sort(perm.begin(), perm.end(), [&](size_t x, size_t y) { return dist2(x) < dist2(y); });
+    std::stable_sort(perm.begin(), perm.end(), [&](size_t x, size_t y) {
+      if (cls[x] != cls[y]) return cls_min[cls[x]] != cls_min[cls[y]] ? cls_min[cls[x]] < cls_min[cls[y]] : cls[x] < cls[y];
+      return dist2(x) < dist2(y);
+    });
     std::vector<Group> sorted;
-    for (size_t gi : perm) sorted.push_back(groups[gi]);
+    int prev_cls = -1;
+    for (size_t gi : perm) {
+      sorted.push_back(groups[gi]);
+      sorted.back().same_normal = cls[gi] == prev_cls;
+      prev_cls = cls[gi];
+    }
     groups.swap(sorted);
   }
   for (const Group& g : groups) {
@@ -191,9 +219,9 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, const float c
     }
     DevPlane p;
     std::memset(&p, 0, sizeof p);
-    for (int k = 0; k < 3; k++) p.n[k] = static_cast<float>(g.n[k]);
+    for (int k = 0; k < 3; k++) p.n[k] = static_cast<float>(g.flip ? -g.n[k] : g.n[k]);   // the class's first normal, bit for bit
     // the pair evaluation adds two roundings of 1 - x (<= 1.2e-7 each) and the corner mismatch measured above
-    p.d0 = static_cast<float>(g.d0); p.kt = static_cast<float>(g.kt * 1.0001); p.ktol = static_cast<float>((g.ktol + 4e-7 + pair_slack) * 1.0001);
+    p.d0 = static_cast<float>(g.flip ? -g.d0 : g.d0); p.kt = static_cast<float>(g.kt * 1.0001); p.ktol = static_cast<float>((g.ktol + 4e-7 + pair_slack) * 1.0001);
     for (size_t i = 0; i < nt; i++) {
       if (partner[i] < 0 || static_cast<size_t>(partner[i]) < i) continue;
       const int bi = unshared[i], ai = (bi + 1) % 3;
@@ -207,6 +235,7 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, const float c
       fp.order.push_back(g.tris[i].index);
       p.n_tris++;
     }
+    if (g.same_normal) p.n_tris |= 0x80000000u;
     fp.planes.push_back(p);
   }
   fp.n_prog_tris = static_cast<uint32_t>(fp.order.size());

@@ -60,7 +60,7 @@ struct alignas(16) DevPlane {       // 32 B: one s_load_dwordx8
   float n[3]; float d0;             // unit normal, n.v0
   float kt;                         // tolerance of the t >= kEPS test   (multiplied by |1/(n.d)|)
   float ktol;                       // barycentric tolerance, max over the plane's triangles (same factor)
-  uint32_t n_tris;                  // single-triangle records that follow the pair records
+  uint32_t n_tris;                  // single-triangle records that follow the pair records; bit 31: same normal vector as the previous plane
   uint32_t n_pairs;                 // parallelogram records: ONE DevTriFilter, TWO consecutive candidate bits
 };
 // A single triangle: u, v = barycentric coordinates of v1, v2.  A parallelogram pair (two coplanar triangles that
@@ -580,10 +580,13 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
     ConstWords tr = (ConstWords)(sc.tri_filters);
     const int n_planes = static_cast<int>(sc.n_planes);
     uint32_t bit = 1u;                                       // candidate bit of the next program triangle (SALU)
+    float nd = 0.f, no = 0.f, rc = 0.f;
     for (int p = 0; p < n_planes; ++p, pl += 8) {           // DevPlane = 8 dwords
-      const float nd = __builtin_fmaf(cw_f(pl, 0), d.x, __builtin_fmaf(cw_f(pl, 1), d.y, cw_f(pl, 2) * d.z));
-      const float no = __builtin_fmaf(cw_f(pl, 0), o.x, __builtin_fmaf(cw_f(pl, 1), o.y, cw_f(pl, 2) * o.z));
-      const float rc = __builtin_amdgcn_rcpf(nd);
+      if (!(pl[6] & 0x80000000u)) {                         // a plane parallel to the previous one (same stored normal) reuses n.d, n.o and 1 / n.d
+        nd = __builtin_fmaf(cw_f(pl, 0), d.x, __builtin_fmaf(cw_f(pl, 1), d.y, cw_f(pl, 2) * d.z));
+        no = __builtin_fmaf(cw_f(pl, 0), o.x, __builtin_fmaf(cw_f(pl, 1), o.y, cw_f(pl, 2) * o.z));
+        rc = __builtin_amdgcn_rcpf(nd);
+      }
       const float tp = (cw_f(pl, 3) - no) * rc;
       const float rho = Abs(rc);
       const float Px = __builtin_fmaf(tp, d.x, o.x), Py = __builtin_fmaf(tp, d.y, o.y), Pz = __builtin_fmaf(tp, d.z, o.z);
@@ -597,7 +600,7 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
       const float ptol = cw_f(pl, 5) * rho;
       const float mtol = grazing ? -3.402823466e+38f : -ptol;                             // grazing: any in-plane position passes
       bool plane_hit = false;
-      const int nt = static_cast<int>(pl[6]), np = static_cast<int>(pl[7]);
+      const int nt = static_cast<int>(pl[6] & 0x7fffffffu), np = static_cast<int>(pl[7]);
       for (int k = 0; k < np; ++k, tr += 8, bit <<= 2) {    // parallelogram pairs: one record, two candidate bits
         const float b = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 2), Py, __builtin_fmaf(cw_f(tr, 4), Pz, cw_f(tr, 6))));
         const float a = __builtin_fmaf(cw_f(tr, 1), Px, __builtin_fmaf(cw_f(tr, 3), Py, __builtin_fmaf(cw_f(tr, 5), Pz, cw_f(tr, 7))));

@@ -732,9 +732,10 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   if (h->two_phase) amber_filter::BuildFilterProgram(objs, fp_center, fprog);
   if (h->two_phase && std::getenv("AMBER_DEBUG_FILTER")) {     // diagnostic: shape of the Phase-A program
     uint32_t pairs = 0, singles = 0;
-    for (const DevPlane& pl : fprog.planes) { pairs += pl.n_pairs; singles += pl.n_tris; }
-    std::fprintf(stderr, "amber_hip: filter program: %zu planes, %u pair records, %u single records, %zu spheres, always mask %#x\n",
-                 fprog.planes.size(), pairs, singles, fprog.spheres.size(), fprog.always_mask);
+    uint32_t shared = 0;
+    for (const DevPlane& pl : fprog.planes) { pairs += pl.n_pairs; singles += pl.n_tris & 0x7fffffffu; shared += pl.n_tris >> 31; }
+    std::fprintf(stderr, "amber_hip: filter program: %zu planes (%u share the previous plane's normal), %u pair records, %u single records, %zu spheres, always mask %#x\n",
+                 fprog.planes.size(), shared, pairs, singles, fprog.spheres.size(), fprog.always_mask);
   }
   for (uint32_t i = 0; i < L.n_blades; i++)            // filter-program slot of every aperture blade (self-candidate trip)
     for (uint32_t k = 0; k < fprog.n_prog_tris; k++)
