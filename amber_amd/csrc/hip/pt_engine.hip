@@ -224,7 +224,12 @@ __global__ void reduce_flagged_kernel(float* __restrict__ fb, const uint32_t* __
   if (p >= n_pixels) return;
   const uint32_t q0 = p * n_samples, q1 = q0 + n_samples;      // n_pixels * n_samples < 2^32 (render_pass splits launches)
   bool any = false;
-  for (uint32_t wd = q0 >> 5; wd <= (q1 - 1u) >> 5; ++wd) any |= flags[wd] != 0u;   // neighbours' bits may share the edge words: harmless
+  if ((n_samples & 127u) == 0u) {                              // the pixel's bits are whole 16-byte groups: wide loads
+    const uint4* f4 = reinterpret_cast<const uint4*>(flags + (q0 >> 5));
+    for (uint32_t k = 0; k < n_samples / 128u; ++k) { const uint4 f = f4[k]; any |= (f.x | f.y | f.z | f.w) != 0u; }
+  } else {
+    for (uint32_t wd = q0 >> 5; wd <= (q1 - 1u) >> 5; ++wd) any |= flags[wd] != 0u;   // neighbours' bits may share the edge words: harmless
+  }
   if (!any) return;
   float v0 = fb[3u * p], v1 = fb[3u * p + 1u], v2 = fb[3u * p + 2u];
   for (uint32_t c0 = 0; c0 < n_samples; c0 += AMBER_ACCUM_CHUNK) {
