@@ -604,9 +604,10 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
       for (int k = 0; k < np; ++k, tr += 8, bit <<= 2) {    // parallelogram pairs: one record, two candidate bits
         const float b = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 2), Py, __builtin_fmaf(cw_f(tr, 4), Pz, cw_f(tr, 6))));
         const float a = __builtin_fmaf(cw_f(tr, 1), Px, __builtin_fmaf(cw_f(tr, 3), Py, __builtin_fmaf(cw_f(tr, 5), Pz, cw_f(tr, 7))));
-        const float g = 1.0f - b - a;
+        const float ba = b + a;                             // 1 - gamma: the second triangle's first coordinate
+        const float g = 1.0f - ba;
         const float m1 = __builtin_fminf(__builtin_fminf(b, a), g);
-        const float m2 = __builtin_fminf(__builtin_fminf(-b, 1.0f - a), 1.0f - g);
+        const float m2 = __builtin_fminf(__builtin_fminf(-b, 1.0f - a), ba);
         const bool keep1 = (!(m1 < mtol) && t_ok) || degenerate;                          // NaN coordinates -> keep
         const bool keep2 = (!(m2 < mtol) && t_ok) || degenerate;
         cand |= keep1 ? bit : 0u;

@@ -87,18 +87,20 @@ struct RenderArgs {
 // queue head the bottleneck -- 190 ms per launch; 1024 paths (16 generation rounds) is 15 atomics per microsecond, and the
 // tail it can leave on one wave is ~35 iterations (80 us).
 #define AMBER_CLAIM_PATHS 1024u
-template <bool kLight> struct PoolLayout { static constexpr int kFields = kLight ? 13 : 11; };   // o3 d3 w(1|3) origin_slot rng2 q
+// Pool slot: three 16-byte chunks {o.xyz d.x} {d.yz w slot} {rng q -} (stride 48 B: ds_read_b128 / ds_write_b128 without bank
+// conflicts); light tracing carries an RGB weight and uses a fourth chunk.
+template <bool kLight> struct PoolLayout { static constexpr int kChunks = kLight ? 4 : 3; };
 
 template <int kEngine, bool kLight = false>
 __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megakernel(const RenderArgs a) {
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
   constexpr bool kTwoPhase = kEngine == ENGINE_TWO_PHASE;
-  constexpr int kFields = PoolLayout<kLight>::kFields;
+  constexpr int kChunks = PoolLayout<kLight>::kChunks;
   __shared__ DevObject lds_objects[kTwoPhase ? AMBER_MAX_LDS_OBJECTS : 1];
-  __shared__ uint32_t lds_pool[4][kFields][64];               // [wave][field][slot]
+  __shared__ uint4 lds_pool[4][64 * kChunks];                 // [wave][slot * kChunks + chunk]
   if (kTwoPhase) StageObjects(sc, lds_objects);
-  uint32_t (*pool)[64] = lds_pool[threadIdx.x >> 6];
+  uint4* pool = lds_pool[threadIdx.x >> 6];
 
   uint32_t claim_next = 0, claim_end = 0;    // wave-uniform: paths claimed from the global queue, not yet generated
   uint32_t pool_count = 0;                   // wave-uniform: rays in the pool (slots [0, pool_count))
@@ -156,13 +158,10 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
               GenerateEyeRay(sc, px, py, grng, go, gd, ew, gslot);
               gw = v3(ew, ew, ew);                            // Leading<RGB>(.., Radiant(weight)) lens_basic.h:139-144
             }
-            pool[0][lane] = __float_as_uint(go.x); pool[1][lane] = __float_as_uint(go.y); pool[2][lane] = __float_as_uint(go.z);
-            pool[3][lane] = __float_as_uint(gd.x); pool[4][lane] = __float_as_uint(gd.y); pool[5][lane] = __float_as_uint(gd.z);
-            pool[6][lane] = static_cast<uint32_t>(gslot);
-            pool[7][lane] = static_cast<uint32_t>(grng); pool[8][lane] = static_cast<uint32_t>(grng >> 32);
-            pool[9][lane] = gq;
-            pool[10][lane] = __float_as_uint(gw.x);
-            if (kLight) { pool[11][lane] = __float_as_uint(gw.y); pool[12][lane] = __float_as_uint(gw.z); }
+            pool[lane * kChunks + 0] = make_uint4(__float_as_uint(go.x), __float_as_uint(go.y), __float_as_uint(go.z), __float_as_uint(gd.x));
+            pool[lane * kChunks + 1] = make_uint4(__float_as_uint(gd.y), __float_as_uint(gd.z), __float_as_uint(gw.x), static_cast<uint32_t>(gslot));
+            pool[lane * kChunks + 2] = make_uint4(static_cast<uint32_t>(grng), static_cast<uint32_t>(grng >> 32), gq, 0u);
+            if (kLight) pool[lane * kChunks + (kChunks - 1)] = make_uint4(__float_as_uint(gw.y), __float_as_uint(gw.z), 0u, 0u);
           }
           pool_count = n_new;
           AMBER_STAMP(1);
@@ -171,13 +170,15 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
         const uint32_t take = pool_count < left ? pool_count : left;
         if (need && !alive && rank >= served && rank < served + take) {      // pop: the wave's own LDS writes are in order, no barrier
           const uint32_t sl = pool_count - 1u - (rank - served);
-          o = v3(__uint_as_float(pool[0][sl]), __uint_as_float(pool[1][sl]), __uint_as_float(pool[2][sl]));
-          d = v3(__uint_as_float(pool[3][sl]), __uint_as_float(pool[4][sl]), __uint_as_float(pool[5][sl]));
-          origin_slot = static_cast<int>(pool[6][sl]);
-          rng = static_cast<uint64_t>(pool[7][sl]) | (static_cast<uint64_t>(pool[8][sl]) << 32);
-          q = pool[9][sl];
-          const float wx = __uint_as_float(pool[10][sl]);
-          w = kLight ? v3(wx, __uint_as_float(pool[11][sl]), __uint_as_float(pool[12][sl])) : v3(wx, wx, wx);
+          const uint4 c0 = pool[sl * kChunks + 0], c1 = pool[sl * kChunks + 1], c2 = pool[sl * kChunks + 2];
+          o = v3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z));
+          d = v3(__uint_as_float(c0.w), __uint_as_float(c1.x), __uint_as_float(c1.y));
+          origin_slot = static_cast<int>(c1.w);
+          rng = static_cast<uint64_t>(c2.x) | (static_cast<uint64_t>(c2.y) << 32);
+          q = c2.z;
+          const float wx = __uint_as_float(c1.z);
+          if (kLight) { const uint4 c3 = pool[sl * kChunks + (kChunks - 1)]; w = v3(wx, __uint_as_float(c3.x), __uint_as_float(c3.y)); }
+          else w = v3(wx, wx, wx);
           meas = v3(0.f, 0.f, 0.f);
           casts = 0;
           alive = true;
