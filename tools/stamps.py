@@ -3,6 +3,8 @@ import ctypes as C, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import amber_amd.api as api
 api._LIB_PATH = api._ROOT / "lib" / "libamber_hip_stamps.so"
+if not api._LIB_PATH.exists():                      # measurement builds are not kept in the tree: build on demand (30 s)
+    import subprocess; subprocess.run(["make", "-C", str(api._ROOT / "csrc"), "stamps"], check=True, stdout=subprocess.DEVNULL)
 import amber_amd as A
 lib = A.load_library()
 lib.amber_hip_pt_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong * 8)]
