@@ -278,11 +278,8 @@ inline QuantizedBvh QuantizeBvh(const std::vector<DevBvhNode>& bin, int32_t root
       }
     }
     DevBvhNodeQ& q = out.nodes[i];
-    for (int side = 0; side < 2; side++) {
-      q.w[3 * side + 0] = uint32_t(ql[side][0]) | (uint32_t(ql[side][1]) << 16);
-      q.w[3 * side + 1] = uint32_t(ql[side][2]) | (uint32_t(qh[side][0]) << 16);
-      q.w[3 * side + 2] = uint32_t(qh[side][1]) | (uint32_t(qh[side][2]) << 16);
-    }
+    for (int side = 0; side < 2; side++)
+      for (int c = 0; c < 3; c++) q.w[3 * side + c] = uint32_t(ql[side][c]) | (uint32_t(qh[side][c]) << 16);   // one word per axis: min | max << 16
     q.left = QuantizedLeafRef(nd.left, is_sphere_slot);
     q.right = QuantizedLeafRef(nd.right, is_sphere_slot);
   }

@@ -30,7 +30,26 @@ __device__ __forceinline__ void StampAt(StampCtx* c, int k) {
 #define AMBER_STAMP_PARAM , StampCtx* stamp_ctx
 #define AMBER_STAMP_ARG , stamp_ctx
 #define AMBER_STAMP(k) StampAt(stamp_ctx, k)
+// Engine BVH in the same build: lane / wave-trip counters of the divergent loops instead of clocks (tools/bvh_counters.py).
+// acc[2k] += 1 on every lane that executes the site, acc[2k+1] += 1 on the first active lane only (wave-level trips).
+__device__ __forceinline__ void CountAt(StampCtx* c, int k) {
+  if (!c) return;
+  const unsigned long long m = __ballot(true);
+  c->acc[2 * k] += 1ull;
+  if (__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)) == 0u) c->acc[2 * k + 1] += 1ull;
+}
+#ifdef AMBER_BVH_CLOCKS   /* the same sites as clocks: where a wave's time goes (tools/bvh_counters.py --clocks) */
+#define AMBER_COUNT(k)
+#define AMBER_CLK(k) do { if (stamp_ctx) StampAt(stamp_ctx, k); } while (0)
 #else
+#define AMBER_COUNT(k) CountAt(stamp_ctx, k)
+#define AMBER_CLK(k)
+#endif
+#define AMBER_STAMP_PARAM_OPT , StampCtx* stamp_ctx = nullptr
+#else
+#define AMBER_COUNT(k)
+#define AMBER_CLK(k)
+#define AMBER_STAMP_PARAM_OPT
 #define AMBER_STAMP_PARAM
 #define AMBER_STAMP_ARG
 #define AMBER_STAMP(k)
@@ -92,7 +111,7 @@ struct alignas(16) DevBvhNode {   // 64 B
 // profiles/r02_config3_memory_counters.txt), so bytes -- i.e. load instructions -- per visit are what counts.
 // The grid step is 1 / 65535 of the scene extent: 3e-5 of it, 0.3 % of the smallest sphere of config 3.
 struct alignas(16) DevBvhNodeQ {  // 32 B
-  uint32_t w[6];                  // 16-bit planes: L.min.x|L.min.y<<16, L.min.z|L.max.x<<16, L.max.y|L.max.z<<16, then the same for R
+  uint32_t w[6];                  // 16-bit planes, one word per axis: L.min.x|L.max.x<<16, L.y, L.z, R.x, R.y, R.z (a rotation by 16 swaps entry and exit)
   int32_t left, right;            // >= 0 inner node index; < 0 leaf: -(ref+1) = first*8 + all_spheres*4 + count (count <= 3)
 };
 // Light-tracing source record: one per DiffuseLight object, sorted by power (scene/light_set.h:61-82).
@@ -700,18 +719,16 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
 #ifndef AMBER_BVH_STACK
 #define AMBER_BVH_STACK 32
 #endif
-// Slab test of one child box from its six plane parameters t = (plane - o) / d, computed by the caller as one FMA per
-// plane (plane * inv - o * inv).  Culling only has to be conservative; the extra rounding of the FMA form is covered by
-// the slack and by the padded boxes: the entry is lowered and the exit raised by 2^-20 of their own magnitude plus
-// slack_abs (per ray, BvhBegin).  Axes the ray is parallel to arrive as NaN planes and min/max skip them.
-// NaN anywhere -> treated as a hit.  (Packed v_pk_fma_f32 evaluation of the planes was tried: 6 fewer VALU
-// instructions per node but two more live registers, 1.7 % slower at the kernel's register cap.)
-#define AMBER_BVH_REL_SLACK 9.5367431640625e-07f   /* 2^-20: rounding of the one-FMA plane parameters; 2^-16 costs 13 % on config 3 (the absolute part scales with |o/d|) */
-__device__ __forceinline__ void SlabDecide(float x0, float x1, float y0, float y1, float z0, float z1, float slack_abs, float t_best, bool& hit, float& t_in) {
-  float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
-  float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-  tn = __builtin_fmaf(tn, -AMBER_BVH_REL_SLACK, tn - slack_abs);            // tn >= 0
-  tf = __builtin_fmaf(Abs(tf), AMBER_BVH_REL_SLACK, tf + slack_abs);
+// Slab test of one child box.  The caller evaluates the six plane parameters t = (plane - o) / d as one FMA each
+// (q * A + B, BvhTrav) -- already sorted into the three ENTRY and the three EXIT planes of this ray (the sign of d decides
+// which of an axis' two planes is which, and a ray knows it once: BvhOperands), and already widened: the entry parameters
+// are lowered and the exit parameters raised by the ray's slack (rounding of the FMA form, direction-length drift), folded
+// into B.  So no per-axis min/max and no slack arithmetic is left here: 5 instructions per box instead of 15.
+// Culling only has to be conservative.  Axes the ray is parallel to arrive as NaN planes, which max3/min3 skip; the lower
+// clamp of the entry is -slack (the widened form of t >= 0), passed as neg_slack.  NaN anywhere -> treated as a hit.
+__device__ __forceinline__ void SlabDecide(float nx, float ny, float nz, float fx, float fy, float fz, float neg_slack, float t_best, bool& hit, float& t_in) {
+  const float tn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz, neg_slack));
+  const float tf = __builtin_fminf(__builtin_fminf(fx, fy), fz);
   t_in = tn;
   hit = !(tn > tf) && !(tn > t_best);
 }
@@ -729,17 +746,22 @@ __device__ __forceinline__ void ClosestHitLeafList(const DevScene& sc, V3 o, V3 
 // Traversal state of one ray.  It lives in registers (+ the lane's LDS stack) so that a traversal can be suspended
 // while other lanes of the wave are shaded (pt_bvh_megakernel) and resumed afterwards.
 // Slab parameter of a quantised plane q on axis c:  t = (gmin + q*step - o) / d  is evaluated as ONE fma, q * A + B, with
-// A = step / d and B = (gmin - o) / d per ray; the per-ray margin E that widens every box (direction-length drift, below)
-// lives in two B vectors: min planes use o + E, max planes o - E.
+// A = step / d and B = (gmin - o) / d per ray.  B exists twice: b_in for the plane the ray ENTERS the slab through (the min
+// plane if d > 0, the max plane otherwise), b_out for the other; everything that widens a box for this ray is folded in --
+// the margin E (direction-length drift, BvhOperands) and the slack of the t interval.  rot (0 or 16 per axis) rotates a
+// node word (min | max << 16) so that the entry plane sits in the low half.
 struct BvhTrav {
   V3 A;                // step / d
-  V3 b_mn, b_mx;       // (gmin - (o + E)) / d for the min planes, (gmin - (o - E)) / d for the max planes
-  float slack_abs;     // absolute widening of [t_in, t_out] for this ray (BvhOperands)
+  V3 b_in, b_out;      // entry planes: (gmin - o -+ E) / d - slack;  exit planes: ... + slack
+  uint32_t rot[3];     // 16 where d < 0
+  float neg_slack;     // -slack: lower clamp of the entry parameter
   int32_t cur;         // >= 0 inner node, < 0 leaf reference, AMBER_BVH_DONE finished
+  int32_t pend;        // postponed leaf reference (< 0), 0 = none (BvhRound)
   int sp;              // entries on the lane's stack
   bool overflow;       // the stack was too small (cannot happen with the builder's depth cap): fall back to the list scan
 };
 #define AMBER_BVH_DONE 0x7fffffff
+#define AMBER_BVH_REL_SLACK 9.5367431640625e-07f   /* 2^-20 */
 
 // Slab-test operands of a ray.
 __device__ __forceinline__ void BvhOperands(const DevScene& sc, V3 o, V3 d, BvhTrav& tr) {
@@ -768,7 +790,8 @@ __device__ __forceinline__ void BvhOperands(const DevScene& sc, V3 o, V3 d, BvhT
   V3 bmn = v3((sc.bvh_gmin[0] - (o.x + E)) * inv.x, (sc.bvh_gmin[1] - (o.y + E)) * inv.y, (sc.bvh_gmin[2] - (o.z + E)) * inv.z);
   V3 bmx = v3((sc.bvh_gmin[0] - (o.x - E)) * inv.x, (sc.bvh_gmin[1] - (o.y - E)) * inv.y, (sc.bvh_gmin[2] - (o.z - E)) * inv.z);
   // Rounding of q * A + B: A and B carry three roundings each and the fma one more -- at most 2^-22 of
-  // (|gmin - o| + E + scene extent) / |d| on the axis; the slack takes 2^-20 of that (per ray, max over the axes).
+  // (|gmin - o| + E + scene extent) / |d| on the axis, which also bounds |t| of every plane of the axis; the slack takes
+  // 2^-20 of that (per ray, max over the axes).  2^-16 costs 13 % on config 3: the term scales with |o / d|.
   V3 mg = v3((Abs(sc.bvh_gmin[0] - o.x) + E + sc.bvh_reach[0]) * Abs(inv.x), (Abs(sc.bvh_gmin[1] - o.y) + E + sc.bvh_reach[1]) * Abs(inv.y),
              (Abs(sc.bvh_gmin[2] - o.z) + E + sc.bvh_reach[2]) * Abs(inv.z));
   // An axis whose operands are not finite (d component 0 or denormal, huge origin) is taken OUT of the slab test by making
@@ -781,8 +804,15 @@ __device__ __forceinline__ void BvhOperands(const DevScene& sc, V3 o, V3 d, BvhT
   if (!(Abs(A.z) < 3.0e38f) || !(Abs(bmn.z) < 3.0e38f) || !(Abs(bmx.z) < 3.0e38f) || !(mg.z < 3.0e38f)) { A.z = kNaN; bmn.z = kNaN; bmx.z = kNaN; mg.z = kNaN; }
   float mag = __builtin_fmaxf(__builtin_fmaxf(mg.x, mg.y), mg.z);                     // fmax skips the NaN axes
   if (!(mag == mag)) mag = 0.0f;                                                      // no axis takes part
-  tr.slack_abs = AMBER_BVH_REL_SLACK * mag + slack_len;
-  tr.A = A; tr.b_mn = bmn; tr.b_mx = bmx;
+  const float slack = AMBER_BVH_REL_SLACK * mag + slack_len;
+  // The subtraction / addition of the slack rounds once more, by at most half an ulp of B +- slack <= 2^-24 * 2 mag: inside
+  // the 2^-20 - 2^-22 of mag the slack has to spare.
+  const bool nx = A.x < 0.0f, ny = A.y < 0.0f, nz = A.z < 0.0f;                       // NaN axes: either order, the planes are NaN
+  tr.b_in = v3((nx ? bmx.x : bmn.x) - slack, (ny ? bmx.y : bmn.y) - slack, (nz ? bmx.z : bmn.z) - slack);
+  tr.b_out = v3((nx ? bmn.x : bmx.x) + slack, (ny ? bmn.y : bmx.y) + slack, (nz ? bmn.z : bmx.z) + slack);
+  tr.rot[0] = nx ? 16u : 0u; tr.rot[1] = ny ? 16u : 0u; tr.rot[2] = nz ? 16u : 0u;
+  tr.neg_slack = -slack;
+  tr.A = A;
 }
 
 __device__ __forceinline__ void BvhBegin(const DevScene& sc, V3 o, V3 d, BvhTrav& tr, HitRec& best) {
@@ -791,7 +821,7 @@ __device__ __forceinline__ void BvhBegin(const DevScene& sc, V3 o, V3 d, BvhTrav
   // A ray with a NaN component cannot hit anything: every exact test forms dot products over all components of o and
   // d, so every t it computes is NaN, and Closer() never accepts a NaN t (the List scan returns "no hit" too).
   const bool nan_ray = !(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z);
-  tr.cur = nan_ray ? AMBER_BVH_DONE : sc.bvh_root; tr.sp = 0; tr.overflow = false;
+  tr.cur = nan_ray ? AMBER_BVH_DONE : sc.bvh_root; tr.pend = 0; tr.sp = 0; tr.overflow = false;
 }
 
 // primitive_sphere.cc:75-107 from the compact (centre, radius) record: the same operations as IntersectSphere; the object
@@ -812,35 +842,50 @@ __device__ __forceinline__ void IntersectSphereLeaf(const DevScene& sc, float4 s
   }
 }
 
-// One round for this lane: descend through at most AMBER_BVH_DESCENT_BUDGET inner nodes; if that reached a leaf, test
-// its objects exactly and pop the next subtree.  Returns false when the traversal is complete.  Unbounded descent
-// ("while-while") makes every lane that already holds a leaf wait for the slowest descent of the wave, one node per
-// round ("if-if") interleaves the expensive exact tests with other lanes' box tests; config 3 at 128 spp (round 1's
-// 64-byte nodes): budget 2 -> 195 ms, 3 -> 175, 4 -> 169, 5 -> 164, 6 -> 165, 8 -> 173, unbounded -> 189.
+// A traversal advances in rounds of two phases.
+// N-phase (BvhDescend, per lane): descend through at most AMBER_BVH_DESCENT_BUDGET inner nodes.  A leaf reached while the
+// lane has none set aside is POSTPONED (tr.pend) and the walk goes on with the next subtree from the stack; a second leaf
+// stops the lane.
+// S-phase: the postponed leaves' objects get their exact tests -- once the wave has collected enough of them, or nobody can
+// descend any more -- so that the expensive tests run with many lanes (counters of the undeferred form, 1M spheres: 8.0
+// sphere tests per ray with 21 % of the lanes, 29.4 node visits with 46 %).  Postponing never changes the result: culling
+// against a larger best.t is still conservative and the (t, index) rule makes the closest hit independent of the order.
+// Unbounded descent ("while-while") makes every stopped lane wait for the slowest descent of the wave, one node per round
+// ("if-if") interleaves too finely; round 1, 64-byte nodes, config 3 at 128 spp: budget 2 -> 195 ms, 3 -> 175, 4 -> 169,
+// 5 -> 164, 6 -> 165, 8 -> 173, unbounded -> 189.
 #ifndef AMBER_BVH_DESCENT_BUDGET
 #define AMBER_BVH_DESCENT_BUDGET 5
 #endif
-__device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, BvhTrav& tr, HitRec& best, const int stack_cap = AMBER_BVH_STACK) {
+__device__ __forceinline__ void BvhDescend(const DevScene& sc, int32_t* lds_stack, BvhTrav& tr, const float t_best, const int stack_cap AMBER_STAMP_PARAM_OPT) {
   int32_t* stack = lds_stack + threadIdx.x;          // element k at stack[k * blockDim.x]
   const uint32_t stride = 256u;                      // every kernel that traverses is launched with 256 threads
-  int32_t cur = tr.cur;
+  int32_t cur = tr.cur, pend = tr.pend;
   int sp = tr.sp;
+  AMBER_CLK(4);
+#define AMBER_BVH_PARK() \
+  if (cur < 0 && pend == 0) { pend = cur; if (sp > 0) { --sp; cur = stack[sp * stride]; } else cur = AMBER_BVH_DONE; }
+  AMBER_BVH_PARK();
   int budget = AMBER_BVH_DESCENT_BUDGET;
   while (cur >= 0 && cur != AMBER_BVH_DONE && budget-- > 0) {
+    AMBER_COUNT(0);
     const uint4* nd = reinterpret_cast<const uint4*>(sc.bvh_nodes + cur);
     const uint4 p = nd[0], q = nd[1];
     const int32_t left = static_cast<int32_t>(q.z), right = static_cast<int32_t>(q.w);
+    // rotate each axis word so that the entry plane is the low half, convert (v_cvt_f32_u32 with a half-word select), one fma
+#define AMBER_ROT(wd, c) __builtin_amdgcn_alignbit((wd), (wd), tr.rot[c])
 #define AMBER_QLO(wd) static_cast<float>((wd) & 0xffffu)
 #define AMBER_QHI(wd) static_cast<float>((wd) >> 16)
-    const float lx0 = __builtin_fmaf(AMBER_QLO(p.x), tr.A.x, tr.b_mn.x), ly0 = __builtin_fmaf(AMBER_QHI(p.x), tr.A.y, tr.b_mn.y), lz0 = __builtin_fmaf(AMBER_QLO(p.y), tr.A.z, tr.b_mn.z);
-    const float lx1 = __builtin_fmaf(AMBER_QHI(p.y), tr.A.x, tr.b_mx.x), ly1 = __builtin_fmaf(AMBER_QLO(p.z), tr.A.y, tr.b_mx.y), lz1 = __builtin_fmaf(AMBER_QHI(p.z), tr.A.z, tr.b_mx.z);
-    const float rx0 = __builtin_fmaf(AMBER_QLO(p.w), tr.A.x, tr.b_mn.x), ry0 = __builtin_fmaf(AMBER_QHI(p.w), tr.A.y, tr.b_mn.y), rz0 = __builtin_fmaf(AMBER_QLO(q.x), tr.A.z, tr.b_mn.z);
-    const float rx1 = __builtin_fmaf(AMBER_QHI(q.x), tr.A.x, tr.b_mx.x), ry1 = __builtin_fmaf(AMBER_QLO(q.y), tr.A.y, tr.b_mx.y), rz1 = __builtin_fmaf(AMBER_QHI(q.y), tr.A.z, tr.b_mx.z);
+    const uint32_t wlx = AMBER_ROT(p.x, 0), wly = AMBER_ROT(p.y, 1), wlz = AMBER_ROT(p.z, 2), wrx = AMBER_ROT(p.w, 0), wry = AMBER_ROT(q.x, 1), wrz = AMBER_ROT(q.y, 2);
+    const float lnx = __builtin_fmaf(AMBER_QLO(wlx), tr.A.x, tr.b_in.x), lny = __builtin_fmaf(AMBER_QLO(wly), tr.A.y, tr.b_in.y), lnz = __builtin_fmaf(AMBER_QLO(wlz), tr.A.z, tr.b_in.z);
+    const float lfx = __builtin_fmaf(AMBER_QHI(wlx), tr.A.x, tr.b_out.x), lfy = __builtin_fmaf(AMBER_QHI(wly), tr.A.y, tr.b_out.y), lfz = __builtin_fmaf(AMBER_QHI(wlz), tr.A.z, tr.b_out.z);
+    const float rnx = __builtin_fmaf(AMBER_QLO(wrx), tr.A.x, tr.b_in.x), rny = __builtin_fmaf(AMBER_QLO(wry), tr.A.y, tr.b_in.y), rnz = __builtin_fmaf(AMBER_QLO(wrz), tr.A.z, tr.b_in.z);
+    const float rfx = __builtin_fmaf(AMBER_QHI(wrx), tr.A.x, tr.b_out.x), rfy = __builtin_fmaf(AMBER_QHI(wry), tr.A.y, tr.b_out.y), rfz = __builtin_fmaf(AMBER_QHI(wrz), tr.A.z, tr.b_out.z);
+#undef AMBER_ROT
 #undef AMBER_QLO
 #undef AMBER_QHI
     bool hl, hr; float tl, tr_;
-    SlabDecide(lx0, lx1, ly0, ly1, lz0, lz1, tr.slack_abs, best.t, hl, tl);
-    SlabDecide(rx0, rx1, ry0, ry1, rz0, rz1, tr.slack_abs, best.t, hr, tr_);
+    SlabDecide(lnx, lny, lnz, lfx, lfy, lfz, tr.neg_slack, t_best, hl, tl);
+    SlabDecide(rnx, rny, rnz, rfx, rfy, rfz, tr.neg_slack, t_best, hr, tr_);
     if (hl && hr) {
       const bool left_first = !(tr_ < tl);
       const int32_t near_ = left_first ? left : right, far_ = left_first ? right : left;
@@ -856,26 +901,46 @@ __device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack,
     } else {
       cur = AMBER_BVH_DONE;
     }
+    AMBER_BVH_PARK();
   }
-  bool more = false;
-  if (cur >= 0 && cur != AMBER_BVH_DONE) more = true;   // budget used up: keep descending next round
-  else if (cur != AMBER_BVH_DONE) {                         // cur < 0: a leaf
-    const uint32_t ref = static_cast<uint32_t>(-(cur + 1));
-    const uint32_t first = ref >> 3, count = ref & 3u;
-    if (ref & 4u) {                                         // spheres only: one 16-byte record each
-      for (uint32_t k = 0; k < count; ++k) IntersectSphereLeaf(sc, sc.bvh_spheres[first + k], first + k, o, d, best);
-    } else {
-      for (uint32_t k = 0; k < count; ++k) {
-        const uint32_t oi = sc.bvh_prims[first + k];                 // scene index (tie rule, reported hit); independent of ...
-        const DevObject& ob = sc.bvh_objects[first + k];             // ... the record itself, stored in leaf order: no dependent load
-        IntersectObject<true>(ob, ob.kind, static_cast<int>(oi), static_cast<int>(first + k), o, d, best);
-      }
+#undef AMBER_BVH_PARK
+  AMBER_CLK(2);
+  tr.cur = cur; tr.sp = sp; tr.pend = pend;
+}
+
+// Exact tests of one leaf by the lane that owns the ray.
+__device__ __forceinline__ void BvhLeafPrivate(const DevScene& sc, int32_t leaf, V3 o, V3 d, HitRec& best AMBER_STAMP_PARAM_OPT) {
+  const uint32_t ref = static_cast<uint32_t>(-(leaf + 1));
+  const uint32_t first = ref >> 3, count = ref & 3u;
+  if (ref & 4u) {                                           // spheres only: one 16-byte record each
+    for (uint32_t k = 0; k < count; ++k) { AMBER_COUNT(1); IntersectSphereLeaf(sc, sc.bvh_spheres[first + k], first + k, o, d, best); }
+  } else {
+    for (uint32_t k = 0; k < count; ++k) {
+      const uint32_t oi = sc.bvh_prims[first + k];                 // scene index (tie rule, reported hit); independent of ...
+      const DevObject& ob = sc.bvh_objects[first + k];             // ... the record itself, stored in leaf order: no dependent load
+      IntersectObject<true>(ob, ob.kind, static_cast<int>(oi), static_cast<int>(first + k), o, d, best);
     }
-    if (sp > 0) { --sp; cur = stack[sp * stride]; more = true; }
-    else cur = AMBER_BVH_DONE;
   }
-  tr.cur = cur; tr.sp = sp;
-  return more;
+}
+
+// S-phase: the postponed leaves are tested once a third of the lanes still traversing hold one, or nobody can descend
+// (config 3 at 128 spp: no postponing 142.3 ms; 1/1 168.7, 3/4 146.8, 1/2 140.4, 1/3 137.5, 1/4 138.8, 1/6 140.5).
+// (Tried: dealing the collected sphere tests out one per lane through ds_bpermute, every lane of the wave working -- 13
+// trips with 68 % of the lanes instead of 29 with 30 %, but 160 ms: the longer dependent chain per round costs more.)
+__device__ __forceinline__ void BvhLeafPhase(const DevScene& sc, V3 o, V3 d, BvhTrav& tr, HitRec& best AMBER_STAMP_PARAM_OPT) {
+  const bool has_pend = tr.pend != 0;
+  const uint32_t n_lanes = static_cast<uint32_t>(__popcll(__ballot(true)));
+  const uint32_t n_pend = static_cast<uint32_t>(__popcll(__ballot(has_pend)));
+  const bool nobody_descends = __ballot(tr.cur >= 0 && tr.cur != AMBER_BVH_DONE) == 0ull;
+  if (has_pend && (n_pend * 3u >= n_lanes || nobody_descends)) { BvhLeafPrivate(sc, tr.pend, o, d, best AMBER_STAMP_ARG); tr.pend = 0; }
+  AMBER_CLK(3);
+}
+
+// One round for a lane on its own; returns false when the traversal is complete.
+__device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, BvhTrav& tr, HitRec& best, const int stack_cap = AMBER_BVH_STACK AMBER_STAMP_PARAM_OPT) {
+  BvhDescend(sc, lds_stack, tr, best.t, stack_cap AMBER_STAMP_ARG);
+  BvhLeafPhase(sc, o, d, tr, best AMBER_STAMP_ARG);
+  return tr.cur != AMBER_BVH_DONE || tr.pend != 0;
 }
 
 __device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, HitRec& best) {

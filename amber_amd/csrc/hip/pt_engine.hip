@@ -279,11 +279,15 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? 5 : 4) pt_bvh_megakernel(c
   uint32_t casts = 0;
   uint32_t rays_wave = 0;                                   // wave-uniform (SGPR): rays shaded by this wave
   int origin_slot = -1;
-  BvhTrav tr; tr.A = v3(0.f, 0.f, 0.f); tr.b_mn = v3(0.f, 0.f, 0.f); tr.b_mx = v3(0.f, 0.f, 0.f); tr.slack_abs = 0.f;
-  tr.cur = AMBER_BVH_DONE; tr.sp = 0; tr.overflow = false;
+  BvhTrav tr; tr.A = v3(0.f, 0.f, 0.f); tr.b_in = v3(0.f, 0.f, 0.f); tr.b_out = v3(0.f, 0.f, 0.f); tr.neg_slack = 0.f; tr.rot[0] = tr.rot[1] = tr.rot[2] = 0u;
+  tr.cur = AMBER_BVH_DONE; tr.pend = 0; tr.sp = 0; tr.overflow = false;
   HitRec hit; hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.idx = -1; hit.slot = -1;
 #ifdef AMBER_STAMPS
-  StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
+  StampCtx stamp_store{}, stamp_shade{}; StampCtx* stamp_ctx = &stamp_store;     // counters here; PathShade's clocks go to a dummy
+#define AMBER_SHADE_STAMP_ARG , &stamp_shade
+  stamp_ctx->last = __builtin_amdgcn_s_memtime();
+#else
+#define AMBER_SHADE_STAMP_ARG
 #endif
 
   for (;;) {
@@ -332,7 +336,9 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? 5 : 4) pt_bvh_megakernel(c
     if (need) lane_done = true;
     if (__ballot(!lane_done) == 0ull) break;
 
+    AMBER_CLK(0);
     if (!alive && !lane_done) {                             // regenerate: next sample of the item, start its traversal
+      AMBER_COUNT(3);
       rng = XorShiftSeed(a.hashed_seed, pixel, s);
       if (kLight) {
         GenerateLightRay(sc, rng, o, d, w, origin_slot);
@@ -350,29 +356,41 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? 5 : 4) pt_bvh_megakernel(c
       traversing = true;
     }
 
+    AMBER_CLK(1);
     for (;;) {                                              // traversal rounds until a batch of lanes is ready to shade
       const unsigned long long tm = __ballot(traversing);
       if (tm == 0ull) break;
       if (__popcll(__ballot(alive && !traversing)) >= AMBER_BVH_SHADE_BATCH) break;
       if (traversing) {
-        traversing = BvhRound(sc, lds_stack, o, d, tr, hit, kStack);
+        AMBER_COUNT(2);
+        traversing = BvhRound(sc, lds_stack, o, d, tr, hit, kStack AMBER_STAMP_ARG);
         if (!traversing && tr.overflow) ClosestHitLeafList(sc, o, d, hit);
       }
     }
 
+    AMBER_CLK(6);
     rays_wave += static_cast<uint32_t>(__popcll(__ballot(alive && !traversing)));
     if (alive && !traversing) {                             // shade the lanes whose closest hit is known
       if (kLight) {
         const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, pixel, s - 1u, sc.sensor.size_f};
-        alive = PathShade<false, ENGINE_BVH, true>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, &sink);
+        alive = PathShade<false, ENGINE_BVH, true>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_SHADE_STAMP_ARG, &sink);
       } else {
-        alive = PathShade<false, ENGINE_BVH, false>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, nullptr);
+        alive = PathShade<false, ENGINE_BVH, false>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_SHADE_STAMP_ARG, nullptr);
       }
       if (alive) { BvhBegin(sc, o, d, tr, hit); traversing = true; }
       else sum = sum + meas;                                // sequential sum over the item's samples
     }
+    AMBER_CLK(5);
   }
 
+#undef AMBER_SHADE_STAMP_ARG
+#ifdef AMBER_STAMPS
+#ifdef AMBER_BVH_CLOCKS
+  if (a.stamps) for (int k = 0; k < 8; k++) atomicAdd(a.stamps + k, stamp_ctx->acc[k] >> 6);      // lane-time / 64
+#else
+  if (a.stamps) for (int k = 0; k < 8; k++) if (stamp_ctx->acc[k]) atomicAdd(a.stamps + k, stamp_ctx->acc[k]);
+#endif
+#endif
   if (lane == 0 && rays_wave) atomicAdd(a.ray_count, static_cast<unsigned long long>(rays_wave));
 }
 

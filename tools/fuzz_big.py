@@ -1,15 +1,18 @@
 """Large random soups (tens of thousands of triangles, spheres, disks, cylinders): engine BVH (parallel build, deep tree)
-against engine LIST, bit for bit.   python tools/fuzz_big.py [n_scenes] [n_objects]"""
+against engine LIST, bit for bit.   python tools/fuzz_big.py [n_scenes] [n_objects] [sphere share]
+(a sphere share near 1 makes most leaves all-sphere leaves: the wave-cooperative leaf phase)"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
 import amber_amd as A
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n_obj = int(sys.argv[2]) if len(sys.argv) > 2 else 80000
+p_sphere = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0 / 6.0
 W, H, spp = 64, 48, 4
 for seed in range(n_scenes):
     rng = np.random.default_rng(1000 + seed)
-    kinds = rng.choice([0, 0, 0, 1, 2, 3], n_obj).astype(np.uint32)
+    q = (1.0 - p_sphere) / 5.0
+    kinds = rng.choice([0, 1, 2, 3], n_obj, p=[3 * q, p_sphere, q, q]).astype(np.uint32)
     params = np.zeros((n_obj, 12), np.float32)
     c = rng.uniform(-1, 1, (n_obj, 3)) * rng.choice([1.0, 1.0, 30.0], (n_obj, 1))          # a third of the objects far out: deep, unbalanced tree
     size = (10.0 ** rng.uniform(-3, -0.5, n_obj))
