@@ -824,20 +824,40 @@ __device__ __forceinline__ void BvhBegin(const DevScene& sc, V3 o, V3 d, BvhTrav
   tr.cur = nan_ray ? AMBER_BVH_DONE : sc.bvh_root; tr.pend = 0; tr.sp = 0; tr.overflow = false;
 }
 
-// primitive_sphere.cc:75-107 from the compact (centre, radius) record: the same operations as IntersectSphere; the object
-// index (tie rule, reported hit) is fetched only when the distance can win.
-__device__ __forceinline__ void IntersectSphereLeaf(const DevScene& sc, float4 s, uint32_t slot, V3 o, V3 d, HitRec& best) {
+// primitive_sphere.cc:75-107 from the compact (centre, radius) records of a leaf of 1..3 spheres, in two stages.
+// Stage 1, all spheres of the leaf (loads issued together): the coefficients b, c and the sign of the discriminant -- 20
+// instructions each.  Stage 2, only for the spheres whose discriminant is not negative (a third of them on config 3): the
+// roots -- a square root and two divisions, 50 instructions -- the reference's choice of the root and the (t, index) rule;
+// the object index (tie rule, reported hit) is fetched only when the distance can win.  A lane runs stage 2 once per
+// surviving sphere, so a wave makes as many trips through it as its worst lane has survivors (mostly one) instead of one
+// per sphere of the leaf.  The operations on each sphere are those of IntersectSphere; only their grouping differs.
+__device__ __forceinline__ void SphereCoefficients(float4 s, V3 o, V3 d, float& b, float& c) {
   const V3 co = v3(s.x, s.y, s.z) - o;
-  const float b = -2.0f * Dot(co, d);
-  const float c = SquaredLength(co) - s.w * s.w;
-  float alpha, beta;
-  if (SolveQuadratic(1.0f, b, c, alpha, beta)) {
-    float t;
-    bool ok = true;
-    if (alpha > AMBER_KEPS) t = alpha; else if (beta > AMBER_KEPS) t = beta; else { ok = false; t = 0.f; }
-    if (ok && IsFinite(t) && !(t > best.t)) {
-      const int i = static_cast<int>(sc.bvh_prims[slot]);
-      if (Closer<true>(t, i, best)) { best.t = t; best.idx = i; best.slot = static_cast<int>(slot); }
+  b = -2.0f * Dot(co, d);
+  c = SquaredLength(co) - s.w * s.w;
+}
+__device__ __forceinline__ void IntersectSphereLeaf(const DevScene& sc, uint32_t first, uint32_t count, V3 o, V3 d, HitRec& best AMBER_STAMP_PARAM_OPT) {
+  const float4* sp = sc.bvh_spheres + first;
+  const float4 s0 = sp[0], s1 = sp[count > 1u ? 1u : 0u], s2 = sp[count > 2u ? 2u : 0u];
+  float b0, c0, b1, c1, b2, c2;
+  SphereCoefficients(s0, o, d, b0, c0); SphereCoefficients(s1, o, d, b1, c1); SphereCoefficients(s2, o, d, b2, c2);
+  // algebra.h:33-34: "if (d < 0) return false" -- a NaN discriminant goes on (and ends as a NaN distance, which no hit accepts)
+  uint32_t todo = (!(b0 * b0 - 4.0f * 1.0f * c0 < 0.0f) ? 1u : 0u) | (count > 1u && !(b1 * b1 - 4.0f * 1.0f * c1 < 0.0f) ? 2u : 0u) |
+                  (count > 2u && !(b2 * b2 - 4.0f * 1.0f * c2 < 0.0f) ? 4u : 0u);
+  while (todo) {
+    AMBER_COUNT(1);
+    const uint32_t k = (todo & 1u) ? 0u : ((todo & 2u) ? 1u : 2u);
+    todo &= todo - 1u;
+    const float b = k == 0u ? b0 : (k == 1u ? b1 : b2), c = k == 0u ? c0 : (k == 1u ? c1 : c2);
+    float alpha, beta;
+    if (SolveQuadratic(1.0f, b, c, alpha, beta)) {
+      float t;
+      bool ok = true;
+      if (alpha > AMBER_KEPS) t = alpha; else if (beta > AMBER_KEPS) t = beta; else { ok = false; t = 0.f; }
+      if (ok && IsFinite(t) && !(t > best.t)) {
+        const int i = static_cast<int>(sc.bvh_prims[first + k]);
+        if (Closer<true>(t, i, best)) { best.t = t; best.idx = i; best.slot = static_cast<int>(first + k); }
+      }
     }
   }
 }
@@ -913,7 +933,7 @@ __device__ __forceinline__ void BvhLeafPrivate(const DevScene& sc, int32_t leaf,
   const uint32_t ref = static_cast<uint32_t>(-(leaf + 1));
   const uint32_t first = ref >> 3, count = ref & 3u;
   if (ref & 4u) {                                           // spheres only: one 16-byte record each
-    for (uint32_t k = 0; k < count; ++k) { AMBER_COUNT(1); IntersectSphereLeaf(sc, sc.bvh_spheres[first + k], first + k, o, d, best); }
+    IntersectSphereLeaf(sc, first, count, o, d, best AMBER_STAMP_ARG);
   } else {
     for (uint32_t k = 0; k < count; ++k) {
       const uint32_t oi = sc.bvh_prims[first + k];                 // scene index (tie rule, reported hit); independent of ...
