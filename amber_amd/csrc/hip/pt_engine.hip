@@ -263,8 +263,11 @@ __global__ void reduce_flagged_kernel(float* __restrict__ fb, const uint32_t* __
 #endif
 // kStack: entries of the per-lane LDS stack (chosen from the tree depth at create time).  24 entries = 24 KB per
 // workgroup let 5 workgroups share a CU (96 VGPRs), 32 entries only 4: config 3, 128 spp: 193 vs 208 ms.
+#ifndef AMBER_BVH_WGS
+#define AMBER_BVH_WGS 5
+#endif
 template <bool kLight, int kStack>
-__global__ void __launch_bounds__(256, kStack <= 24 ? 5 : 4) pt_bvh_megakernel(const RenderArgs a) {
+__global__ void __launch_bounds__(256, kStack <= 24 ? AMBER_BVH_WGS : 4) pt_bvh_megakernel(const RenderArgs a) {
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
   __shared__ int32_t lds_stack[kStack * 256];
@@ -915,7 +918,7 @@ namespace {
 // Workgroups of the persistent kernels that fit a CU at once: pt_bvh_megakernel is bounded by its LDS traversal stacks
 // and VGPRs (5 with 24-entry stacks, else 4); the others are capped to AMBER_MEGAKERNEL_WAVES_PER_SIMD by their launch bounds.
 uint32_t ResidentBlocksPerCu(uint32_t hit_engine, uint32_t bvh_depth) {
-  return hit_engine == AMBER_ENGINE_BVH ? (bvh_depth <= 24 ? 5u : 4u) : (AMBER_MEGAKERNEL_WAVES_PER_SIMD > 5 ? static_cast<uint32_t>(AMBER_MEGAKERNEL_WAVES_PER_SIMD) : 5u);   // uncapped: 87 VGPRs -> 5
+  return hit_engine == AMBER_ENGINE_BVH ? (bvh_depth <= 24 ? static_cast<uint32_t>(AMBER_BVH_WGS) : 4u) : (AMBER_MEGAKERNEL_WAVES_PER_SIMD > 5 ? static_cast<uint32_t>(AMBER_MEGAKERNEL_WAVES_PER_SIMD) : 5u);   // uncapped: 87 VGPRs -> 5
 }
 
 // Engine WAVEFRONT host loop: batches of <= max_chunks accumulation chunks; per batch generate, then bounce launches
