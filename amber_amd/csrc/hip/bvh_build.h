@@ -29,6 +29,7 @@ namespace amber_bvh {
 
 using amber_dev::DevBvhNode;
 using amber_dev::DevBvhNodeQ;
+using amber_dev::DevBvhNodeQ4;
 using amber_dev::DevObject;
 
 #ifndef AMBER_BVH_LEAF_SIZE
@@ -282,6 +283,72 @@ inline QuantizedBvh QuantizeBvh(const std::vector<DevBvhNode>& bin, int32_t root
       for (int c = 0; c < 3; c++) q.w[3 * side + c] = uint32_t(ql[side][c]) | (uint32_t(qh[side][c]) << 16);   // one word per axis: min | max << 16
     q.left = QuantizedLeafRef(nd.left, is_sphere_slot);
     q.right = QuantizedLeafRef(nd.right, is_sphere_slot);
+  }
+  return out;
+}
+
+// AMBER_BVH_WIDE builds: the 2-wide tree collapsed to 4-wide nodes on the grid of `grid` (QuantizeBvh's result for the same
+// tree).  A node takes the two children of its 2-wide node and, while it has room, replaces the inner child with the
+// largest surface by that child's two children.  Absent children: reference -1 (a leaf of no objects), inverted box.
+struct QuantizedBvh4 {
+  std::vector<amber_dev::DevBvhNodeQ4> nodes;
+  int32_t root_ref = -1;
+  uint32_t depth = 0;
+};
+template <typename IsSphere>
+inline QuantizedBvh4 CollapseBvh4(const std::vector<DevBvhNode>& bin, int32_t root_ref, const QuantizedBvh& grid, IsSphere is_sphere_slot) {
+  QuantizedBvh4 out;
+  out.root_ref = QuantizedLeafRef(root_ref, is_sphere_slot);
+  if (bin.empty() || root_ref < 0) return out;
+  struct Kid { int32_t ref; float mn[3], mx[3]; };
+  auto kids_of = [&](int32_t node, Kid k[2]) {
+    const DevBvhNode& nd = bin[node];
+    for (int side = 0; side < 2; side++) {
+      const float* xy = side ? nd.rxy : nd.lxy;
+      k[side].ref = side ? nd.right : nd.left;
+      k[side].mn[0] = xy[0]; k[side].mn[1] = xy[1]; k[side].mx[0] = xy[2]; k[side].mx[1] = xy[3];
+      k[side].mn[2] = nd.z[side ? 2 : 0]; k[side].mx[2] = nd.z[side ? 3 : 1];
+    }
+  };
+  auto area = [](const Kid& k) { const double x = double(k.mx[0]) - k.mn[0], y = double(k.mx[1]) - k.mn[1], z = double(k.mx[2]) - k.mn[2]; return x * y + y * z + z * x; };
+  struct Job { int32_t node2; uint32_t me; uint32_t depth; };
+  std::vector<Job> todo;
+  out.nodes.emplace_back();
+  todo.push_back(Job{root_ref, 0u, 1u});
+  out.root_ref = 0;
+  while (!todo.empty()) {
+    const Job job = todo.back(); todo.pop_back();
+    out.depth = std::max(out.depth, job.depth);
+    Kid kid[4]; int n = 2;
+    kids_of(job.node2, kid);
+    while (n < 4) {
+      int best = -1; double best_area = -1;
+      for (int i = 0; i < n; i++) if (kid[i].ref >= 0 && area(kid[i]) > best_area) { best_area = area(kid[i]); best = i; }
+      if (best < 0) break;
+      Kid two[2]; kids_of(kid[best].ref, two);
+      kid[best] = two[0]; kid[n++] = two[1];
+    }
+    amber_dev::DevBvhNodeQ4 q;
+    for (int i = 0; i < 4; i++) {
+      if (i >= n) { for (int c = 0; c < 3; c++) q.w[3 * i + c] = 0x0000ffffu; q.child[i] = -1; continue; }    // min 65535, max 0
+      for (int c = 0; c < 3; c++) {
+        const double g = grid.gmin[c], st = grid.step[c];
+        double a = std::floor((double(kid[i].mn[c]) - g) / st), b = std::ceil((double(kid[i].mx[c]) - g) / st);
+        a = std::min(65535.0, std::max(0.0, a)); b = std::min(65535.0, std::max(0.0, b));
+        while (a > 0 && g + a * st > kid[i].mn[c]) a -= 1;
+        while (b < 65535 && g + b * st < kid[i].mx[c]) b += 1;
+        q.w[3 * i + c] = uint32_t(a) | (uint32_t(b) << 16);
+      }
+      if (kid[i].ref >= 0) {
+        const uint32_t idx = static_cast<uint32_t>(out.nodes.size());
+        out.nodes.emplace_back();
+        todo.push_back(Job{kid[i].ref, idx, job.depth + 1});
+        q.child[i] = static_cast<int32_t>(idx);
+      } else {
+        q.child[i] = QuantizedLeafRef(kid[i].ref, is_sphere_slot);
+      }
+    }
+    out.nodes[job.me] = q;
   }
   return out;
 }

@@ -114,6 +114,16 @@ struct alignas(16) DevBvhNodeQ {  // 32 B
   uint32_t w[6];                  // 16-bit planes, one word per axis: L.min.x|L.max.x<<16, L.y, L.z, R.x, R.y, R.z (a rotation by 16 swaps entry and exit)
   int32_t left, right;            // >= 0 inner node index; < 0 leaf: -(ref+1) = first*8 + all_spheres*4 + count (count <= 3)
 };
+// AMBER_BVH_WIDE builds (measurement: VERDICT r01 item 4 asked for a 4-wide tree): the 2-wide tree collapsed to up to four
+// children per node, boxes on the same grid, 64 bytes = four 16-byte loads per visit.  An absent child has the reference
+// -1 (a leaf of zero objects) and an inverted box.
+struct alignas(16) DevBvhNodeQ4 {  // 64 B
+  uint32_t w[12];                  // child k, axis a: w[3k + a] = min | max << 16
+  int32_t child[4];
+};
+#ifndef AMBER_BVH_WIDE
+#define AMBER_BVH_WIDE 0
+#endif
 // Light-tracing source record: one per DiffuseLight object, sorted by power (scene/light_set.h:61-82).
 struct alignas(16) DevLight {     // 96 B
   uint32_t kind; int32_t slot;      // primitive kind ; filter-program slot of a light triangle (-1 otherwise)
@@ -155,6 +165,7 @@ struct DevScene {
   uint32_t n_prog_tris;        // program slots [0, n_prog_tris) are filtered triangles, then spheres, then the rest
   const DevObject* __restrict__ prog_objects;   // objects in program order, kind |= scene index << 8 (staged to LDS)
   const DevBvhNodeQ* __restrict__ bvh_nodes;    // engine BVH: quantised 2-wide nodes
+  const DevBvhNodeQ4* __restrict__ bvh_nodes4;  // AMBER_BVH_WIDE builds: the collapsed 4-wide nodes (else null)
   float bvh_gmin[3], bvh_step[3];               // quantisation grid: plane = bvh_gmin + q * bvh_step
   float bvh_reach[3];                           // max(|bounds_min - x|, |bounds_max - x|) over x in the bounds, per axis = extent (slab rounding slack)
   const float4* __restrict__ bvh_spheres;       // (centre, radius) of every object in leaf order (zeros for non-spheres): leaves of spheres only test from here
@@ -888,6 +899,42 @@ __device__ __forceinline__ void BvhDescend(const DevScene& sc, int32_t* lds_stac
   int budget = AMBER_BVH_DESCENT_BUDGET;
   while (cur >= 0 && cur != AMBER_BVH_DONE && budget-- > 0) {
     AMBER_COUNT(0);
+#if AMBER_BVH_WIDE
+    const uint4* nd = reinterpret_cast<const uint4*>(sc.bvh_nodes4 + cur);
+    const uint4 p0 = nd[0], p1 = nd[1], p2 = nd[2], cr = nd[3];
+#define AMBER_ROT(wd, c) __builtin_amdgcn_alignbit((wd), (wd), tr.rot[c])
+#define AMBER_QLO(wd) static_cast<float>((wd) & 0xffffu)
+#define AMBER_QHI(wd) static_cast<float>((wd) >> 16)
+#define AMBER_CHILD(wx_, wy_, wz_, hit_, key_) { \
+      const uint32_t wx = AMBER_ROT(wx_, 0), wy = AMBER_ROT(wy_, 1), wz = AMBER_ROT(wz_, 2); \
+      const float nx = __builtin_fmaf(AMBER_QLO(wx), tr.A.x, tr.b_in.x), ny = __builtin_fmaf(AMBER_QLO(wy), tr.A.y, tr.b_in.y), nz = __builtin_fmaf(AMBER_QLO(wz), tr.A.z, tr.b_in.z); \
+      const float fx = __builtin_fmaf(AMBER_QHI(wx), tr.A.x, tr.b_out.x), fy = __builtin_fmaf(AMBER_QHI(wy), tr.A.y, tr.b_out.y), fz = __builtin_fmaf(AMBER_QHI(wz), tr.A.z, tr.b_out.z); \
+      float tin; SlabDecide(nx, ny, nz, fx, fy, fz, tr.neg_slack, t_best, hit_, tin); key_ = hit_ ? tin : 3.402823466e+38f; }
+    bool h0, h1, h2, h3; float k0, k1, k2, k3;
+    AMBER_CHILD(p0.x, p0.y, p0.z, h0, k0); AMBER_CHILD(p0.w, p1.x, p1.y, h1, k1);
+    AMBER_CHILD(p1.z, p1.w, p2.x, h2, k2); AMBER_CHILD(p2.y, p2.z, p2.w, h3, k3);
+#undef AMBER_CHILD
+#undef AMBER_ROT
+#undef AMBER_QLO
+#undef AMBER_QHI
+    int32_t r0 = static_cast<int32_t>(cr.x), r1 = static_cast<int32_t>(cr.y), r2 = static_cast<int32_t>(cr.z), r3 = static_cast<int32_t>(cr.w);
+    const int n_hit = (h0 ? 1 : 0) + (h1 ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
+    // nearest first: sort the four (entry, reference) pairs (misses carry FLT_MAX) -- network (0,1)(2,3)(0,2)(1,3)(1,2)
+#define AMBER_CSWAP(ka, ra, kb, rb) { const bool sw = kb < ka; const float kt = sw ? kb : ka; kb = sw ? ka : kb; ka = kt; const int32_t rt = sw ? rb : ra; rb = sw ? ra : rb; ra = rt; }
+    AMBER_CSWAP(k0, r0, k1, r1); AMBER_CSWAP(k2, r2, k3, r3); AMBER_CSWAP(k0, r0, k2, r2); AMBER_CSWAP(k1, r1, k3, r3); AMBER_CSWAP(k1, r1, k2, r2);
+#undef AMBER_CSWAP
+    if (n_hit > 0) {
+      // the others go on the stack, the farthest first
+      if (n_hit > 3) { if (sp < stack_cap) { stack[sp * stride] = r3; ++sp; } else tr.overflow = true; }
+      if (n_hit > 2) { if (sp < stack_cap) { stack[sp * stride] = r2; ++sp; } else tr.overflow = true; }
+      if (n_hit > 1) { if (sp < stack_cap) { stack[sp * stride] = r1; ++sp; } else tr.overflow = true; }
+      cur = r0;
+    } else if (sp > 0) {
+      --sp; cur = stack[sp * stride];
+    } else {
+      cur = AMBER_BVH_DONE;
+    }
+#else
     const uint4* nd = reinterpret_cast<const uint4*>(sc.bvh_nodes + cur);
     const uint4 p = nd[0], q = nd[1];
     const int32_t left = static_cast<int32_t>(q.z), right = static_cast<int32_t>(q.w);
@@ -921,6 +968,7 @@ __device__ __forceinline__ void BvhDescend(const DevScene& sc, int32_t* lds_stac
     } else {
       cur = AMBER_BVH_DONE;
     }
+#endif
     AMBER_BVH_PARK();
   }
 #undef AMBER_BVH_PARK

@@ -570,6 +570,7 @@ struct amber_hip_pt {
   DevSphereFilter* d_sphere_filters = nullptr;
   DevObject* d_prog_objects = nullptr;
   DevBvhNodeQ* d_bvh_nodes = nullptr;
+  DevBvhNodeQ4* d_bvh_nodes4 = nullptr;      // AMBER_BVH_WIDE builds only
   float4* d_bvh_spheres = nullptr;
   uint32_t* d_bvh_prims = nullptr;
   DevObject* d_bvh_objects = nullptr;
@@ -805,6 +806,14 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMalloc(&h->d_bvh_nodes, (qbvh.nodes.size() + 1) * sizeof(DevBvhNodeQ)));
   HIP_TRY_H(hipMalloc(&h->d_bvh_prims, (bvh.prim_index.size() + 1) * sizeof(uint32_t)));
   if (!qbvh.nodes.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_nodes, qbvh.nodes.data(), qbvh.nodes.size() * sizeof(DevBvhNodeQ), hipMemcpyHostToDevice));
+#if AMBER_BVH_WIDE
+  {
+    amber_bvh::QuantizedBvh4 q4 = amber_bvh::CollapseBvh4(bvh.nodes, bvh.root_ref, qbvh, [&](uint32_t slot) { return (objs[bvh.prim_index[slot]].kind & 0xffu) == AMBER_PRIM_SPHERE; });
+    HIP_TRY_H(hipMalloc(&h->d_bvh_nodes4, (q4.nodes.size() + 1) * sizeof(DevBvhNodeQ4)));
+    if (!q4.nodes.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_nodes4, q4.nodes.data(), q4.nodes.size() * sizeof(DevBvhNodeQ4), hipMemcpyHostToDevice));
+    qbvh.root_ref = q4.root_ref;
+  }
+#endif
   if (!bvh.prim_index.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_prims, bvh.prim_index.data(), bvh.prim_index.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   {
     std::vector<DevObject> leaf_order(bvh.prim_index.size());
@@ -839,7 +848,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades;
   sc.planes = h->d_planes; sc.tri_filters = h->d_tri_filters; sc.sphere_filters = h->d_sphere_filters;
   sc.n_planes = static_cast<uint32_t>(fprog.planes.size()); sc.n_sphere_filters = static_cast<uint32_t>(fprog.spheres.size());
-  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_spheres = h->d_bvh_spheres; sc.bvh_root = qbvh.root_ref;
+  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_nodes4 = h->d_bvh_nodes4; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_spheres = h->d_bvh_spheres; sc.bvh_root = qbvh.root_ref;
   for (int c = 0; c < 3; c++) { sc.bvh_gmin[c] = qbvh.gmin[c]; sc.bvh_step[c] = qbvh.step[c]; sc.bvh_reach[c] = qbvh.reach[c]; }
   {
     // per-ray box margin of engine BVH (BvhBegin): centre and half diagonal of the scene bounds, 1 / smallest sphere radius
@@ -1246,6 +1255,7 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_sphere_filters) (void)hipFree(h->d_sphere_filters);
   if (h->d_prog_objects) (void)hipFree(h->d_prog_objects);
   if (h->d_bvh_nodes) (void)hipFree(h->d_bvh_nodes);
+  if (h->d_bvh_nodes4) (void)hipFree(h->d_bvh_nodes4);
   if (h->d_bvh_spheres) (void)hipFree(h->d_bvh_spheres);
   if (h->d_bvh_prims) (void)hipFree(h->d_bvh_prims);
   if (h->d_bvh_objects) (void)hipFree(h->d_bvh_objects);
