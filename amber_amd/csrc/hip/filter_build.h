@@ -31,6 +31,7 @@ struct FilterProgram {
   std::vector<DevSphereFilter> spheres;
   std::vector<uint32_t> order;          // program slot -> scene object index
   uint32_t n_prog_tris = 0, always_mask = 0;
+  uint32_t n_simple_planes = 0;         // the first planes of the program hold exactly one parallelogram pair and nothing else
 };
 
 // `center`: the filter works in coordinates relative to this point (the device subtracts it from the ray origin), so its
@@ -237,6 +238,31 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, const float c
     }
     if (g.same_normal) p.n_tris |= 0x80000000u;
     fp.planes.push_back(p);
+  }
+  // Planes that hold exactly one pair and no single triangle -- a wall, a floor, a rectangular light -- go first, in their
+  // relative order: the device runs them in a loop without inner record loops (ClosestHitTwoPhase: this code is bound by
+  // instruction delivery, and every scalar branch of the nested loops costs about as much as four VALU instructions).
+  // "Same normal as the previous plane" is re-derived for the new order.
+  {
+    std::vector<DevPlane> planes; std::vector<DevTriFilter> tris; std::vector<uint32_t> order;
+    for (int pass = 0; pass < 2; pass++) {
+      size_t rec = 0, slot = 0;
+      for (const DevPlane& pl : fp.planes) {
+        const uint32_t nt = pl.n_tris & 0x7fffffffu, np = pl.n_pairs;
+        const bool simple = np == 1 && nt == 0;
+        if (simple == (pass == 0)) {
+          DevPlane q = pl;
+          q.n_tris = nt;
+          if (!planes.empty() && std::memcmp(planes.back().n, q.n, sizeof q.n) == 0) q.n_tris |= 0x80000000u;
+          planes.push_back(q);
+          for (uint32_t k = 0; k < np + nt; k++) tris.push_back(fp.tris[rec + k]);
+          for (uint32_t k = 0; k < 2 * np + nt; k++) order.push_back(fp.order[slot + k]);
+          if (pass == 0) fp.n_simple_planes++;
+        }
+        rec += np + nt; slot += 2 * np + nt;
+      }
+    }
+    fp.planes.swap(planes); fp.tris.swap(tris); fp.order.swap(order);
   }
   fp.n_prog_tris = static_cast<uint32_t>(fp.order.size());
   fp.order.insert(fp.order.end(), sphere_index.begin(), sphere_index.end());

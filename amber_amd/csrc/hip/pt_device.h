@@ -161,6 +161,7 @@ struct DevScene {
   const DevTriFilter* __restrict__ tri_filters;
   const DevSphereFilter* __restrict__ sphere_filters;
   uint32_t n_planes, n_sphere_filters;
+  uint32_t n_simple_planes;    // the first planes of the program: one pair record each, evaluated without inner loops
   uint32_t always_mask;        // program slots that are always candidates (disks, cylinders, degenerate triangles)
   uint32_t n_prog_tris;        // program slots [0, n_prog_tris) are filtered triangles, then spheres, then the rest
   const DevObject* __restrict__ prog_objects;   // objects in program order, kind |= scene index << 8 (staged to LDS)
@@ -611,40 +612,54 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
     const int n_planes = static_cast<int>(sc.n_planes);
     uint32_t bit = 1u;                                       // candidate bit of the next program triangle (SALU)
     float nd = 0.f, no = 0.f, rc = 0.f;
-    for (int p = 0; p < n_planes; ++p, pl += 8) {           // DevPlane = 8 dwords
-      if (!(pl[6] & 0x80000000u)) {                         // a plane parallel to the previous one (same stored normal) reuses n.d, n.o and 1 / n.d
-        nd = __builtin_fmaf(cw_f(pl, 0), d.x, __builtin_fmaf(cw_f(pl, 1), d.y, cw_f(pl, 2) * d.z));
-        no = __builtin_fmaf(cw_f(pl, 0), o.x, __builtin_fmaf(cw_f(pl, 1), o.y, cw_f(pl, 2) * o.z));
-        rc = __builtin_amdgcn_rcpf(nd);
-      }
-      const float tp = (cw_f(pl, 3) - no) * rc;
-      const float rho = Abs(rc);
-      const float Px = __builtin_fmaf(tp, d.x, o.x), Py = __builtin_fmaf(tp, d.y, o.y), Pz = __builtin_fmaf(tp, d.z, o.z);
-      const float kr = cw_f(pl, 4) * rho;                   // distance tolerance of this plane for this ray
-      const bool t_ok = (tp >= AMBER_KEPS - kr) && !(tp - kr > t_upper);                  // beyond kEPS, and not certainly behind a certain hit
-      // nearly parallel: the in-plane coordinates are not trusted (every triangle of the plane stays a candidate), the
-      // distance still is, down to |n.d| = 1e-6; below that, or NaN, everything is kept
-      const bool degenerate = !(Abs(nd) >= 1e-6f);
-      const bool grazing = !(Abs(nd) >= AMBER_GRAZING);
-      const bool t_sure = (tp - kr > AMBER_KEPS) && !grazing;
-      const float ptol = cw_f(pl, 5) * rho;
-      const float mtol = grazing ? -3.402823466e+38f : -ptol;                             // grazing: any in-plane position passes
+#define AMBER_PLANE_SETUP() \
+      if (!(pl[6] & 0x80000000u)) {                         /* a plane parallel to the previous one (same stored normal) reuses n.d, n.o and 1 / n.d */ \
+        nd = __builtin_fmaf(cw_f(pl, 0), d.x, __builtin_fmaf(cw_f(pl, 1), d.y, cw_f(pl, 2) * d.z)); \
+        no = __builtin_fmaf(cw_f(pl, 0), o.x, __builtin_fmaf(cw_f(pl, 1), o.y, cw_f(pl, 2) * o.z)); \
+        rc = __builtin_amdgcn_rcpf(nd); \
+      } \
+      const float tp = (cw_f(pl, 3) - no) * rc; \
+      const float rho = Abs(rc); \
+      const float Px = __builtin_fmaf(tp, d.x, o.x), Py = __builtin_fmaf(tp, d.y, o.y), Pz = __builtin_fmaf(tp, d.z, o.z); \
+      const float kr = cw_f(pl, 4) * rho;                   /* distance tolerance of this plane for this ray */ \
+      const bool t_ok = (tp >= AMBER_KEPS - kr) && !(tp - kr > t_upper);                  /* beyond kEPS, and not certainly behind a certain hit */ \
+      /* nearly parallel: the in-plane coordinates are not trusted (every triangle of the plane stays a candidate), the */ \
+      /* distance still is, down to |n.d| = 1e-6; below that, or NaN, everything is kept */ \
+      const bool degenerate = !(Abs(nd) >= 1e-6f); \
+      const bool grazing = !(Abs(nd) >= AMBER_GRAZING); \
+      const bool t_sure = (tp - kr > AMBER_KEPS) && !grazing; \
+      const float ptol = cw_f(pl, 5) * rho; \
+      const float mtol = grazing ? -3.402823466e+38f : -ptol;                             /* grazing: any in-plane position passes */ \
       bool plane_hit = false;
+#ifndef AMBER_NO_CERTAIN_HITS
+#define AMBER_PLANE_HIT(m_) plane_hit |= (m_) >= ptol
+#else
+#define AMBER_PLANE_HIT(m_)
+#endif
+#define AMBER_PAIR_RECORD() { \
+        const float b = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 2), Py, __builtin_fmaf(cw_f(tr, 4), Pz, cw_f(tr, 6)))); \
+        const float a = __builtin_fmaf(cw_f(tr, 1), Px, __builtin_fmaf(cw_f(tr, 3), Py, __builtin_fmaf(cw_f(tr, 5), Pz, cw_f(tr, 7)))); \
+        const float ba = b + a;                             /* 1 - gamma: the second triangle's first coordinate */ \
+        const float g = 1.0f - ba; \
+        const float m1 = __builtin_fminf(__builtin_fminf(b, a), g); \
+        const float m2 = __builtin_fminf(__builtin_fminf(-b, 1.0f - a), ba); \
+        const bool keep1 = (!(m1 < mtol) && t_ok) || degenerate;                          /* NaN coordinates -> keep */ \
+        const bool keep2 = (!(m2 < mtol) && t_ok) || degenerate; \
+        cand |= keep1 ? bit : 0u; \
+        cand |= keep2 ? (bit << 1) : 0u; \
+        AMBER_PLANE_HIT(__builtin_fmaxf(m1, m2)); }
+    const int n_simple = static_cast<int>(sc.n_simple_planes);
+    int p = 0;
+    for (; p < n_simple; ++p, pl += 8, tr += 8, bit <<= 2) {  // planes of one parallelogram pair (filter_build.h): no inner loops
+      AMBER_PLANE_SETUP();
+      AMBER_PAIR_RECORD();
+      if (plane_hit && t_sure) t_upper = __builtin_fminf(t_upper, tp + kr);
+    }
+    for (; p < n_planes; ++p, pl += 8) {                    // DevPlane = 8 dwords
+      AMBER_PLANE_SETUP();
       const int nt = static_cast<int>(pl[6] & 0x7fffffffu), np = static_cast<int>(pl[7]);
       for (int k = 0; k < np; ++k, tr += 8, bit <<= 2) {    // parallelogram pairs: one record, two candidate bits
-        const float b = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 2), Py, __builtin_fmaf(cw_f(tr, 4), Pz, cw_f(tr, 6))));
-        const float a = __builtin_fmaf(cw_f(tr, 1), Px, __builtin_fmaf(cw_f(tr, 3), Py, __builtin_fmaf(cw_f(tr, 5), Pz, cw_f(tr, 7))));
-        const float ba = b + a;                             // 1 - gamma: the second triangle's first coordinate
-        const float g = 1.0f - ba;
-        const float m1 = __builtin_fminf(__builtin_fminf(b, a), g);
-        const float m2 = __builtin_fminf(__builtin_fminf(-b, 1.0f - a), ba);
-        const bool keep1 = (!(m1 < mtol) && t_ok) || degenerate;                          // NaN coordinates -> keep
-        const bool keep2 = (!(m2 < mtol) && t_ok) || degenerate;
-        cand |= keep1 ? bit : 0u;
-        cand |= keep2 ? (bit << 1) : 0u;
-#ifndef AMBER_NO_CERTAIN_HITS
-        plane_hit |= __builtin_fmaxf(m1, m2) >= ptol;
-#endif
+        AMBER_PAIR_RECORD();
       }
       for (int k = 0; k < nt; ++k, tr += 8, bit <<= 1) {    // DevTriFilter = 8 dwords
         const float u = __builtin_fmaf(cw_f(tr, 0), Px, __builtin_fmaf(cw_f(tr, 2), Py, __builtin_fmaf(cw_f(tr, 4), Pz, cw_f(tr, 6))));
@@ -653,12 +668,13 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
         const float m = __builtin_fminf(__builtin_fminf(u, v), w);
         const bool keep = (!(m < mtol) && t_ok) || degenerate;
         cand |= keep ? bit : 0u;
-#ifndef AMBER_NO_CERTAIN_HITS
-        plane_hit |= m >= ptol;
-#endif
+        AMBER_PLANE_HIT(m);
       }
       if (plane_hit && t_sure) t_upper = __builtin_fminf(t_upper, tp + kr);
     }
+#undef AMBER_PLANE_SETUP
+#undef AMBER_PAIR_RECORD
+#undef AMBER_PLANE_HIT
     ConstWords sp = (ConstWords)(sc.sphere_filters);
     const int ns = static_cast<int>(sc.n_sphere_filters);
     for (int k = 0; k < ns; ++k, sp += 8, bit <<= 1) {      // DevSphereFilter = 8 dwords
