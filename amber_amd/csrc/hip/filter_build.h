@@ -31,7 +31,7 @@ struct FilterProgram {
   std::vector<DevSphereFilter> spheres;
   std::vector<uint32_t> order;          // program slot -> scene object index
   uint32_t n_prog_tris = 0, always_mask = 0;
-  uint32_t n_simple_planes = 0;         // the first planes of the program hold exactly one parallelogram pair and nothing else
+  uint32_t n_simple_planes = 0;         // the first planes of the program (an even number) form slabs: two parallel planes of one parallelogram pair each
 };
 
 // `center`: the filter works in coordinates relative to this point (the device subtracts it from the ray origin), so its
@@ -239,29 +239,38 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, const float c
     if (g.same_normal) p.n_tris |= 0x80000000u;
     fp.planes.push_back(p);
   }
-  // Planes that hold exactly one pair and no single triangle -- a wall, a floor, a rectangular light -- go first, in their
-  // relative order: the device runs them in a loop without inner record loops (ClosestHitTwoPhase: this code is bound by
-  // instruction delivery, and every scalar branch of the nested loops costs about as much as four VALU instructions).
-  // "Same normal as the previous plane" is re-derived for the new order.
+  // Slabs first.  A plane that holds exactly one parallelogram pair and nothing else -- a wall, a floor, a rectangular
+  // light -- and is followed by another such plane with the SAME stored normal forms a slab with it; the slabs go first, in
+  // their relative order, and the device runs them two planes per iteration with neither inner record loops nor the
+  // "same normal?" branch (ClosestHitTwoPhase: that code is bound by instruction delivery, and every scalar branch of the
+  // nested loops costs about as much as four VALU instructions).  Everything else follows in the general form; "same
+  // normal as the previous plane" is re-derived for the new order.
   {
-    std::vector<DevPlane> planes; std::vector<DevTriFilter> tris; std::vector<uint32_t> order;
-    for (int pass = 0; pass < 2; pass++) {
-      size_t rec = 0, slot = 0;
-      for (const DevPlane& pl : fp.planes) {
-        const uint32_t nt = pl.n_tris & 0x7fffffffu, np = pl.n_pairs;
-        const bool simple = np == 1 && nt == 0;
-        if (simple == (pass == 0)) {
-          DevPlane q = pl;
-          q.n_tris = nt;
-          if (!planes.empty() && std::memcmp(planes.back().n, q.n, sizeof q.n) == 0) q.n_tris |= 0x80000000u;
-          planes.push_back(q);
-          for (uint32_t k = 0; k < np + nt; k++) tris.push_back(fp.tris[rec + k]);
-          for (uint32_t k = 0; k < 2 * np + nt; k++) order.push_back(fp.order[slot + k]);
-          if (pass == 0) fp.n_simple_planes++;
-        }
+    struct Span { size_t rec, slot; };
+    std::vector<Span> span(fp.planes.size());
+    { size_t rec = 0, slot = 0;
+      for (size_t i = 0; i < fp.planes.size(); i++) {
+        span[i] = Span{rec, slot};
+        const uint32_t nt = fp.planes[i].n_tris & 0x7fffffffu, np = fp.planes[i].n_pairs;
         rec += np + nt; slot += 2 * np + nt;
+      } }
+    auto simple = [&](size_t i) { return fp.planes[i].n_pairs == 1 && (fp.planes[i].n_tris & 0x7fffffffu) == 0; };
+    std::vector<char> in_slab(fp.planes.size(), 0);
+    for (size_t i = 0; i + 1 < fp.planes.size(); i++)
+      if (!in_slab[i] && simple(i) && simple(i + 1) && std::memcmp(fp.planes[i].n, fp.planes[i + 1].n, sizeof fp.planes[i].n) == 0) { in_slab[i] = in_slab[i + 1] = 1; i++; }
+    std::vector<DevPlane> planes; std::vector<DevTriFilter> tris; std::vector<uint32_t> order;
+    for (int pass = 0; pass < 2; pass++)
+      for (size_t i = 0; i < fp.planes.size(); i++) {
+        if ((in_slab[i] != 0) != (pass == 0)) continue;
+        DevPlane q = fp.planes[i];
+        const uint32_t nt = q.n_tris & 0x7fffffffu, np = q.n_pairs;
+        q.n_tris = nt;
+        if (!planes.empty() && std::memcmp(planes.back().n, q.n, sizeof q.n) == 0) q.n_tris |= 0x80000000u;
+        planes.push_back(q);
+        for (uint32_t k = 0; k < np + nt; k++) tris.push_back(fp.tris[span[i].rec + k]);
+        for (uint32_t k = 0; k < 2 * np + nt; k++) order.push_back(fp.order[span[i].slot + k]);
+        if (pass == 0) fp.n_simple_planes++;
       }
-    }
     fp.planes.swap(planes); fp.tris.swap(tris); fp.order.swap(order);
   }
   fp.n_prog_tris = static_cast<uint32_t>(fp.order.size());

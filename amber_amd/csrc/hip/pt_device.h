@@ -161,7 +161,7 @@ struct DevScene {
   const DevTriFilter* __restrict__ tri_filters;
   const DevSphereFilter* __restrict__ sphere_filters;
   uint32_t n_planes, n_sphere_filters;
-  uint32_t n_simple_planes;    // the first planes of the program: one pair record each, evaluated without inner loops
+  uint32_t n_simple_planes;    // the first planes of the program, an even number: slabs of two parallel planes with one pair record each
   uint32_t always_mask;        // program slots that are always candidates (disks, cylinders, degenerate triangles)
   uint32_t n_prog_tris;        // program slots [0, n_prog_tris) are filtered triangles, then spheres, then the rest
   const DevObject* __restrict__ prog_objects;   // objects in program order, kind |= scene index << 8 (staged to LDS)
@@ -612,12 +612,11 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
     const int n_planes = static_cast<int>(sc.n_planes);
     uint32_t bit = 1u;                                       // candidate bit of the next program triangle (SALU)
     float nd = 0.f, no = 0.f, rc = 0.f;
-#define AMBER_PLANE_SETUP() \
-      if (!(pl[6] & 0x80000000u)) {                         /* a plane parallel to the previous one (same stored normal) reuses n.d, n.o and 1 / n.d */ \
+#define AMBER_PLANE_NORMAL() \
         nd = __builtin_fmaf(cw_f(pl, 0), d.x, __builtin_fmaf(cw_f(pl, 1), d.y, cw_f(pl, 2) * d.z)); \
         no = __builtin_fmaf(cw_f(pl, 0), o.x, __builtin_fmaf(cw_f(pl, 1), o.y, cw_f(pl, 2) * o.z)); \
-        rc = __builtin_amdgcn_rcpf(nd); \
-      } \
+        rc = __builtin_amdgcn_rcpf(nd);
+#define AMBER_PLANE_SETUP() \
       const float tp = (cw_f(pl, 3) - no) * rc; \
       const float rho = Abs(rc); \
       const float Px = __builtin_fmaf(tp, d.x, o.x), Py = __builtin_fmaf(tp, d.y, o.y), Pz = __builtin_fmaf(tp, d.z, o.z); \
@@ -650,12 +649,15 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
         AMBER_PLANE_HIT(__builtin_fmaxf(m1, m2)); }
     const int n_simple = static_cast<int>(sc.n_simple_planes);
     int p = 0;
-    for (; p < n_simple; ++p, pl += 8, tr += 8, bit <<= 2) {  // planes of one parallelogram pair (filter_build.h): no inner loops
-      AMBER_PLANE_SETUP();
-      AMBER_PAIR_RECORD();
-      if (plane_hit && t_sure) t_upper = __builtin_fminf(t_upper, tp + kr);
+    for (; p < n_simple; p += 2) {                          // slabs (filter_build.h): two parallel planes of one parallelogram pair each
+      AMBER_PLANE_NORMAL();
+      { AMBER_PLANE_SETUP(); AMBER_PAIR_RECORD(); if (plane_hit && t_sure) t_upper = __builtin_fminf(t_upper, tp + kr); }
+      pl += 8; tr += 8; bit <<= 2;
+      { AMBER_PLANE_SETUP(); AMBER_PAIR_RECORD(); if (plane_hit && t_sure) t_upper = __builtin_fminf(t_upper, tp + kr); }
+      pl += 8; tr += 8; bit <<= 2;
     }
     for (; p < n_planes; ++p, pl += 8) {                    // DevPlane = 8 dwords
+      if (!(pl[6] & 0x80000000u)) { AMBER_PLANE_NORMAL(); } // a plane parallel to the previous one (same stored normal) reuses n.d, n.o and 1 / n.d
       AMBER_PLANE_SETUP();
       const int nt = static_cast<int>(pl[6] & 0x7fffffffu), np = static_cast<int>(pl[7]);
       for (int k = 0; k < np; ++k, tr += 8, bit <<= 2) {    // parallelogram pairs: one record, two candidate bits
@@ -673,6 +675,7 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
       if (plane_hit && t_sure) t_upper = __builtin_fminf(t_upper, tp + kr);
     }
 #undef AMBER_PLANE_SETUP
+#undef AMBER_PLANE_NORMAL
 #undef AMBER_PAIR_RECORD
 #undef AMBER_PLANE_HIT
     ConstWords sp = (ConstWords)(sc.sphere_filters);
