@@ -707,24 +707,25 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
   // Otherwise (t above kEPS, or NaN) the bit stays and the full exact test decides below.
   {
     const bool has_self = origin_slot >= 0 && ((cand >> (origin_slot & 31)) & 1u) != 0u;
-    if (__any(has_self)) {
-      if (has_self) {
-        const DevObject& ob = lds_objects[origin_slot];
-        const V3 A = ld3(ob.a), E1 = ld3(ob.e1), E2 = ld3(ob.e2);
-        const float det = Dot(Cross(d, E2), E1);
-        const float t = Dot(Cross(o_world - A, E1), E2) / det;
-        if (t <= AMBER_KEPS) cand &= ~(1u << origin_slot);
-      }
+    if (has_self) {
+      const DevObject& ob = lds_objects[origin_slot];
+      const V3 A = ld3(ob.a), E1 = ld3(ob.e1), E2 = ld3(ob.e2);
+      const float det = Dot(Cross(d, E2), E1);
+      const float t = Dot(Cross(o_world - A, E1), E2) / det;
+      if (t <= AMBER_KEPS) cand &= ~(1u << origin_slot);
     }
   }
   // Phase B: filtered triangles first, then everything else (keeps the per-lane kind branch out of the hot loop)
   const uint32_t tri_bits = sc.n_prog_tris >= 32u ? 0xffffffffu : ((1u << sc.n_prog_tris) - 1u);
   uint32_t mt = cand & tri_bits;
-  while (__any(mt != 0u)) {
 #ifdef AMBER_STAMPS
+  while (__any(mt != 0u)) {                                  // diagnostic build: all lanes stay in the loop so that lane 0 can count
     stamp_ctx->acc[7] += 1ull + (static_cast<unsigned long long>(__popcll(__ballot(mt != 0u))) << 32);   // lo: wave trips, hi: lane tests
-#endif
     if (mt != 0u) {
+#else
+  while (mt != 0u) {                                         // per lane; the wave leaves the loop with its last lane
+    {
+#endif
       const int slot = __builtin_ctz(mt);
       mt &= mt - 1u;
       const DevObject& ob = lds_objects[slot];
@@ -732,13 +733,11 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
     }
   }
   uint32_t mo = cand & ~tri_bits;
-  while (__any(mo != 0u)) {
-    if (mo != 0u) {
-      const int slot = __builtin_ctz(mo);
-      mo &= mo - 1u;
-      const DevObject& ob = lds_objects[slot];
-      IntersectObject<true>(ob, ob.kind & 0xffu, static_cast<int>(ob.kind >> 8), slot, o_world, d, best);
-    }
+  while (mo != 0u) {
+    const int slot = __builtin_ctz(mo);
+    mo &= mo - 1u;
+    const DevObject& ob = lds_objects[slot];
+    IntersectObject<true>(ob, ob.kind & 0xffu, static_cast<int>(ob.kind >> 8), slot, o_world, d, best);
   }
 }
 
