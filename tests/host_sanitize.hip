@@ -66,7 +66,7 @@ int main() {
     amber_filter::FilterProgram fp;
     { const float zero_center[3] = {0, 0, 0}; amber_filter::BuildFilterProgram(objs, zero_center, fp); }
     uint32_t pairs = 0, singles = 0;
-    for (const auto& pl : fp.planes) { pairs += pl.n_pairs; singles += pl.n_tris; }
+    for (const auto& pl : fp.planes) { pairs += pl.n_pairs; singles += pl.n_tris & 0x7fffffffu; }   // bit 31 of n_tris: same normal as the previous plane
     std::vector<int> slot_of(objs.size(), 0);
     for (uint32_t idx : fp.order) if (idx < objs.size()) slot_of[idx]++;
     bool each_once = true;
@@ -78,7 +78,14 @@ int main() {
                   fp.spheres.size(), fp.always_mask);
       return 1;
     }
-    std::printf("ok   filter program: 9 planes, 22 triangles in 11 pair records, 3 spheres\n");
+    // slabs: an even number of leading planes, one pair each, the second of every two parallel to the first
+    bool slabs_ok = fp.n_simple_planes % 2 == 0 && fp.n_simple_planes <= fp.planes.size();
+    for (uint32_t i = 0; i < fp.n_simple_planes && slabs_ok; i++) {
+      const auto& pl = fp.planes[i];
+      slabs_ok = pl.n_pairs == 1 && (pl.n_tris & 0x7fffffffu) == 0 && ((i & 1u) == 0 || (pl.n_tris >> 31) == 1u);
+    }
+    if (!slabs_ok || fp.n_simple_planes != 8) { std::printf("FAIL filter program: slabs (%u leading planes)\n", fp.n_simple_planes); return 1; }
+    std::printf("ok   filter program: 9 planes (4 slabs first), 22 triangles in 11 pair records, 3 spheres\n");
     CheckBvh(objs, "cornell");
   }
   // 2. degenerate inputs: pinhole (zero-area triangle), one object, coincident centres, extreme coordinates
