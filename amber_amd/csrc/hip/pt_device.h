@@ -66,8 +66,9 @@ struct alignas(16) DevObject {   // 64 B
 };
 struct alignas(16) DevMaterial {  // 32 B
   uint32_t kind; float rho[3];
-  float param; float r0; float pad[2];
-};
+  float param; float r0;
+  float aux0, aux1;               // per-material constants of the sampling code, computed once on the host with the same binary32
+};                                //   operations: Phong 1 / (e + 1) and (e + 2) / (e + 1); Refraction 1 / ior
 struct alignas(16) DevBlade {     // 64 B: aperture triangle with explicit vertices (SampleSurfacePoint)
   float v0[3], v1[3], v2[3], n[3];
   int32_t slot;                   // the blade's slot in the two-phase filter program (-1 if it is not a filtered triangle)
@@ -1134,7 +1135,7 @@ __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 
       const float r1 = Uniform(rng);
       float cos_theta, sin_theta;
       if (phong) {
-        cos_theta = Pow(r0, 1.0f / (m.param + 1.0f));
+        cos_theta = Pow(r0, m.aux0);                     // r0 ^ (1 / (e + 1))
         sin_theta = Sqrt(1.0f - cos_theta * cos_theta);
       } else {
         cos_theta = Sqrt(r0);
@@ -1147,7 +1148,7 @@ __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 
       const float signed_cos_i = Dot(di, normal);
       if (signed_cos_o * signed_cos_i <= 0.0f && attempt < AMBER_PHONG_MAX_TRIES) continue;
       dir_in = di;
-      weight = ((m.param + 2.0f) / (m.param + 1.0f) * Abs(signed_cos_i)) * rho;
+      weight = (m.aux1 * Abs(signed_cos_i)) * rho;      // (e + 2) / (e + 1) * |cos|
       break;
     }
   } else if (kind == MAT_SPECULAR) {                     // material_specular.cc:62-70
@@ -1155,7 +1156,7 @@ __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 
     weight = 1.0f * rho;
   } else if (kind == MAT_REFRACTION) {                   // material_refraction.cc:177-220
     const float signed_cos_alpha = Dot(dir_out, normal);
-    const float ior = signed_cos_alpha > 0.0f ? 1.0f / m.param : m.param;
+    const float ior = signed_cos_alpha > 0.0f ? m.aux0 : m.param;   // 1 / ior when entering
     const float squared_cos_beta = 1.0f - (1.0f - signed_cos_alpha * signed_cos_alpha) * (ior * ior);
     const V3 dir_r = PerfectReflection(dir_out, normal, signed_cos_alpha);
     if (squared_cos_beta < 0.0f) {
@@ -1187,7 +1188,7 @@ __device__ __forceinline__ void SampleImportance(const DevMaterial& m, V3 normal
   if (m.kind != MAT_REFRACTION) { SampleLight(m, normal, dir_out, rng, dir_in, weight); return; }
   const V3 rho = ld3(m.rho);
   const float signed_cos_alpha = Dot(dir_out, normal);
-  const float ior = signed_cos_alpha > 0.0f ? 1.0f / m.param : m.param;
+  const float ior = signed_cos_alpha > 0.0f ? m.aux0 : m.param;   // 1 / ior when entering
   const float squared_cos_beta = 1.0f - (1.0f - signed_cos_alpha * signed_cos_alpha) * (ior * ior);
   const V3 dir_r = PerfectReflection(dir_out, normal, signed_cos_alpha);
   if (squared_cos_beta < 0.0f) { dir_in = dir_r; weight = 1.0f * rho; return; }

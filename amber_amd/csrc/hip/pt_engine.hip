@@ -725,6 +725,11 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     DevMaterial& m = mats[i];
     std::memset(&m, 0, sizeof m);
     m.kind = f.kind; m.rho[0] = f.rho[0]; m.rho[1] = f.rho[1]; m.rho[2] = f.rho[2]; m.param = f.param; m.r0 = f.r0;
+    // constants the reference recomputes for every sample (material_phong.cc:92-105, material_refraction.cc:181-183): the same
+    // binary32 operations, once (volatile: no wider intermediate, no reassociation)
+    volatile float e1 = f.param + 1.0f, e2 = f.param + 2.0f;
+    if (f.kind == AMBER_MAT_PHONG) { volatile float a = 1.0f / e1, b = e2 / e1; m.aux0 = a; m.aux1 = b; }
+    else if (f.kind == AMBER_MAT_REFRACTION) { volatile float a = 1.0f / f.param; m.aux0 = a; }
   }
   const AmberFlatThinLens& L = s->lens;
   std::vector<DevBlade> blades(L.n_blades);
