@@ -1117,10 +1117,6 @@ __device__ __forceinline__ V3 Radiance(const DevMaterial& m, V3 normal, V3 dir_o
 __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 dir_out, uint64_t& rng, V3& dir_in, V3& weight) {
   const V3 rho = ld3(m.rho);
   const uint32_t kind = m.kind;
-  // dot(dir_out, n) and the mirror direction are used by Phong, Specular and Refraction alike: evaluated once for the wave
-  // instead of once per material branch (the same expressions, so the same bits)
-  const float signed_cos_o = Dot(dir_out, normal);
-  const V3 mirror = PerfectReflection(dir_out, normal, signed_cos_o);
   if (kind == MAT_LAMBERTIAN || kind == MAT_PHONG) {
     // Lambertian (material_lambertian.cc:61-70, HemispherePSA sampling.h:234-265) and Phong (material_phong.cc:81-106,
     // CosinePower sampling.h:267-300) share the lobe construction -- orthonormal basis, two uniforms, sin/cos of phi,
@@ -1128,7 +1124,8 @@ __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 
     // so a wave with lanes on both materials pays for the shared part once; each lane still executes exactly the
     // operations of its own material (Phong re-samples until the direction is on the side of dir_out).
     const bool phong = kind == MAT_PHONG;
-    const V3 w = phong ? mirror : (signed_cos_o > 0.0f ? normal : -normal);
+    const float signed_cos_o = Dot(dir_out, normal);
+    const V3 w = phong ? PerfectReflection(dir_out, normal, signed_cos_o) : (signed_cos_o > 0.0f ? normal : -normal);
     V3 u, v; OrthonormalBasis(w, u, v);                  // CosinePower rebuilds the same basis on every attempt
     // The reference's Phong loop re-samples forever when no direction of the lobe lies on dir_out's side (possible with a
     // normal that is not of unit length); a kernel must terminate, so attempt AMBER_PHONG_MAX_TRIES is accepted as it
@@ -1155,13 +1152,13 @@ __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 
       break;
     }
   } else if (kind == MAT_SPECULAR) {                     // material_specular.cc:62-70
-    dir_in = mirror;
+    dir_in = PerfectReflection(dir_out, normal, Dot(dir_out, normal));
     weight = 1.0f * rho;
   } else if (kind == MAT_REFRACTION) {                   // material_refraction.cc:177-220
-    const float signed_cos_alpha = signed_cos_o;
+    const float signed_cos_alpha = Dot(dir_out, normal);
     const float ior = signed_cos_alpha > 0.0f ? m.aux0 : m.param;   // 1 / ior when entering
     const float squared_cos_beta = 1.0f - (1.0f - signed_cos_alpha * signed_cos_alpha) * (ior * ior);
-    const V3 dir_r = mirror;
+    const V3 dir_r = PerfectReflection(dir_out, normal, signed_cos_alpha);
     if (squared_cos_beta < 0.0f) {
       dir_in = dir_r; weight = 1.0f * rho;
     } else {
