@@ -38,3 +38,28 @@ def test_four_wide_bvh_build_matches_engine_list():
     env = dict(os.environ, AMBER_AMD_LIB="libamber_hip_wide.so")
     r = subprocess.run([sys.executable, "-c", SCRIPT % str(ROOT)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "WIDE OK" in r.stdout, r.stdout + r.stderr
+
+
+STAMPS_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r)
+import amber_amd as A
+assert str(A.library_path()).endswith("libamber_hip_stamps.so")
+sc = A.HostScene.cornell_box(); sn = A.Sensor.default(256, 256)
+rays = {}
+for e in (A.ENGINE_TWO_PHASE, A.ENGINE_LIST, A.ENGINE_BVH):
+    pt = A.PathTracer(sc, sn, engine=e); pt.render_pass(0, 32); pt.sync(); rays[e] = pt.ray_count(); pt.close()
+assert len(set(rays.values())) == 1, rays
+print("STAMPS OK", rays)
+"""
+
+
+@pytest.mark.gpu
+def test_diagnostic_build_renders_the_same_paths():
+    """The -DAMBER_STAMPS build (tools/stamps.py, tools/bvh_counters.py) adds clocks and counters, nothing else: every engine
+    must still cast exactly the rays of engine LIST.  (Guards the tools: a hoisted expression once pushed the stamped two-phase
+    kernel's register pressure into a miscompile that lost 5 % of the rays -- in that build only.)"""
+    subprocess.run(["make", "-C", str(ROOT / "amber_amd" / "csrc"), "stamps"], check=True, capture_output=True, timeout=900)
+    env = dict(os.environ, AMBER_AMD_LIB="libamber_hip_stamps.so")
+    r = subprocess.run([sys.executable, "-c", STAMPS_SCRIPT % str(ROOT)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "STAMPS OK" in r.stdout, r.stdout + r.stderr
