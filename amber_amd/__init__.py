@@ -5,12 +5,14 @@ The product is the shared library ``amber_amd/lib/libamber_hip.so`` (gfx950 kern
 package is a thin ctypes binding used by the tests, ``bench.py`` and the multi-GPU driver; it
 contains no rendering code of its own and has no CPU fallback.
 """
+from . import api  # noqa: F401
 from .api import (  # noqa: F401
     ENGINE_AUTO,
     ENGINE_BVH,
     ENGINE_LIST,
     ENGINE_TWO_PHASE,
     ENGINE_WAVEFRONT,
+    PT_FLAG_BVH_POOL,
     AmberError,
     FlatMaterial,
     FlatObject,

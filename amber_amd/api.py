@@ -71,13 +71,14 @@ class HostStats(C.Structure):
 PRIM_TRIANGLE, PRIM_SPHERE, PRIM_DISK, PRIM_CYLINDER = 0, 1, 2, 3
 MAT_LAMBERTIAN, MAT_PHONG, MAT_SPECULAR, MAT_REFRACTION, MAT_DIFFUSE_LIGHT, MAT_EYE = 0, 1, 2, 3, 4, 5
 ENGINE_AUTO, ENGINE_LIST, ENGINE_TWO_PHASE, ENGINE_BVH, ENGINE_WAVEFRONT = 0, 1, 2, 3, 4
+PT_FLAG_NULL_STREAM, PT_FLAG_BVH_POOL = 1, 2
 
 # every symbol include/amber_hip.h and include/amber_host.h declare
 ABI_SYMBOLS = [
     "amber_hip_pt_create", "amber_hip_pt_render_pass", "amber_hip_pt_clear", "amber_hip_pt_sync",
     "amber_hip_pt_download", "amber_hip_pt_device_framebuffer", "amber_hip_pt_stream", "amber_hip_pt_local_rows", "amber_hip_pt_kernel_time", "amber_hip_pt_destroy",
-    "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_math_mode", "amber_hip_device_count", "amber_hip_lt_trace",
-    "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math", "amber_hip_kat_signatures",
+    "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_math_mode", "amber_hip_device_count", "amber_hip_lt_trace", "amber_hip_lt_trace_range",
+    "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math", "amber_hip_kat_signatures", "amber_hip_pt_signatures",
     "amber_host_cornell_box", "amber_host_scene_import", "amber_host_scene_create", "amber_host_scene_destroy", "amber_host_scene_flatten",
     "amber_host_pt_create", "amber_host_render", "amber_host_render_devices", "amber_host_last_error", "amber_host_tonemap", "amber_host_export",
 ]
@@ -122,12 +123,16 @@ def load_library() -> C.CDLL:
     lib.amber_hip_pt_destroy.restype = None
     if hasattr(lib, "amber_hip_lt_trace"):     # absent only in older builds loaded by tools/ab_lib.py
         lib.amber_hip_lt_trace.argtypes = [vp, u32, u32, vp, u32, C.POINTER(u32), C.POINTER(u64)]
+    if hasattr(lib, "amber_hip_lt_trace_range"):
+        lib.amber_hip_lt_trace_range.argtypes = [vp, u32, u32, u32, u32, vp, u32, C.POINTER(u32), C.POINTER(u64)]
     lib.amber_hip_kat_cast.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     lib.amber_hip_kat_sample.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     lib.amber_hip_kat_eye.argtypes = [vp, u32, vp, vp, vp]
     lib.amber_hip_kat_trace.argtypes = [vp, u32, vp, vp, u32, vp, vp]
     lib.amber_hip_kat_math.argtypes = [i32, i32, u32, vp, vp]
     lib.amber_hip_kat_signatures.argtypes = [vp, u32, u32, vp]
+    if hasattr(lib, "amber_hip_pt_signatures"):    # absent only in older builds loaded by tools/ab_lib.py
+        lib.amber_hip_pt_signatures.argtypes = [vp, u32, u32, vp]
     lib.amber_host_cornell_box.restype = vp
     lib.amber_host_cornell_box.argtypes = [C.c_float, C.c_float, u32]
     lib.amber_host_scene_import.restype = vp
@@ -255,12 +260,13 @@ class PathTracer:
     """amber_hip_pt handle: the device-side engine for one band of the framebuffer on one GPU."""
 
     def __init__(self, scene: HostScene, sensor: Sensor, seed: int = 12345, max_depth: int = 0, device: int = 0,
-                 rows=None, stream: int | None = None, engine: int = ENGINE_AUTO, stripe=None):
-        """rows = (y0, y1) contiguous band; stripe = (S, period) keeps only rows with (y - y0) % period < S."""
+                 rows=None, stream: int | None = None, engine: int = ENGINE_AUTO, stripe=None, flags: int = 0):
+        """rows = (y0, y1) contiguous band; stripe = (S, period) keeps only rows with (y - y0) % period < S;
+        flags = AMBER_PT_FLAG_* bits (PT_FLAG_BVH_POOL: engine BVH with the per-wave ray pool scheduler)."""
         self.sensor = sensor
         rb, re = rows if rows is not None else (0, sensor.height)
         s_rows, s_period = stripe if stripe else (0, 0)
-        p = PtParams(seed, max_depth, device, rb, re, stream, engine, s_rows, s_period, 0)
+        p = PtParams(seed, max_depth, device, rb, re, stream, engine, s_rows, s_period, flags)
         h = C.c_void_p()
         _check(load_library().amber_host_pt_create(scene._h, C.byref(sensor), C.byref(p), C.byref(h)), host=True)
         self._h = h
@@ -312,14 +318,18 @@ class PathTracer:
         _check(load_library().amber_hip_pt_kernel_time(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
-    def lt_trace(self, first_sample: int, n_samples: int, capacity: int = 1 << 16):
-        """Light tracing (algorithm_lt.cc): splats of W*H light paths per pass, sorted (pass, path, bounce).
-        Returns (structured numpy array of records, ray count)."""
+    def lt_trace(self, first_sample: int, n_samples: int, capacity: int = 1 << 16, paths=None):
+        """Light tracing (algorithm_lt.cc): splats of W*H light paths per pass (or of the light paths [paths[0], paths[1])),
+        sorted (pass, path, bounce).  Returns (structured numpy array of records, ray count)."""
         dt = np.dtype([("path", np.uint32), ("sample", np.uint32), ("bounce", np.uint32), ("pixel", np.uint32), ("rgb", np.float32, (3,)), ("pad", np.uint32)])
         while True:
             out = np.zeros(capacity, dt)
             n, rays = C.c_uint32(), C.c_uint64()
-            rc = load_library().amber_hip_lt_trace(self._h, first_sample, n_samples, out.ctypes.data, capacity, C.byref(n), C.byref(rays))
+            if paths is None:
+                rc = load_library().amber_hip_lt_trace(self._h, first_sample, n_samples, out.ctypes.data, capacity, C.byref(n), C.byref(rays))
+            else:
+                rc = load_library().amber_hip_lt_trace_range(self._h, first_sample, n_samples, paths[0], paths[1], out.ctypes.data, capacity,
+                                                             C.byref(n), C.byref(rays))
             if rc == -4 and n.value > capacity:
                 capacity = n.value
                 continue
@@ -365,6 +375,13 @@ class PathTracer:
         rows, width, _ = self.band_shape
         out = np.zeros((rows, width, n_samples), np.uint64)
         _check(load_library().amber_hip_kat_signatures(self._h, first_sample, n_samples, out.ctypes.data))
+        return out
+
+    def render_signatures(self, first_sample: int, n_samples: int) -> np.ndarray:
+        """kat_signatures' layout and meaning, produced by the PRODUCT render kernel (its signature instantiation)."""
+        rows, width, _ = self.band_shape
+        out = np.zeros((rows, width, n_samples), np.uint64)
+        _check(load_library().amber_hip_pt_signatures(self._h, first_sample, n_samples, out.ctypes.data))
         return out
 
     def close(self):

@@ -43,7 +43,7 @@ struct Option {
   std::uint64_t seed = 12345;
   int device = 0;
   std::vector<int> devices;          // --devices N = ordinals 0..N-1, --device-list a,b,c = exactly those (repeats allowed)
-  std::uint32_t max_depth = 0, engine = 0, samples_per_launch = 32;
+  std::uint32_t max_depth = 0, engine = 0, samples_per_launch = 0;   // 0 = batches adapt to time (rendering.h)
   bool help = false;
 };
 

@@ -8,6 +8,8 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <chrono>
+#include <map>
 #include <thread>
 #include <vector>
 #include <type_traits>
@@ -400,15 +402,21 @@ const Image<RGB> HipPathTracing::Render(const Scene<RGB>& scene, const Sensor& s
     std::vector<std::thread> workers;
     for (uint32_t r = 0; r < n_dev; r++)
       workers.emplace_back([&, r] {
-        AmberPtParams p{};
-        p.seed = options_.seed; p.max_depth = options_.max_depth; p.device = devices[r]; p.engine = options_.engine;
-        p.row_begin = rb; p.row_end = re;
-        if (n_dev > 1) {
-          p.row_begin = std::min(rb + r * kStripe, re); p.row_end = re;
-          p.stripe_rows = kStripe; p.stripe_period = kStripe * n_dev;
-          if (p.row_begin == p.row_end && p.row_begin == 0) return;       // empty image: nothing to create (0,0 would mean "all rows")
+        try {                                                            // an exception must not leave a std::thread (std::terminate)
+          AmberPtParams p{};
+          p.seed = options_.seed; p.max_depth = options_.max_depth; p.device = devices[r]; p.engine = options_.engine; p.reserved = options_.flags;
+          p.row_begin = rb; p.row_end = re;
+          if (n_dev > 1) {
+            p.row_begin = std::min(rb + r * kStripe, re); p.row_end = re;
+            p.stripe_rows = kStripe; p.stripe_period = kStripe * n_dev;
+            if (p.row_begin == p.row_end && p.row_begin == 0) return;     // empty image: nothing to create (0,0 would mean "all rows")
+          }
+          if (amber_hip_pt_create(&fs.flat, &s, &p, &handles[r].h) != AMBER_OK) errors[r] = amber_hip_last_error();   // thread-local message
+        } catch (const std::exception& e) {
+          errors[r] = std::string("exception: ") + e.what();
+        } catch (...) {
+          errors[r] = "unknown exception";
         }
-        if (amber_hip_pt_create(&fs.flat, &s, &p, &handles[r].h) != AMBER_OK) errors[r] = amber_hip_last_error();   // thread-local message
       });
     for (auto& w : workers) w.join();
   }
@@ -416,23 +424,34 @@ const Image<RGB> HipPathTracing::Render(const Scene<RGB>& scene, const Sensor& s
     if (!errors[r].empty()) throw std::runtime_error("amber_hip_pt_create (device " + std::to_string(devices[r]) + "): " + errors[r]);
 
   // Context contract (context.cc:48-60): each successful Iterate() is one whole-image sample.
-  // Claim up to samples_per_launch passes, render them on every handle (launches are asynchronous: the devices run
-  // concurrently), wait for all, repeat until Iterate() fails.
-  const uint32_t batch = options_.samples_per_launch ? options_.samples_per_launch : 1;
+  // Claim a batch of passes, render them on every handle (launches are asynchronous: the devices run concurrently), wait
+  // for all, repeat until Iterate() fails.  samples_per_launch = 0 (default): the batch adapts to TIME -- it starts at one
+  // accumulation chunk and doubles while a batch takes less than kBatchTargetMs, so that expiry (--time, SIGINT) and the
+  // progress line stay responsive whatever the scene costs, and a long render does not synchronise with the host every 64
+  // samples (round 2: `--spp 1024` was 16 launches + 16 host synchronisations per device).  Batches are multiples of the
+  // chunk, so the summation order -- and every bit of the image -- is that of one launch.
+  constexpr double kBatchTargetMs = 100.0;
+  constexpr uint32_t kBatchMax = 4096;
+  const bool adaptive = options_.samples_per_launch == 0;
+  uint32_t batch = adaptive ? AMBER_ACCUM_CHUNK : options_.samples_per_launch;
   uint32_t first = 0;
   for (;;) {
     uint32_t n = 0;
     while (n < batch && context.Iterate()) n++;
     if (n == 0) break;
+    const auto t0 = std::chrono::steady_clock::now();
     for (auto& hd : handles) if (hd.h) Check(amber_hip_pt_render_pass(hd.h, first, n), "amber_hip_pt_render_pass");
     for (auto& hd : handles) if (hd.h) Check(amber_hip_pt_sync(hd.h), "amber_hip_pt_sync");   // bounded run-ahead: progress polling stays truthful
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     first += n;
     stats_.passes += n;
     if (n < batch) break;
+    if (adaptive && ms < kBatchTargetMs && batch < kBatchMax) batch *= 2;
   }
 
   auto image = sensor.CreateImage<RGB>();
   std::vector<float> band;
+  std::map<int, double> device_ms;
   for (uint32_t r = 0; r < n_dev; r++) {
     if (!handles[r].h) continue;
     uint32_t local_rows = 0;
@@ -444,7 +463,7 @@ const Image<RGB> HipPathTracing::Render(const Scene<RGB>& scene, const Sensor& s
     uint32_t launches = 0; double ms = 0;
     Check(amber_hip_pt_kernel_time(handles[r].h, &launches, &ms), "amber_hip_pt_kernel_time");
     stats_.launches += launches;
-    stats_.kernel_ms = std::max(stats_.kernel_ms, ms);           // the devices run side by side
+    device_ms[devices[r]] += ms;                                 // handles on one device run one after another ...
     // local row l of handle r is global row y: contiguous band, or the l-th row of its stripes
     const uint32_t y0 = n_dev > 1 ? std::min(rb + r * kStripe, re) : rb;
     for (uint32_t l = 0; l < local_rows; l++) {
@@ -455,6 +474,7 @@ const Image<RGB> HipPathTracing::Render(const Scene<RGB>& scene, const Sensor& s
       }
     }
   }
+  for (const auto& kv : device_ms) stats_.kernel_ms = std::max(stats_.kernel_ms, kv.second);   // ... distinct devices side by side
   // Accumulator::Mean (accumulator.h:88-95): Sum() / size_ -- component-wise binary32 division
   if (stats_.passes) image /= RGB(static_cast<real_type>(stats_.passes));
   return image;
@@ -466,32 +486,75 @@ const Image<RGB> HipLightTracing::Render(const Scene<RGB>& scene, const Sensor& 
   stats_ = HipPathTracingStats();
   const scene::FlatScene fs = scene.Flatten();
   AmberSensor s{static_cast<uint32_t>(sensor.Width()), static_cast<uint32_t>(sensor.Height()), sensor.SceneWidth(), sensor.SceneHeight()};
-  AmberPtParams p{};
-  p.seed = options_.seed; p.max_depth = options_.max_depth; p.device = options_.device; p.engine = options_.engine;
-  Handle handle;
-  Check(amber_hip_pt_create(&fs.flat, &s, &p, &handle.h), "amber_hip_pt_create");
+  // One handle per listed device, each with the whole scene and sensor.  Light paths are independent (the sampler is
+  // seeded per (light path, pass)), so the path INDEX shards across the devices the way rows do for path tracing
+  // (the reference parallelises lt exactly like pt: algorithm_lt.cc:82-95 -> ParallelMean): device r traces the
+  // paths [r P / N, (r + 1) P / N) of every claimed pass, on a host thread of its own (amber_hip_lt_trace_range is
+  // synchronous), and the splat lists -- each sorted (pass, path, bounce), over disjoint path ranges -- are merged into
+  // the reference's accumulation order before they are added.  The image is bit-identical to one device's.
+  const std::vector<int> devices = options_.devices.empty() ? std::vector<int>{options_.device} : options_.devices;
+  const uint32_t n_dev = static_cast<uint32_t>(devices.size());
+  const uint32_t n_paths = s.width * s.height;
+  std::vector<Handle> handles(n_dev);
+  for (uint32_t r = 0; r < n_dev; r++) {
+    AmberPtParams p{};
+    p.seed = options_.seed; p.max_depth = options_.max_depth; p.device = devices[r]; p.engine = options_.engine; p.reserved = options_.flags;
+    Check(amber_hip_pt_create(&fs.flat, &s, &p, &handles[r].h), "amber_hip_pt_create");
+  }
   auto sum = sensor.CreateImage<RGB>();
-  std::vector<AmberSplat> splats(1u << 16);
-  const uint32_t batch = options_.samples_per_launch ? options_.samples_per_launch : 1;
+  std::vector<std::vector<AmberSplat>> lists(n_dev, std::vector<AmberSplat>(1u << 16));
+  std::vector<uint32_t> counts(n_dev, 0);
+  std::vector<uint64_t> rays(n_dev, 0);
+  std::vector<std::string> errors(n_dev);
+  std::vector<AmberSplat> merged;
+  const uint32_t batch = options_.samples_per_launch ? options_.samples_per_launch : 64;
   uint32_t first = 0;
   for (;;) {
     uint32_t n = 0;
     while (n < batch && context.Iterate()) n++;
     if (n == 0) break;
-    uint32_t n_out = 0; uint64_t rays = 0;
-    int rc = amber_hip_lt_trace(handle.h, first, n, splats.data(), static_cast<uint32_t>(splats.size()), &n_out, &rays);
-    if (rc == AMBER_ENOMEM && n_out > splats.size()) {      // grow once and repeat the (deterministic) batch
-      splats.resize(n_out);
-      rc = amber_hip_lt_trace(handle.h, first, n, splats.data(), static_cast<uint32_t>(splats.size()), &n_out, &rays);
+    auto trace = [&](uint32_t r) {
+      try {
+        const uint32_t p0 = static_cast<uint32_t>(static_cast<uint64_t>(n_paths) * r / n_dev), p1 = static_cast<uint32_t>(static_cast<uint64_t>(n_paths) * (r + 1) / n_dev);
+        int rc = amber_hip_lt_trace_range(handles[r].h, first, n, p0, p1, lists[r].data(), static_cast<uint32_t>(lists[r].size()), &counts[r], &rays[r]);
+        if (rc == AMBER_ENOMEM && counts[r] > lists[r].size()) {    // grow once and repeat the (deterministic) batch
+          lists[r].resize(counts[r]);
+          rc = amber_hip_lt_trace_range(handles[r].h, first, n, p0, p1, lists[r].data(), static_cast<uint32_t>(lists[r].size()), &counts[r], &rays[r]);
+        }
+        if (rc != AMBER_OK) errors[r] = amber_hip_last_error();
+      } catch (const std::exception& e) { errors[r] = std::string("exception: ") + e.what(); }
+        catch (...) { errors[r] = "unknown exception"; }
+    };
+    if (n_dev == 1) trace(0);
+    else {
+      std::vector<std::thread> workers;
+      for (uint32_t r = 0; r < n_dev; r++) workers.emplace_back(trace, r);
+      for (auto& w : workers) w.join();
     }
-    Check(rc, "amber_hip_lt_trace");
-    stats_.rays += rays; stats_.launches++;
+    for (uint32_t r = 0; r < n_dev; r++)
+      if (!errors[r].empty()) throw std::runtime_error("amber_hip_lt_trace_range (device " + std::to_string(devices[r]) + "): " + errors[r]);
+    const AmberSplat* all = lists[0].data();
+    uint32_t n_out = counts[0];
+    if (n_dev > 1) {
+      merged.clear();
+      for (uint32_t r = 0; r < n_dev; r++) merged.insert(merged.end(), lists[r].begin(), lists[r].begin() + counts[r]);
+      // (pass, path, bounce): within a pass the devices' path ranges ascend with r, so a stable sort by pass would do;
+      // the full key keeps the order independent of how the ranges were cut
+      std::sort(merged.begin(), merged.end(), [](const AmberSplat& x, const AmberSplat& y) {
+        if (x.sample != y.sample) return x.sample < y.sample;
+        if (x.path != y.path) return x.path < y.path;
+        return x.bounce < y.bounce;
+      });
+      all = merged.data(); n_out = static_cast<uint32_t>(merged.size());
+    }
+    for (uint32_t r = 0; r < n_dev; r++) stats_.rays += rays[r];
+    stats_.launches++;
     uint32_t k = 0;
     for (uint32_t pass = first; pass < first + n; pass++) {
-      if (k >= n_out || splats[k].sample != pass) continue;
+      if (k >= n_out || all[k].sample != pass) continue;
       auto image = sensor.CreateImage<RGB>();                // one pass image, algorithm_lt.cc:115-122
-      for (; k < n_out && splats[k].sample == pass; k++)
-        image[Pixel(splats[k].pixel % s.width, splats[k].pixel / s.width)] += RGB(splats[k].rgb[0], splats[k].rgb[1], splats[k].rgb[2]);
+      for (; k < n_out && all[k].sample == pass; k++)
+        image[Pixel(all[k].pixel % s.width, all[k].pixel / s.width)] += RGB(all[k].rgb[0], all[k].rgb[1], all[k].rgb[2]);
       sum += image;
     }
     first += n; stats_.passes += n;

@@ -73,7 +73,9 @@ struct HipPathTracingOptions {
   // of ITS rows, the row sums are copied straight to the host image.  Pixels are independent under the per-(pixel,sample)
   // sampler, so the image is bit-identical to a single-device render.
   std::vector<int> devices;
-  std::uint32_t samples_per_launch = 64;   // Context::Iterate() calls claimed per kernel launch (upper bound)
+  std::uint32_t samples_per_launch = 0;    // Context::Iterate() calls claimed per kernel launch; 0 = adapt to time: start at one
+                                           // accumulation chunk, double while a batch takes < 100 ms (expiry latency stays bounded)
+  std::uint32_t flags = 0;          // AMBER_PT_FLAG_* bits passed to every handle
   std::uint32_t row_begin = 0, row_end = 0;   // framebuffer band; 0,0 = whole image
   std::uint32_t engine = 0;         // AMBER_ENGINE_*
 };

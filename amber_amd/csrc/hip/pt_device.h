@@ -3,9 +3,12 @@
 // Arithmetic contract (DESIGN.md "Numerics"): every float operation below is a single IEEE
 // binary32 operation in the order the reference performs it; the translation unit is built with
 // -ffp-contract=off (the reference's x86 build has no FMA) and hipcc's default correctly rounded
-// f32 divide/sqrt and un-flushed subnormals.  No OCML math call is on the path: sin/cos/pow are
-// the "portable" forms specified in DESIGN.md (Cephes-style reduction + polynomials, atanh-series
-// log, Taylor exp), built from + - * / only, so the CPU oracle reproduces them bit-for-bit.
+// f32 divide/sqrt and un-flushed subnormals.  No OCML math call is on the path: sin / cos / pow
+// execute glibc 2.35's binary32 sincosf / powf -- double-precision kernels, fused multiply-adds
+// where the x86-64 FMA variant has them, one rounding to binary32 at the end -- operation for
+// operation (section "sin / cos / pow" below), so the CPU oracle and the live libm the reference
+// calls produce the same bits.  (-DAMBER_BUILD_PORTABLE_MATH builds round 1's own + - * / forms
+// instead; a measurement build, never the product.)
 //
 // Reference citations are relative to /root/reference.
 #pragma once
@@ -45,9 +48,19 @@ __device__ __forceinline__ void CountAt(StampCtx* c, int k) {
 #define AMBER_COUNT(k) CountAt(stamp_ctx, k)
 #define AMBER_CLK(k)
 #endif
+/* -DAMBER_COUNT_ALT: slots 2 and 3 count leaf-phase executions and ray swaps instead of rounds and shading calls */
+#ifdef AMBER_COUNT_ALT
+#define AMBER_COUNT_ROUNDS(k)
+#define AMBER_COUNT_LEAVES(k) AMBER_COUNT(k)
+#else
+#define AMBER_COUNT_ROUNDS(k) AMBER_COUNT(k)
+#define AMBER_COUNT_LEAVES(k)
+#endif
 #define AMBER_STAMP_PARAM_OPT , StampCtx* stamp_ctx = nullptr
 #else
 #define AMBER_COUNT(k)
+#define AMBER_COUNT_ROUNDS(k)
+#define AMBER_COUNT_LEAVES(k)
 #define AMBER_CLK(k)
 #define AMBER_STAMP_PARAM_OPT
 #define AMBER_STAMP_PARAM
@@ -867,7 +880,7 @@ __device__ __forceinline__ void SphereCoefficients(float4 s, V3 o, V3 d, float& 
   c = SquaredLength(co) - s.w * s.w;
 }
 __device__ __forceinline__ void IntersectSphereLeaf(const DevScene& sc, uint32_t first, uint32_t count, V3 o, V3 d, HitRec& best AMBER_STAMP_PARAM_OPT) {
-  const float4* sp = sc.bvh_spheres + first;
+  const float4* sp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.bvh_spheres) + (first << 4));   // uniform base + 32-bit offset
   const float4 s0 = sp[0], s1 = sp[count > 1u ? 1u : 0u], s2 = sp[count > 2u ? 2u : 0u];
   float b0, c0, b1, c1, b2, c2;
   SphereCoefficients(s0, o, d, b0, c0); SphereCoefficients(s1, o, d, b1, c1); SphereCoefficients(s2, o, d, b2, c2);
@@ -906,14 +919,52 @@ __device__ __forceinline__ void IntersectSphereLeaf(const DevScene& sc, uint32_t
 #ifndef AMBER_BVH_DESCENT_BUDGET
 #define AMBER_BVH_DESCENT_BUDGET 5
 #endif
-__device__ __forceinline__ void BvhDescend(const DevScene& sc, int32_t* lds_stack, BvhTrav& tr, const float t_best, const int stack_cap AMBER_STAMP_PARAM_OPT) {
-  int32_t* stack = lds_stack + threadIdx.x;          // element k at stack[k * blockDim.x]
-  const uint32_t stride = 256u;                      // every kernel that traverses is launched with 256 threads
+// Where a lane keeps the far children it has not visited yet.
+//  BvhStackLds     the whole stack in LDS, [level][thread of the workgroup] (conflict-free ds_read/write_b32); a push beyond
+//                  `cap` sets the overflow flag (the caller then falls back to the list scan; cannot happen with the
+//                  builder's depth cap).
+//  BvhStackHybrid  pt_bvh_pool_kernel: the first `lds_levels` levels in LDS, [level][lane of the wave]; deeper levels in
+//                  global memory, [level][thread of the grid] (coalesced; one lane's store -> load of the same address is
+//                  ordered like scratch memory is).  1M-sphere scene: a ray pushes 6.9 entries, 1.1 % of them at depth >= 8.
+struct BvhStackLds {
+  int32_t* base; int cap;                              // base = lds_stack + threadIdx.x; every kernel that uses it runs 256 threads
+  __device__ __forceinline__ void push(int& sp, int32_t v, bool& overflow) const { if (sp < cap) { base[sp * 256] = v; ++sp; } else overflow = true; }
+  __device__ __forceinline__ int32_t pop(int& sp) const { --sp; return base[sp * 256]; }
+};
+typedef int32_t __attribute__((address_space(3)))* LdsInts;
+typedef int32_t __attribute__((address_space(1)))* GlobalInts;
+struct BvhStackHybrid {
+  LdsInts lds;               // WAVE-UNIFORM (SGPR): the wave's [level][lane] block
+  GlobalInts glob;           // WAVE-UNIFORM: column of the wave's lane 0 in the global levels
+  uint32_t glob_stride; int lds_levels, cap;
+  // The pointers carry their address spaces on purpose.  With generic pointers the compiler turns "LDS level or global
+  // level" into a select between two POINTERS and one flat_load (generic address, both memory counters, a full s_waitcnt)
+  // on every pop, and spills the operands of the address it then keeps -- measured on the 1M-sphere scene: every traversal
+  // trip 1.85x slower.  The lane index is recomputed where it is used (opaque to the optimiser, or it is hoisted and spilled).
+  static __device__ __forceinline__ uint32_t LaneId() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  }
+  __device__ __forceinline__ void push(int& sp, int32_t v, bool& overflow) const {
+    if (sp < lds_levels) lds[sp * 64 + static_cast<int>(LaneId())] = v;
+    else if (sp < cap) glob[static_cast<uint32_t>(sp - lds_levels) * glob_stride + LaneId()] = v;
+    else { overflow = true; return; }
+    ++sp;
+  }
+  __device__ __forceinline__ int32_t pop(int& sp) const {
+    --sp;
+    if (sp < lds_levels) return lds[sp * 64 + static_cast<int>(LaneId())];
+    return glob[static_cast<uint32_t>(sp - lds_levels) * glob_stride + LaneId()];
+  }
+};
+template <class Stack>
+__device__ __forceinline__ void BvhDescend(const DevScene& sc, const Stack& stack, BvhTrav& tr, const float t_best AMBER_STAMP_PARAM_OPT) {
   int32_t cur = tr.cur, pend = tr.pend;
   int sp = tr.sp;
   AMBER_CLK(4);
 #define AMBER_BVH_PARK() \
-  if (cur < 0 && pend == 0) { pend = cur; if (sp > 0) { --sp; cur = stack[sp * stride]; } else cur = AMBER_BVH_DONE; }
+  if (cur < 0 && pend == 0) { pend = cur; if (sp > 0) cur = stack.pop(sp); else cur = AMBER_BVH_DONE; }
   AMBER_BVH_PARK();
   int budget = AMBER_BVH_DESCENT_BUDGET;
   while (cur >= 0 && cur != AMBER_BVH_DONE && budget-- > 0) {
@@ -944,17 +995,18 @@ __device__ __forceinline__ void BvhDescend(const DevScene& sc, int32_t* lds_stac
 #undef AMBER_CSWAP
     if (n_hit > 0) {
       // the others go on the stack, the farthest first
-      if (n_hit > 3) { if (sp < stack_cap) { stack[sp * stride] = r3; ++sp; } else tr.overflow = true; }
-      if (n_hit > 2) { if (sp < stack_cap) { stack[sp * stride] = r2; ++sp; } else tr.overflow = true; }
-      if (n_hit > 1) { if (sp < stack_cap) { stack[sp * stride] = r1; ++sp; } else tr.overflow = true; }
+      if (n_hit > 3) stack.push(sp, r3, tr.overflow);
+      if (n_hit > 2) stack.push(sp, r2, tr.overflow);
+      if (n_hit > 1) stack.push(sp, r1, tr.overflow);
       cur = r0;
     } else if (sp > 0) {
-      --sp; cur = stack[sp * stride];
+      cur = stack.pop(sp);
     } else {
       cur = AMBER_BVH_DONE;
     }
 #else
-    const uint4* nd = reinterpret_cast<const uint4*>(sc.bvh_nodes + cur);
+    // uniform base + 32-bit byte offset (the tree is < 4 GB): global_load with an SGPR base, no 64-bit address arithmetic per visit
+    const uint4* nd = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.bvh_nodes) + (static_cast<uint32_t>(cur) << 5));
     const uint4 p = nd[0], q = nd[1];
     const int32_t left = static_cast<int32_t>(q.z), right = static_cast<int32_t>(q.w);
     // rotate each axis word so that the entry plane is the low half, convert (v_cvt_f32_u32 with a half-word select), one fma
@@ -975,15 +1027,14 @@ __device__ __forceinline__ void BvhDescend(const DevScene& sc, int32_t* lds_stac
     if (hl && hr) {
       const bool left_first = !(tr_ < tl);
       const int32_t near_ = left_first ? left : right, far_ = left_first ? right : left;
-      if (sp < stack_cap) { stack[sp * stride] = far_; ++sp; }
-      else tr.overflow = true;                         // stay correct anyway (list scan at the end)
+      stack.push(sp, far_, tr.overflow);              // overflow: stay correct anyway (list scan at the end)
       cur = near_;
     } else if (hl) {
       cur = left;
     } else if (hr) {
       cur = right;
     } else if (sp > 0) {
-      --sp; cur = stack[sp * stride];
+      cur = stack.pop(sp);
     } else {
       cur = AMBER_BVH_DONE;
     }
@@ -997,6 +1048,7 @@ __device__ __forceinline__ void BvhDescend(const DevScene& sc, int32_t* lds_stac
 
 // Exact tests of one leaf by the lane that owns the ray.
 __device__ __forceinline__ void BvhLeafPrivate(const DevScene& sc, int32_t leaf, V3 o, V3 d, HitRec& best AMBER_STAMP_PARAM_OPT) {
+  AMBER_COUNT_LEAVES(2);
   const uint32_t ref = static_cast<uint32_t>(-(leaf + 1));
   const uint32_t first = ref >> 3, count = ref & 3u;
   if (ref & 4u) {                                           // spheres only: one 16-byte record each
@@ -1024,10 +1076,15 @@ __device__ __forceinline__ void BvhLeafPhase(const DevScene& sc, V3 o, V3 d, Bvh
 }
 
 // One round for a lane on its own; returns false when the traversal is complete.
-__device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, BvhTrav& tr, HitRec& best, const int stack_cap = AMBER_BVH_STACK AMBER_STAMP_PARAM_OPT) {
-  BvhDescend(sc, lds_stack, tr, best.t, stack_cap AMBER_STAMP_ARG);
+template <class Stack>
+__device__ __forceinline__ bool BvhRoundOn(const DevScene& sc, const Stack& stack, V3 o, V3 d, BvhTrav& tr, HitRec& best AMBER_STAMP_PARAM_OPT) {
+  BvhDescend(sc, stack, tr, best.t AMBER_STAMP_ARG);
   BvhLeafPhase(sc, o, d, tr, best AMBER_STAMP_ARG);
   return tr.cur != AMBER_BVH_DONE || tr.pend != 0;
+}
+__device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, BvhTrav& tr, HitRec& best, const int stack_cap = AMBER_BVH_STACK AMBER_STAMP_PARAM_OPT) {
+  const BvhStackLds stack{lds_stack + threadIdx.x, stack_cap};
+  return BvhRoundOn(sc, stack, o, d, tr, best AMBER_STAMP_ARG);
 }
 
 __device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, HitRec& best) {

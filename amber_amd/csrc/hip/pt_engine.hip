@@ -1,11 +1,19 @@
 // pt_engine.hip -- kernels and C ABI (include/amber_hip.h) of the gfx950 path-tracing engine.
 //
-// Engine MEGAKERNEL (this file): persistent waves pull work items (pixel, chunk of 8 samples) from one global
-// queue; a lane whose path ended regenerates the next eye ray in place, so every loop iteration of a wave performs
-// one closest-hit query for each lane that still has work.  Ray / throughput / sampler state never leaves VGPRs;
-// scene records are read with wave-uniform indices through scalar loads (two-phase / list engines) or per lane
-// through a flattened BVH.  HBM traffic: one 12-byte item sum per (pixel, chunk), reduced into the framebuffer by
-// reduce_partials_kernel in chunk order.  wavefront.inc holds the streaming (SoA queues in HBM) formulation.
+// Persistent work-queue kernels.  The work unit is ONE PATH, numbered q = (band pixel) * n_samples + (sample offset)
+// within a launch; a wave claims blocks of consecutive paths with one atomicAdd on the global queue head.
+//   pt_megakernel       (<= 32 objects: engines LIST / TWO_PHASE; also light tracing) -- lanes are decoupled from pixels:
+//                       eye rays are generated 64 at a time into a per-wave pool in LDS, a lane whose path ended pops the
+//                       next ray (ballot + mbcnt rank); ray / throughput / sampler state lives in VGPRs; scene records
+//                       arrive through scalar loads (wave-uniform indices).
+//   pt_bvh_pool_kernel  (engine BVH, bvh_pool.inc) -- 64 rays in flight on the lanes plus a pool of waiting rays per wave
+//                       in LDS: a lane whose traversal finished swaps its ray for a waiting one at once, finished rays
+//                       are shaded in batches; resumable traversal with a short per-lane stack in LDS.
+//   pt_bvh_megakernel   (engine BVH, light tracing only) -- round 2's form: lanes own (pixel, chunk) items.
+// Accumulation without owners: a path that ends with a non-zero measurement appends a record {q, rgb} (slots reserved
+// per wave, 64 at a time) and sets bit q of a bitmap; rec_rank_kernel / rec_place_kernel move the records into path order
+// and reduce_flagged_kernel forms, per pixel, exactly the sums of the numerical contract.
+// wavefront.inc holds the streaming (SoA queues in HBM, one launch per bounce) formulation, kept for measurement.
 //
 // Replaces: PathTracing<RGB>::Thread::operator() / Render
 //           (/root/reference/src/amber/rendering/algorithm_pt.cc:112-160).
@@ -44,41 +52,88 @@ int Fail(int code, const std::string& msg) { g_last_error = msg; return code; }
 struct RenderArgs {
   DevScene scene;
   float* partial;            // pt_bvh_megakernel: [n_chunks][n_pixels][3] per-item sums of this launch
-  uint32_t* flags;           // pt_megakernel: bit q set = path q of this launch ended with a non-zero measurement ...
-  float* values;             // ... stored in values[3q .. 3q+2]
+  uint32_t* flags;           // path-granular kernels: bit q set = path q of this launch ended with a non-zero measurement ...
+  uint4* records;            // ... appended as {q, r, g, b}; q = 0xffffffff marks a reserved slot that was never used
+  unsigned int* rec_count;   // slots handed out so far (waves reserve AMBER_REC_BLOCK at a time)
+  uint32_t rec_capacity;     // slots of `records`; a launch that needs more is repeated by the host with a larger buffer
   unsigned long long* ray_count;
   unsigned int* next_item;   // work-queue head (zeroed before every launch)
   unsigned long long* stamps; // diagnostic build only (AMBER_STAMPS): 8 section sums
   DevSplat* splats;          // light tracing: splat records, their counter and capacity
   unsigned int* splat_count;
   uint32_t splat_capacity;
+  int32_t* bvh_stack;        // pt_bvh_pool_kernel: traversal-stack levels beyond the LDS part, [level][thread of the grid]
+  float* carried;            // pt_bvh_pool_kernel: measurements of the (degenerate) paths that carry a non-zero one across bounces, [thread of the grid * kRays/64 ...]
+  unsigned long long* sig;   // signature variants: sig[q] = the path's hit-object / hit-distance hashes (amber_hip_pt_signatures)
   uint64_t hashed_seed;      // SplitMix64(global_seed)
   uint32_t row_begin;
   uint32_t stripe_rows, stripe_period;   // 0,0 = contiguous rows
   uint32_t n_pixels;         // pixels of the band
   uint32_t first_sample, n_samples;
-  uint32_t n_chunks, n_items;   // pt_bvh_megakernel: items = (pixel, chunk); pt_megakernel: n_items = paths of the launch
+  uint32_t n_chunks, n_items;   // pt_bvh_megakernel: items = (pixel, chunk); path-granular kernels: n_items = paths of the launch
+  uint32_t path_offset;      // light tracing: index of the first light path of this launch's range (amber_hip_lt_trace_range)
 };
+
+// FNV-1a-32 step over the four bytes of v (path signatures: amber_hip_kat_signatures, amber_hip_pt_signatures)
+__device__ __forceinline__ uint32_t Fnv32(uint32_t h, uint32_t v) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) { h ^= (v >> (8 * k)) & 0xffu; h *= 16777619u; }
+  return h;
+}
+
+// Accumulation without owners, device side.  A path that ends with a measurement other than +0 appends {q, rgb} to the
+// record buffer and sets bit q.  Slots are reserved per WAVE, AMBER_REC_BLOCK at a time (one atomicAdd on the shared
+// counter per 64 records: a scene in which every second path reaches a light would otherwise put 5e8 atomics on one
+// address -- the L2 retires ~88 of those per microsecond); [rec_next, rec_end) is the wave's open block (SGPRs).  Must be
+// called with all 64 lanes active.  A slot beyond the buffer is not written: the counter then tells the host to repeat
+// the launch with a larger buffer (RenderPassPaths).
+#define AMBER_REC_BLOCK 64u
+#define AMBER_REC_UNUSED 0xffffffffu
+__device__ __forceinline__ void EmitRecords(const RenderArgs& a, bool emit, uint32_t q, V3 meas, uint32_t& rec_next, uint32_t& rec_end) {
+  const unsigned long long me = __ballot(emit);
+  if (me == 0ull) return;                                     // wave-uniform
+  const uint32_t n = static_cast<uint32_t>(__popcll(me));
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(me >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(me), 0u));
+  const uint32_t room = rec_end - rec_next;
+  uint32_t fresh = 0;
+  if (n > room) {                                             // n <= 64 = AMBER_REC_BLOCK: one new block always suffices
+    if ((threadIdx.x & 63u) == 0u) fresh = atomicAdd(a.rec_count, AMBER_REC_BLOCK);
+    fresh = __builtin_amdgcn_readfirstlane(fresh);
+  }
+  if (emit) {
+    const uint32_t slot = rank < room ? rec_next + rank : fresh + (rank - room);
+    if (slot < a.rec_capacity) a.records[slot] = make_uint4(q, __float_as_uint(meas.x), __float_as_uint(meas.y), __float_as_uint(meas.z));
+    atomicOr(a.flags + (q >> 5), 1u << (q & 31u));
+  }
+  if (n > room) { rec_next = fresh + (n - room); rec_end = fresh + AMBER_REC_BLOCK; }
+  else rec_next += n;
+}
+// At the end of a wave: the slots of its open block that were never used are marked.
+__device__ __forceinline__ void CloseRecords(const RenderArgs& a, uint32_t rec_next, uint32_t rec_end) {
+  const uint32_t k = rec_next + (threadIdx.x & 63u);
+  if (k < rec_end && k < a.rec_capacity) a.records[k].x = AMBER_REC_UNUSED;
+}
 
 // pt_megakernel: persistent waves, work unit = ONE PATH, lanes decoupled from pixels.
 //
 //  * Paths of a launch are numbered q = plocal * n_samples + k (band pixel, sample offset): 64 consecutive paths are 64
-//    samples of one pixel (coherent eye rays, first hits and materials).  A wave claims 64 paths with ONE atomicAdd on
-//    the global queue head.
+//    samples of one pixel (coherent eye rays, first hits and materials).  A wave claims AMBER_CLAIM_PATHS paths with ONE
+//    atomicAdd on the global queue head.
 //  * Eye rays are generated 64 at a time, by ALL lanes of the wave, into the wave's pool in LDS (SoA, 64 slots); a lane
 //    whose path has ended pops the next ray from the pool (ballot + mbcnt rank), whichever path that is.  Round 1's
 //    kernel regenerated in place, i.e. the whole wave executed the eye-ray code for the half of its lanes whose paths had
 //    just ended -- 16 % of the kernel at 48 % lane utilisation; here that code runs once per 64 paths with every lane
 //    busy, and no lane ever waits: a generation round happens only when the pool cannot serve a lane.
 //  * Accumulation.  Lanes no longer own pixels, so a path that ends with a non-zero measurement (it reached a light:
-//    2e-5 of the Cornell paths) stores it to values[q] and sets bit q of a bitmap; reduce_flagged_kernel then forms, per
-//    pixel, exactly the sums of the numerical contract -- samples of a chunk of AMBER_ACCUM_CHUNK in order, chunk sums
-//    added to the framebuffer in chunk order -- skipping the +0 terms, which is exact: a running
-//    binary32 sum that starts at +0 never becomes -0, and x + (+0) = x for every other x.  HBM traffic per launch: the
-//    bitmap (n_paths / 8 bytes, cleared and read once) and the few values -- round 1 wrote 12 B per (pixel, chunk), 5.5 GB
-//    per config-2 launch after write amplification; values[] is address space that is touched only where a bit is set.
+//    2e-5 of the Cornell paths) appends a record {q, rgb} and sets bit q of a bitmap (EmitRecords); the rank / place /
+//    reduce kernels below then form, per pixel, exactly the sums of the numerical contract -- samples of a chunk of
+//    AMBER_ACCUM_CHUNK in order, chunk sums added to the framebuffer in chunk order -- skipping the
+//    +0 terms, which is exact: a running binary32 sum that starts at +0 never becomes -0, and x + (+0) = x for every
+//    other x.  HBM per launch: the bitmap (n_paths / 8 bytes, cleared and read once) and 16 B per record.
 //  * kLight: the same worker loop traces LIGHT paths (algorithm_lt.cc:112-163): path q = (light path index, pass),
 //    nothing is stored at a path's end, Eye hits append splat records instead.
+//  * kSig (tests only, amber_hip_pt_signatures): the same kernel also hashes every cast's hit object and hit distance and
+//    stores the pair at the path's end -- the PRODUCT kernel's paths, compared with the oracle's one by one.
 #ifndef AMBER_MEGAKERNEL_WAVES_PER_SIMD
 #define AMBER_MEGAKERNEL_WAVES_PER_SIMD 6
 #endif
@@ -91,7 +146,7 @@ struct RenderArgs {
 // conflicts); light tracing carries an RGB weight and uses a fourth chunk.
 template <bool kLight> struct PoolLayout { static constexpr int kChunks = kLight ? 4 : 3; };
 
-template <int kEngine, bool kLight = false>
+template <int kEngine, bool kLight = false, bool kSig = false>
 __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megakernel(const RenderArgs a) {
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
@@ -100,10 +155,11 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
   __shared__ DevObject lds_objects[kTwoPhase ? AMBER_MAX_LDS_OBJECTS : 1];
   __shared__ uint4 lds_pool[4][64 * kChunks];                 // [wave][slot * kChunks + chunk]
   if (kTwoPhase) StageObjects(sc, lds_objects);
-  uint4* pool = lds_pool[threadIdx.x >> 6];
+  uint4* pool = lds_pool[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];   // wave-uniform, and the compiler knows it: the pool address stays in an SGPR
 
   uint32_t claim_next = 0, claim_end = 0;    // wave-uniform: paths claimed from the global queue, not yet generated
   uint32_t pool_count = 0;                   // wave-uniform: rays in the pool (slots [0, pool_count))
+  uint32_t rec_next = 0, rec_end = 0;        // wave-uniform: the wave's open block of record slots
   bool exhausted = false;                    // wave-uniform: the global queue is empty
   bool retired = false, alive = false;
   uint32_t q = 0;                            // path of this lane
@@ -113,6 +169,7 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
   uint32_t casts = 0;
   uint32_t rays_wave = 0;                    // wave-uniform (SGPR): rays cast by this wave
   int origin_slot = -1;                      // filter-program slot of the triangle the current ray starts on
+  uint32_t sig_obj = 2166136261u, sig_t = 2166136261u;   // kSig only
 #ifdef AMBER_STAMPS
   StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
   stamp_ctx->last = __builtin_amdgcn_s_memtime();
@@ -147,7 +204,7 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
             const uint32_t plocal = gq / a.n_samples, k = gq - plocal * a.n_samples;
             uint64_t grng; V3 go, gd, gw; int gslot;
             if (kLight) {
-              grng = XorShiftSeed(a.hashed_seed, plocal, a.first_sample + k);
+              grng = XorShiftSeed(a.hashed_seed, a.path_offset + plocal, a.first_sample + k);
               GenerateLightRay(sc, grng, go, gd, gw, gslot);
             } else {
               const uint32_t lrow = plocal / sc.sensor.w;
@@ -164,11 +221,15 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
             if (kLight) pool[lane * kChunks + (kChunks - 1)] = make_uint4(__float_as_uint(gw.y), __float_as_uint(gw.z), 0u, 0u);
           }
           pool_count = n_new;
+          // The pops below read slots that OTHER lanes of this wave have just written.  One wave's LDS instructions execute
+          // in order, so the hardware needs nothing here; the barrier (no instruction: a scheduling fence for the compiler)
+          // pins the order of the stores above and the loads below in the instruction stream.
+          __builtin_amdgcn_wave_barrier();
           AMBER_STAMP(1);
         }
         const uint32_t left = n_need - served;
         const uint32_t take = pool_count < left ? pool_count : left;
-        if (need && !alive && rank >= served && rank < served + take) {      // pop: the wave's own LDS writes are in order, no barrier
+        if (need && !alive && rank >= served && rank < served + take) {      // pop
           const uint32_t sl = pool_count - 1u - (rank - served);
           const uint4 c0 = pool[sl * kChunks + 0], c1 = pool[sl * kChunks + 1], c2 = pool[sl * kChunks + 2];
           o = v3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z));
@@ -181,8 +242,10 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
           else w = v3(wx, wx, wx);
           meas = v3(0.f, 0.f, 0.f);
           casts = 0;
+          if (kSig) { sig_obj = 2166136261u; sig_t = 2166136261u; }
           alive = true;
         }
+        __builtin_amdgcn_wave_barrier();                     // the next generation round overwrites the slots just read
         pool_count -= take; served += take;
         if (served == n_need) break;
       }
@@ -191,22 +254,27 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
     }
 
     rays_wave += static_cast<uint32_t>(__popcll(__ballot(alive)));
+    bool emit = false;
     if (alive) {
       if (kLight) {
         const uint32_t plocal = q / a.n_samples;
-        const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, plocal, a.first_sample + (q - plocal * a.n_samples), sc.sensor.size_f};
+        const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, a.path_offset + plocal, a.first_sample + (q - plocal * a.n_samples), sc.sensor.size_f};
         alive = PathStep<false, kEngine, true>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, &sink);
+      } else if (kSig) {
+        Bounce b;
+        alive = PathStep<true, kEngine>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, &b AMBER_STAMP_ARG);
+        sig_obj = Fnv32(sig_obj, static_cast<uint32_t>(b.object));
+        if (b.object >= 0) sig_t = Fnv32(sig_t, __float_as_uint(b.t));
+        if (!alive) a.sig[q] = static_cast<unsigned long long>(sig_obj) | (static_cast<unsigned long long>(sig_t) << 32);
       } else {
         alive = PathStep<false, kEngine>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG);
-        if (!alive && ((__float_as_uint(meas.x) | __float_as_uint(meas.y) | __float_as_uint(meas.z)) != 0u)) {   // anything but +0 (RGB)
-          float* v = a.values + static_cast<size_t>(q) * 3u;
-          v[0] = meas.x; v[1] = meas.y; v[2] = meas.z;
-          atomicOr(a.flags + (q >> 5), 1u << (q & 31u));
-        }
       }
+      emit = !kLight && !alive && ((__float_as_uint(meas.x) | __float_as_uint(meas.y) | __float_as_uint(meas.z)) != 0u);   // anything but +0 (RGB)
     }
+    if (!kLight) EmitRecords(a, emit, q, meas, rec_next, rec_end);
   }
 
+  if (!kLight) CloseRecords(a, rec_next, rec_end);
 #ifdef AMBER_STAMPS
   if (lane == 0 && a.stamps) for (int k = 0; k < 8; k++) atomicAdd(a.stamps + k, stamp_ctx->acc[k]);
 #endif
@@ -214,16 +282,92 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
   if (lane == 0 && rays_wave) atomicAdd(a.ray_count, static_cast<unsigned long long>(rays_wave));
 }
 
+// ---- from records to ordered per-pixel sums ------------------------------------------------------------------------
+// The records of a launch arrive in no order.  The bitmap gives every record its place: record of path q goes to
+//   sorted[ base(pixel of q) + (set bits of that pixel below q) ],   base(p) = set bits of all pixels before p,
+// so reduce_flagged_kernel can walk a pixel's bits in sample order and read its measurements consecutively.
+//   rec_rank_kernel        per pixel: number of set bits, exclusive prefix within the workgroup, workgroup total
+//   rec_scan_blocks_kernel one workgroup: exclusive prefix over the workgroup totals; also folds the launch's ray count
+//                          into the handle's total
+//   rec_place_kernel       per record slot: q -> place, copy the measurement
+// All of them, and the reduction, do NOTHING when the launch ran out of record slots (*rec_count > capacity): the host
+// then repeats the launch with a larger buffer and the framebuffer and ray total have not been touched.
+__device__ __forceinline__ uint32_t PixelBits(const uint32_t* __restrict__ flags, uint32_t q0, uint32_t q1) {   // set bits in [q0, q1)
+  if (q0 == q1) return 0u;
+  const uint32_t w0 = q0 >> 5, w1 = (q1 - 1u) >> 5;
+  const uint32_t lo = 0xffffffffu << (q0 & 31u), hi = 0xffffffffu >> (31u - ((q1 - 1u) & 31u));
+  if (w0 == w1) return static_cast<uint32_t>(__popc(flags[w0] & lo & hi));
+  uint32_t c = static_cast<uint32_t>(__popc(flags[w0] & lo)) + static_cast<uint32_t>(__popc(flags[w1] & hi));
+  for (uint32_t wd = w0 + 1u; wd < w1; ++wd) c += static_cast<uint32_t>(__popc(flags[wd]));
+  return c;
+}
+__global__ void rec_rank_kernel(const uint32_t* __restrict__ flags, uint32_t n_pixels, uint32_t n_samples, uint32_t* __restrict__ excl, uint32_t* __restrict__ block_sum) {
+  __shared__ uint32_t part[256];
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t c = p < n_pixels ? PixelBits(flags, p * n_samples, p * n_samples + n_samples) : 0u;
+  part[threadIdx.x] = c;
+  __syncthreads();
+  for (uint32_t off = 1; off < 256u; off <<= 1) {             // Hillis-Steele inclusive scan
+    const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  if (p < n_pixels) excl[p] = part[threadIdx.x] - c;
+  if (threadIdx.x == 255u) block_sum[blockIdx.x] = part[255];
+}
+__global__ void rec_scan_blocks_kernel(uint32_t* __restrict__ block_sum, uint32_t n_blocks, const unsigned int* __restrict__ rec_count, uint32_t rec_capacity,
+                                       unsigned long long* __restrict__ ray_total, unsigned long long* __restrict__ ray_launch) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) {
+    carry = 0u;
+    if (*rec_count <= rec_capacity) *ray_total += *ray_launch;            // the launch stands: its rays count
+  }
+  __syncthreads();
+  for (uint32_t base = 0; base < n_blocks; base += 1024u) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t c = i < n_blocks ? block_sum[i] : 0u;
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+      const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    if (i < n_blocks) block_sum[i] = carry + part[threadIdx.x] - c;
+    __syncthreads();
+    if (threadIdx.x == 1023u) carry += part[1023];
+    __syncthreads();
+  }
+}
+__global__ void rec_place_kernel(const uint4* __restrict__ records, const unsigned int* __restrict__ rec_count, uint32_t rec_capacity, const uint32_t* __restrict__ flags,
+                                 const uint32_t* __restrict__ excl, const uint32_t* __restrict__ block_sum, uint32_t n_samples, float* __restrict__ sorted) {
+  const uint32_t n = *rec_count;
+  if (n > rec_capacity) return;                               // out of slots: the launch is repeated
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const uint4 r = records[k];
+    if (r.x == AMBER_REC_UNUSED) continue;
+    const uint32_t p = r.x / n_samples;
+    const uint32_t at = block_sum[p >> 8] + excl[p] + PixelBits(flags, p * n_samples, r.x);
+    float* s = sorted + static_cast<size_t>(at) * 3u;
+    s[0] = __uint_as_float(r.y); s[1] = __uint_as_float(r.z); s[2] = __uint_as_float(r.w);
+  }
+}
+
 // fb[pixel] += the measurements of the launch's paths, in the order of the numerical contract: within a chunk of
 // AMBER_ACCUM_CHUNK consecutive samples (counted from the launch's first sample) a sequential binary32 sum, chunk sums
 // added to the framebuffer value in chunk order.  Only paths whose bit is set contribute a term; every other term is +0,
 // and both the chunk sum (starts at +0) and the framebuffer value (cleared to +0) can never be -0, so leaving the +0
-// terms out changes no bit.  One thread per band pixel; the pixel's bits are words [q0 / 32, (q0 + n_samples - 1) / 32].
-__global__ void reduce_flagged_kernel(float* __restrict__ fb, const uint32_t* __restrict__ flags, const float* __restrict__ values,
+// terms out changes no bit.  One thread per band pixel; its measurements are sorted[base ..] in sample order.
+__global__ void reduce_flagged_kernel(float* __restrict__ fb, const uint32_t* __restrict__ flags, const float* __restrict__ sorted, const uint32_t* __restrict__ excl,
+                                      const uint32_t* __restrict__ block_sum, const unsigned int* __restrict__ rec_count, uint32_t rec_capacity,
                                       uint32_t n_pixels, uint32_t n_samples) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pixels) return;
-  const uint32_t q0 = p * n_samples, q1 = q0 + n_samples;      // n_pixels * n_samples < 2^32 (render_pass splits launches)
+  if (*rec_count > rec_capacity) return;                       // out of slots: the launch is repeated
+  const uint32_t q0 = p * n_samples, q1 = q0 + n_samples;      // n_pixels * n_samples < 2^32 (RenderPassPaths splits launches)
   bool any = false;
   if ((n_samples & 127u) == 0u) {                              // the pixel's bits are whole 16-byte groups: wide loads
     const uint4* f4 = reinterpret_cast<const uint4*>(flags + (q0 >> 5));
@@ -232,6 +376,7 @@ __global__ void reduce_flagged_kernel(float* __restrict__ fb, const uint32_t* __
     for (uint32_t wd = q0 >> 5; wd <= (q1 - 1u) >> 5; ++wd) any |= flags[wd] != 0u;   // neighbours' bits may share the edge words: harmless
   }
   if (!any) return;
+  const float* m = sorted + static_cast<size_t>(block_sum[p >> 8] + excl[p]) * 3u;
   float v0 = fb[3u * p], v1 = fb[3u * p + 1u], v2 = fb[3u * p + 2u];
   for (uint32_t c0 = 0; c0 < n_samples; c0 += AMBER_ACCUM_CHUNK) {
     const uint32_t c1 = c0 + AMBER_ACCUM_CHUNK < n_samples ? c0 + AMBER_ACCUM_CHUNK : n_samples;
@@ -240,8 +385,8 @@ __global__ void reduce_flagged_kernel(float* __restrict__ fb, const uint32_t* __
     for (uint32_t k = c0; k < c1; ++k) {
       const uint32_t q = q0 + k;
       if ((flags[q >> 5] >> (q & 31u)) & 1u) {
-        const float* m = values + static_cast<size_t>(q) * 3u;
         s0 = s0 + m[0]; s1 = s1 + m[1]; s2 = s2 + m[2];
+        m += 3;
         hit = true;
       }
     }
@@ -323,7 +468,7 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? AMBER_BVH_WGS : 4) pt_bvh_
         const uint32_t lrow = plocal / sc.sensor.w;
         const uint32_t px = plocal - lrow * sc.sensor.w;
         const uint32_t py = a.row_begin + (a.stripe_rows ? (lrow / a.stripe_rows) * a.stripe_period + lrow % a.stripe_rows : lrow);
-        pixel = px + py * sc.sensor.w;
+        pixel = kLight ? a.path_offset + plocal : px + py * sc.sensor.w;      // light tracing: the light path's index
         slot = chunk * a.n_pixels + plocal;
         s = a.first_sample + chunk * AMBER_ACCUM_CHUNK;
         const uint32_t left = a.first_sample + a.n_samples - s;
@@ -341,7 +486,7 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? AMBER_BVH_WGS : 4) pt_bvh_
 
     AMBER_CLK(0);
     if (!alive && !lane_done) {                             // regenerate: next sample of the item, start its traversal
-      AMBER_COUNT(3);
+      AMBER_COUNT_ROUNDS(3);
       rng = XorShiftSeed(a.hashed_seed, pixel, s);
       if (kLight) {
         GenerateLightRay(sc, rng, o, d, w, origin_slot);
@@ -365,7 +510,7 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? AMBER_BVH_WGS : 4) pt_bvh_
       if (tm == 0ull) break;
       if (__popcll(__ballot(alive && !traversing)) >= AMBER_BVH_SHADE_BATCH) break;
       if (traversing) {
-        AMBER_COUNT(2);
+        AMBER_COUNT_ROUNDS(2);
         traversing = BvhRound(sc, lds_stack, o, d, tr, hit, kStack AMBER_STAMP_ARG);
         if (!traversing && tr.overflow) ClosestHitLeafList(sc, o, d, hit);
       }
@@ -406,6 +551,7 @@ __global__ void reduce_partials_kernel(float* __restrict__ fb, const float* __re
   fb[e] = v;
 }
 
+#include "bvh_pool.inc"
 #include "wavefront.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -503,11 +649,6 @@ __global__ void kat_trace_kernel(const DevScene sc, uint64_t hashed_seed, uint32
 // Path signatures of the handle's band (amber_hip_kat_signatures): thread i traces the path of (band pixel i / n_samples,
 // sample first_sample + i % n_samples) with the render kernels' device functions and writes FNV-1a-32 over the object index
 // of every cast (low word; 0xffffffff = miss) and over the bits of every hit distance (high word).
-__device__ __forceinline__ uint32_t Fnv32(uint32_t h, uint32_t v) {
-#pragma unroll
-  for (int k = 0; k < 4; k++) { h ^= (v >> (8 * k)) & 0xffu; h *= 16777619u; }
-  return h;
-}
 template <int kEngine>
 __global__ void kat_signature_kernel(const DevScene sc, uint64_t hashed_seed, uint64_t n, uint32_t first_sample, uint32_t n_samples,
                                      uint32_t row_begin, uint32_t stripe_rows, uint32_t stripe_period, unsigned long long* out) {
@@ -586,11 +727,24 @@ struct amber_hip_pt {
   unsigned int* d_splat_count = nullptr;
   uint32_t splat_capacity = 0;
   uint64_t hashed_seed_lt = 0;
-  float* d_partial = nullptr;               // engine BVH: per-item sums
+  float* d_partial = nullptr;               // pt_bvh_megakernel: per-item sums
   size_t partial_floats = 0;
-  uint32_t* d_flags = nullptr;              // pt_megakernel: bitmap + values of the paths with a non-zero measurement
-  float* d_values = nullptr;
-  uint64_t pool_paths = 0;                  // paths the two buffers are sized for
+  bool bvh_pool = false;                    // engine BVH renders with pt_bvh_pool_kernel (AMBER_PT_FLAG_BVH_POOL / AMBER_BVH_POOL=1) instead of pt_bvh_megakernel
+  // path-granular accumulation (RenderPassPaths): bitmap, records in arrival order, measurements in path order, ranks
+  uint32_t* d_flags = nullptr;  size_t flag_words = 0;
+  uint4* d_records = nullptr;   float* d_sorted = nullptr;   uint32_t rec_capacity = 0;
+  unsigned int* d_rec_count = nullptr;
+  unsigned long long* d_rays_launch = nullptr;
+  uint32_t* d_excl = nullptr;   uint32_t* d_block_sum = nullptr;   uint32_t rank_pixels = 0;
+  unsigned int* h_rec_count = nullptr;      // pinned: the record counter of the launch in flight
+  hipEvent_t pending_event = nullptr;
+  bool pending = false, pending_checked = true;   // a launch whose record counter has not been looked at yet; checked = it cannot have run out of slots
+  uint32_t pending_first = 0, pending_n = 0;
+  bool density_known = false;
+  double rec_density = 0;                   // record slots used per path, as the last launch measured it
+  int32_t* d_bvh_stack = nullptr;  size_t bvh_stack_ints = 0;     // pt_bvh_pool_kernel: deep traversal-stack levels
+  float* d_carried = nullptr;      size_t carried_floats = 0;     // ... and carried measurements
+  unsigned long long* d_sig = nullptr;  uint64_t sig_paths = 0;   // amber_hip_pt_signatures
   int n_cus = 256;
   uint32_t row_begin = 0, row_end = 0, stripe_rows = 0, stripe_period = 0, local_rows = 0;
   uint64_t seed = 0, hashed_seed = 0;
@@ -743,6 +897,10 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   h->engine = params->engine != AMBER_ENGINE_AUTO ? params->engine : auto_hit;
   h->hit_engine = h->engine == AMBER_ENGINE_WAVEFRONT ? auto_hit : h->engine;
   h->two_phase = h->hit_engine == AMBER_ENGINE_TWO_PHASE;
+  // engine BVH has two schedulers with identical results: the default is the faster one on the 1M-sphere
+  // scene (pt_bvh_megakernel, 74 ms at 64 spp against 79); the environment overrides the flag either way (A/B tools)
+  h->bvh_pool = (params->reserved & AMBER_PT_FLAG_BVH_POOL) != 0u;
+  { const char* ev = std::getenv("AMBER_BVH_POOL"); if (ev && (ev[0] == '0' || ev[0] == '1')) h->bvh_pool = ev[0] == '1'; }
   amber_bvh::FlatBvh bvh;
   if (h->hit_engine == AMBER_ENGINE_BVH) {
     bvh = amber_bvh::BuildBvh(objs);
@@ -1012,47 +1170,183 @@ int RenderPassWavefront(amber_hip_pt* h, uint32_t first_sample, uint32_t n_sampl
 }  // namespace
 
 namespace {
-// pt_megakernel (engines LIST / TWO_PHASE): a launch covers at most kMaxPathsPerLaunch paths (bitmap n/8 bytes, values 12 B
-// of address space per path, touched only where a path reached a light); longer passes are split on chunk boundaries.
-int RenderPassPool(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint32_t n_pixels) {
-  const uint64_t kMaxPathsPerLaunch = 1ull << 30;
+// ---- path-granular launches (pt_megakernel for engines LIST / TWO_PHASE, pt_bvh_pool_kernel for engine BVH) --------------
+// One launch = megakernel + rank / scan / place / reduce.  The record buffer is sized from the density the previous launch
+// measured (record slots per path), with a margin; the very first launch of a handle is one accumulation chunk, whose buffer
+// can hold a record for EVERY path, and doubles as the probe.  A launch that still runs out of slots leaves the framebuffer
+// and the ray total untouched (the device-side kernels check the counter); the host notices when it next touches the handle
+// (ResolvePending), grows the buffer and repeats exactly that launch, so results never depend on the sizing.  Launches are
+// split on chunk boundaries, which leaves the summation order unchanged.
+constexpr uint64_t kMaxPathsPerLaunch = 1ull << 30;       // q and its bitmap index stay 32-bit; bitmap 128 MiB
+constexpr uint64_t kMaxRecordSlots = 48ull << 20;         // 28 B per slot (record + sorted measurement): 1.3 GiB at most
+
+uint32_t PathBlocks(const amber_hip_pt* h, uint64_t n_paths) {
+  const bool bvh = h->hit_engine == AMBER_ENGINE_BVH;
+  uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * (bvh ? static_cast<uint32_t>(AMBER_BVH_POOL_WGS) : ResidentBlocksPerCu(h->hit_engine, h->bvh_depth));
+  const uint64_t by_work = (n_paths + 255u) / 256u;
+  if (by_work < n_blocks) n_blocks = static_cast<uint32_t>(by_work);
+  return n_blocks;
+}
+// record slots that stay unused because every wave reserves them AMBER_REC_BLOCK at a time, plus a floor
+uint64_t RecordSlack(const amber_hip_pt* h) { return static_cast<uint64_t>(h->n_cus) * 8u * 4u * AMBER_REC_BLOCK + 4096u; }
+
+int EnsureRecordCapacity(amber_hip_pt* h, uint64_t slots) {
+  if (slots <= h->rec_capacity) return AMBER_OK;
+  if (slots > 0xfffffff0ull) return Fail(AMBER_ENOMEM, "record buffer beyond 2^32 slots");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->d_records) { HIP_TRY(hipFree(h->d_records)); h->d_records = nullptr; }
+  if (h->d_sorted) { HIP_TRY(hipFree(h->d_sorted)); h->d_sorted = nullptr; }
+  h->rec_capacity = 0;
+  hipError_t e = hipMalloc(&h->d_records, slots * sizeof(uint4));
+  if (e == hipSuccess) e = hipMalloc(&h->d_sorted, slots * 3u * sizeof(float));
+  if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(path records): ") + hipGetErrorString(e));
+  h->rec_capacity = static_cast<uint32_t>(slots);
+  return AMBER_OK;
+}
+
+// Enqueues one launch over samples [first, first + n) of the band.  `sig` != nullptr: the signature variant of the same
+// kernel; nothing is reduced (amber_hip_pt_signatures).
+int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, unsigned long long* sig) {
+  const uint64_t n_paths = static_cast<uint64_t>(n_pixels) * n;
+  const bool bvh = h->hit_engine == AMBER_ENGINE_BVH;
+  const size_t need_words = static_cast<size_t>((n_paths + 31u) / 32u) + 4u;
+  if (need_words > h->flag_words) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_flags) { HIP_TRY(hipFree(h->d_flags)); h->d_flags = nullptr; h->flag_words = 0; }
+    hipError_t e = hipMalloc(&h->d_flags, need_words * sizeof(uint32_t));
+    if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(path bitmap): ") + hipGetErrorString(e));
+    h->flag_words = need_words;
+  }
+  if (n_pixels > h->rank_pixels) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_excl) { HIP_TRY(hipFree(h->d_excl)); h->d_excl = nullptr; }
+    if (h->d_block_sum) { HIP_TRY(hipFree(h->d_block_sum)); h->d_block_sum = nullptr; }
+    h->rank_pixels = 0;
+    hipError_t e = hipMalloc(&h->d_excl, static_cast<size_t>(n_pixels) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&h->d_block_sum, (static_cast<size_t>(n_pixels) / 256u + 2u) * sizeof(uint32_t));
+    if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(pixel ranks): ") + hipGetErrorString(e));
+    h->rank_pixels = n_pixels;
+  }
+  if (!h->d_rec_count) HIP_TRY(hipMalloc(&h->d_rec_count, sizeof(unsigned int)));
+  if (!h->d_rays_launch) HIP_TRY(hipMalloc(&h->d_rays_launch, sizeof(unsigned long long)));
+  if (!h->h_rec_count) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_rec_count), sizeof(unsigned int), hipHostMallocDefault));
+  if (!h->pending_event) HIP_TRY(hipEventCreateWithFlags(&h->pending_event, hipEventDisableTiming));
+  const uint32_t n_blocks = PathBlocks(h, n_paths);
+  if (bvh) {
+    const size_t stack_ints = static_cast<size_t>(h->n_cus) * AMBER_BVH_POOL_WGS * 256u * AMBER_BVH_POOL_GLOBAL_LEVELS;
+    const size_t carried = static_cast<size_t>(h->n_cus) * AMBER_BVH_POOL_WGS * 4u * AMBER_BVH_POOL_CARRIED_PER_WAVE;
+    if (stack_ints > h->bvh_stack_ints) {
+      if (h->d_bvh_stack) { HIP_TRY(hipFree(h->d_bvh_stack)); h->d_bvh_stack = nullptr; h->bvh_stack_ints = 0; }
+      hipError_t e = hipMalloc(&h->d_bvh_stack, stack_ints * sizeof(int32_t));
+      if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(traversal stacks): ") + hipGetErrorString(e));
+      h->bvh_stack_ints = stack_ints;
+    }
+    if (carried > h->carried_floats) {
+      if (h->d_carried) { HIP_TRY(hipFree(h->d_carried)); h->d_carried = nullptr; h->carried_floats = 0; }
+      hipError_t e = hipMalloc(&h->d_carried, carried * sizeof(float));
+      if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(carried measurements): ") + hipGetErrorString(e));
+      h->carried_floats = carried;
+    }
+  }
+  RenderArgs a{};
+  a.scene = h->scene; a.flags = h->d_flags; a.records = h->d_records; a.rec_count = h->d_rec_count; a.rec_capacity = h->rec_capacity;
+  a.ray_count = h->d_rays_launch; a.next_item = h->d_next; a.stamps = h->d_stamps; a.hashed_seed = h->hashed_seed;
+  a.bvh_stack = h->d_bvh_stack; a.carried = h->d_carried; a.sig = sig;
+  a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first; a.n_samples = n;
+  a.n_chunks = (n + AMBER_ACCUM_CHUNK - 1) / AMBER_ACCUM_CHUNK; a.n_items = static_cast<uint32_t>(n_paths);
+  HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_rec_count, 0, sizeof(unsigned int), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_rays_launch, 0, sizeof(unsigned long long), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_flags, 0, need_words * sizeof(uint32_t), h->stream));
+  std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
+  { const int rc = AcquireEventPair(h, &evp); if (rc != AMBER_OK) return rc; }
+  auto& ev = *evp;
+  HIP_TRY(hipEventRecord(ev.first, h->stream));
+  if (sig) {
+    if (bvh) hipLaunchKernelGGL((pt_bvh_pool_kernel<true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL((pt_megakernel<ENGINE_LIST, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+  } else {
+    if (bvh) hipLaunchKernelGGL((pt_bvh_pool_kernel<false>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL((pt_megakernel<ENGINE_LIST>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev.second, h->stream));
+  if (sig) return AMBER_OK;
+  const uint32_t n_rank_blocks = (n_pixels + 255u) / 256u;
+  hipLaunchKernelGGL(rec_rank_kernel, dim3(n_rank_blocks), dim3(256), 0, h->stream, h->d_flags, n_pixels, n, h->d_excl, h->d_block_sum);
+  hipLaunchKernelGGL(rec_scan_blocks_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_block_sum, n_rank_blocks, h->d_rec_count, h->rec_capacity, h->d_rays, h->d_rays_launch);
+  hipLaunchKernelGGL(rec_place_kernel, dim3(static_cast<uint32_t>(h->n_cus) * 8u), dim3(256), 0, h->stream, h->d_records, h->d_rec_count, h->rec_capacity, h->d_flags,
+                     h->d_excl, h->d_block_sum, n, h->d_sorted);
+  hipLaunchKernelGGL(reduce_flagged_kernel, dim3(n_rank_blocks), dim3(256), 0, h->stream, h->d_fb, h->d_flags, h->d_sorted, h->d_excl, h->d_block_sum,
+                     h->d_rec_count, h->rec_capacity, n_pixels, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h->h_rec_count, h->d_rec_count, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipEventRecord(h->pending_event, h->stream));
+  h->pending = true; h->pending_first = first; h->pending_n = n;
+  h->pending_checked = n_paths + RecordSlack(h) <= h->rec_capacity;      // a slot for every path: cannot run out
+  return AMBER_OK;
+}
+
+// Looks at the record counter of the launch in flight (waits for it), remembers the density, and repeats the launch with a
+// larger buffer if it ran out of slots.  Every entry point that reads results, or enqueues work whose order matters, calls it.
+int ResolvePending(amber_hip_pt* h) {
+  while (h->pending) {
+    HIP_TRY(hipEventSynchronize(h->pending_event));
+    h->pending = false;
+    const uint64_t used = *h->h_rec_count;
+    const uint64_t n_paths = static_cast<uint64_t>(h->local_rows) * h->scene.sensor.w * h->pending_n;
+    h->rec_density = n_paths ? static_cast<double>(used) / static_cast<double>(n_paths) : 0.0;
+    h->density_known = true;
+    if (used <= h->rec_capacity) break;
+    // out of slots: nothing of that launch reached the framebuffer or the ray total
+    const int rc = EnsureRecordCapacity(h, used + used / 4u + RecordSlack(h));
+    if (rc != AMBER_OK) return rc;
+    const int rl = LaunchPaths(h, h->pending_first, h->pending_n, h->local_rows * h->scene.sensor.w, nullptr);
+    if (rl != AMBER_OK) return rl;
+  }
+  return AMBER_OK;
+}
+
+int RenderPassPaths(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint32_t n_pixels) {
   uint64_t max_samples = kMaxPathsPerLaunch / n_pixels / AMBER_ACCUM_CHUNK * AMBER_ACCUM_CHUNK;
   if (max_samples == 0) return Fail(AMBER_EINVAL, "band too large for one launch");
+  const uint64_t slack = std::getenv("AMBER_TEST_RECORD_DENSITY_SCALE") ? 64u : RecordSlack(h);   // (test hook: no cushion either)
   uint32_t done = 0;
   while (done < n_samples) {
+    // the previous launch must stand before the next one adds to the framebuffer (the order of the sums is part of the
+    // contract), unless it had a slot for every path
+    if (h->pending && (!h->pending_checked || !h->density_known)) { const int rc = ResolvePending(h); if (rc != AMBER_OK) return rc; }
     uint32_t n = n_samples - done;
     if (n > max_samples) n = static_cast<uint32_t>(max_samples);
-    const uint64_t n_paths = static_cast<uint64_t>(n_pixels) * n;
-    const size_t need_words = static_cast<size_t>((n_paths + 31u) / 32u) + 1u;
-    if (n_paths > h->pool_paths) {
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      if (h->d_flags) { HIP_TRY(hipFree(h->d_flags)); h->d_flags = nullptr; }
-      if (h->d_values) { HIP_TRY(hipFree(h->d_values)); h->d_values = nullptr; }
-      h->pool_paths = 0;
-      hipError_t e = hipMalloc(&h->d_flags, need_words * sizeof(uint32_t));
-      if (e == hipSuccess) e = hipMalloc(&h->d_values, static_cast<size_t>(n_paths) * 3u * sizeof(float));
-      if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(path measurements): ") + hipGetErrorString(e));
-      h->pool_paths = n_paths;
+    uint64_t slots;
+    if (!h->density_known) {
+      // first launch of the handle: a slot for every path, and at most one chunk unless the job is small -- it measures the density
+      if (static_cast<uint64_t>(n_pixels) * n > (4ull << 20) && n > AMBER_ACCUM_CHUNK) n = AMBER_ACCUM_CHUNK;
+      slots = static_cast<uint64_t>(n_pixels) * n + slack;
+    } else {
+      double density = h->rec_density;
+      if (const char* ts = std::getenv("AMBER_TEST_RECORD_DENSITY_SCALE")) density *= std::atof(ts);   // test hook: a wrong estimate must only cost a repeated launch
+      const double per_sample = std::max(1e-9, density * 1.5) * static_cast<double>(n_pixels);   // slots one sample of the band needs, with margin
+      const uint64_t all = static_cast<uint64_t>(n_pixels) * n;
+      const double want = per_sample * n;
+      if (want + static_cast<double>(slack) > static_cast<double>(kMaxRecordSlots) && all + slack > kMaxRecordSlots) {
+        // a dense scene: shorter launches instead of a larger buffer
+        uint64_t fit = static_cast<uint64_t>((static_cast<double>(kMaxRecordSlots) - static_cast<double>(slack)) / per_sample) / AMBER_ACCUM_CHUNK * AMBER_ACCUM_CHUNK;
+        if (fit < AMBER_ACCUM_CHUNK) fit = AMBER_ACCUM_CHUNK;
+        if (n > fit) n = static_cast<uint32_t>(fit);
+      }
+      const uint64_t all_n = static_cast<uint64_t>(n_pixels) * n;
+      slots = std::min<uint64_t>(all_n, static_cast<uint64_t>(per_sample * n) + 1u) + slack;
     }
-    RenderArgs a{};
-    a.scene = h->scene; a.flags = h->d_flags; a.values = h->d_values; a.ray_count = h->d_rays; a.next_item = h->d_next; a.stamps = h->d_stamps; a.hashed_seed = h->hashed_seed;
-    a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first_sample + done; a.n_samples = n;
-    a.n_chunks = (n + AMBER_ACCUM_CHUNK - 1) / AMBER_ACCUM_CHUNK; a.n_items = static_cast<uint32_t>(n_paths);
-    uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth);
-    const uint32_t by_work = static_cast<uint32_t>((n_paths + 255u) / 256u);
-    if (by_work < n_blocks) n_blocks = by_work;
-    HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_flags, 0, need_words * sizeof(uint32_t), h->stream));
-    std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
-    { const int rc = AcquireEventPair(h, &evp); if (rc != AMBER_OK) return rc; }
-    auto& ev = *evp;
-    HIP_TRY(hipEventRecord(ev.first, h->stream));
-    if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL(pt_megakernel<ENGINE_TWO_PHASE>, dim3(n_blocks), dim3(256), 0, h->stream, a);
-    else hipLaunchKernelGGL(pt_megakernel<ENGINE_LIST>, dim3(n_blocks), dim3(256), 0, h->stream, a);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev.second, h->stream));
-    hipLaunchKernelGGL(reduce_flagged_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, h->stream, h->d_fb, h->d_flags, h->d_values, n_pixels, n);
-    HIP_TRY(hipGetLastError());
+    if (slots > h->rec_capacity) {
+      if (h->pending) { const int rc = ResolvePending(h); if (rc != AMBER_OK) return rc; }     // the buffer is in use
+      const int rc = EnsureRecordCapacity(h, slots);
+      if (rc != AMBER_OK) return rc;
+    }
+    const int rl = LaunchPaths(h, first_sample + done, n, n_pixels, nullptr);
+    if (rl != AMBER_OK) return rl;
     done += n;
   }
   return AMBER_OK;
@@ -1067,9 +1361,9 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
   const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
   if (n_pixels == 0) return AMBER_OK;                    // empty band
   if (h->engine == AMBER_ENGINE_WAVEFRONT) return RenderPassWavefront(h, first_sample, n_samples);
-  if (h->hit_engine != AMBER_ENGINE_BVH) return RenderPassPool(h, first_sample, n_samples, n_pixels);
-  // engine BVH (pt_bvh_megakernel): a launch covers at most kMaxPartialFloats of per-item sums and < 2^31 items; longer
-  // passes are split on chunk boundaries, which leaves the summation order (chunks in order) unchanged
+  if (h->hit_engine != AMBER_ENGINE_BVH || h->bvh_pool) return RenderPassPaths(h, first_sample, n_samples, n_pixels);
+  // engine BVH, default scheduler (pt_bvh_megakernel: lanes own (pixel, chunk) items).  A launch covers at most kMaxPartialFloats
+  // of per-item sums and < 2^31 items; longer passes are split on chunk boundaries, which leaves the summation order unchanged
   const uint64_t kMaxPartialFloats = 768ull << 20;    // 3 GiB
   uint64_t max_chunks = kMaxPartialFloats / (static_cast<uint64_t>(n_pixels) * 3u);
   const uint64_t by_items = 0x7fffffffull / n_pixels;
@@ -1114,20 +1408,20 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
   return AMBER_OK;
 }
 
-int amber_hip_lt_trace(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, AmberSplat* out, uint32_t capacity,
-                       uint32_t* n_out, uint64_t* ray_count) {
+int amber_hip_lt_trace_range(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint32_t path_begin, uint32_t path_end,
+                             AmberSplat* out, uint32_t capacity, uint32_t* n_out, uint64_t* ray_count) {
   if (!h || !n_out || (capacity && !out)) return Fail(AMBER_EINVAL, "null argument");
   *n_out = 0;
+  if (ray_count) *ray_count = 0;
   if (h->engine == AMBER_ENGINE_WAVEFRONT) return Fail(AMBER_EINVAL, "light tracing runs on the work-queue kernel (engine auto, list, two_phase or bvh)");
   if (static_cast<uint64_t>(first_sample) + n_samples > 0xffffffffull) return Fail(AMBER_EINVAL, "sample index overflow");
-  if (n_samples == 0 || h->scene.n_lights == 0) { if (ray_count) *ray_count = 0; return AMBER_OK; }
+  const uint32_t all_paths = h->scene.sensor.w * h->scene.sensor.h;          // image.Size() light paths per pass
+  if (path_begin > path_end || path_end > all_paths) return Fail(AMBER_EINVAL, "bad light-path range");
+  const uint32_t n_paths = path_end - path_begin;
+  if (n_samples == 0 || n_paths == 0 || h->scene.n_lights == 0) return AMBER_OK;
   HIP_TRY(hipSetDevice(h->device));
-  const uint32_t n_paths = h->scene.sensor.w * h->scene.sensor.h;           // image.Size() light paths per pass
-  const uint32_t n_chunks = (n_samples + AMBER_ACCUM_CHUNK - 1) / AMBER_ACCUM_CHUNK;
+  { const int rc = ResolvePending(h); if (rc != AMBER_OK) return rc; }
   const bool bvh = h->hit_engine == AMBER_ENGINE_BVH;
-  // pt_megakernel numbers (light path, pass) pairs; pt_bvh_megakernel walks items = (light path, chunk of passes)
-  const uint64_t n_work = bvh ? static_cast<uint64_t>(n_paths) * n_chunks : static_cast<uint64_t>(n_paths) * n_samples;
-  if (n_work > 0x7fffffffull) return Fail(AMBER_EINVAL, "too many light paths for one call");
   const uint32_t dev_capacity = capacity ? capacity : 1u;
   if (dev_capacity > h->splat_capacity) {
     if (h->d_splats) { HIP_TRY(hipFree(h->d_splats)); h->d_splats = nullptr; h->splat_capacity = 0; }
@@ -1136,48 +1430,76 @@ int amber_hip_lt_trace(amber_hip_pt* h, uint32_t first_sample, uint32_t n_sample
     h->splat_capacity = dev_capacity;
   }
   if (!h->d_splat_count) HIP_TRY(hipMalloc(&h->d_splat_count, sizeof(unsigned int)));
+  // One launch numbers its work units with 31 bits -- pt_megakernel: (light path, pass) pairs; pt_bvh_megakernel: (light
+  // path, chunk of passes) items -- so a long range of passes is traced in several launches, each a whole number of chunks.
+  // Launches run in pass order and each one's splats are sorted, so the concatenation is in (pass, path, bounce) order.
+  const uint64_t max_units = 0x7fffffffull / n_paths;
+  if (max_units == 0) return Fail(AMBER_EINVAL, "too many light paths for one launch");
+  uint64_t max_samples = bvh ? max_units * AMBER_ACCUM_CHUNK : max_units / AMBER_ACCUM_CHUNK * AMBER_ACCUM_CHUNK;
+  if (max_samples == 0) max_samples = max_units;               // fewer than a chunk fits: any split is valid for light tracing (nothing is summed on the device)
+  uint64_t total = 0;                                         // splats produced (also beyond the caller's capacity)
   unsigned long long rays_before = 0, rays_after = 0;
   HIP_TRY(hipMemcpyAsync(&rays_before, h->d_rays, sizeof rays_before, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_splat_count, 0, sizeof(unsigned int), h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
-  RenderArgs a{};
-  a.scene = h->scene; a.ray_count = h->d_rays; a.next_item = h->d_next;
-  a.splats = h->d_splats; a.splat_count = h->d_splat_count; a.splat_capacity = dev_capacity; a.hashed_seed = h->hashed_seed_lt;
-  a.n_pixels = n_paths; a.first_sample = first_sample; a.n_samples = n_samples;
-  a.n_chunks = n_chunks; a.n_items = static_cast<uint32_t>(n_work);
-  uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth);
-  const uint32_t by_work = (a.n_items + 255u) / 256u;
-  if (by_work < n_blocks) n_blocks = by_work;
-  if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
-  else if (bvh) {
-    if (h->bvh_depth <= 24) hipLaunchKernelGGL((pt_bvh_megakernel<true, 24>), dim3(n_blocks), dim3(256), 0, h->stream, a);
-    else hipLaunchKernelGGL((pt_bvh_megakernel<true, AMBER_BVH_STACK>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+  uint32_t done = 0;
+  while (done < n_samples) {
+    uint32_t n = n_samples - done;
+    if (n > max_samples) n = static_cast<uint32_t>(max_samples);
+    const uint32_t n_chunks = (n + AMBER_ACCUM_CHUNK - 1) / AMBER_ACCUM_CHUNK;
+    const uint64_t n_work = bvh ? static_cast<uint64_t>(n_paths) * n_chunks : static_cast<uint64_t>(n_paths) * n;
+    HIP_TRY(hipMemsetAsync(h->d_splat_count, 0, sizeof(unsigned int), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
+    RenderArgs a{};
+    a.scene = h->scene; a.ray_count = h->d_rays; a.next_item = h->d_next;
+    a.splats = h->d_splats; a.splat_count = h->d_splat_count; a.splat_capacity = dev_capacity; a.hashed_seed = h->hashed_seed_lt;
+    a.n_pixels = n_paths; a.first_sample = first_sample + done; a.n_samples = n; a.path_offset = path_begin;
+    a.n_chunks = n_chunks; a.n_items = static_cast<uint32_t>(n_work);
+    uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth);
+    const uint32_t by_work = (a.n_items + 255u) / 256u;
+    if (by_work < n_blocks) n_blocks = by_work;
+    if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else if (bvh) {
+      if (h->bvh_depth <= 24) hipLaunchKernelGGL((pt_bvh_megakernel<true, 24>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+      else hipLaunchKernelGGL((pt_bvh_megakernel<true, AMBER_BVH_STACK>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    }
+    else hipLaunchKernelGGL((pt_megakernel<ENGINE_LIST, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    unsigned int produced = 0;
+    HIP_TRY(hipMemcpyAsync(&produced, h->d_splat_count, sizeof produced, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const uint64_t room = total < capacity ? capacity - total : 0;
+    if (produced <= room && produced <= dev_capacity) {
+      if (produced) {
+        static_assert(sizeof(AmberSplat) == sizeof(DevSplat), "splat layouts must agree");
+        AmberSplat* dst = out + total;
+        HIP_TRY(hipMemcpy(dst, h->d_splats, static_cast<size_t>(produced) * sizeof(DevSplat), hipMemcpyDeviceToHost));
+        // the reference adds the splats of pass s in path order (algorithm_lt.cc:112-123): restore that order
+        std::sort(dst, dst + produced, [](const AmberSplat& x, const AmberSplat& y) {
+          if (x.sample != y.sample) return x.sample < y.sample;
+          if (x.path != y.path) return x.path < y.path;
+          return x.bounce < y.bounce;
+        });
+      }
+    }
+    total += produced;                                        // keeps counting: the caller learns the capacity it needs
+    done += n;
   }
-  else hipLaunchKernelGGL((pt_megakernel<ENGINE_LIST, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
-  HIP_TRY(hipGetLastError());
-  unsigned int produced = 0;
-  HIP_TRY(hipMemcpyAsync(&produced, h->d_splat_count, sizeof produced, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(&rays_after, h->d_rays, sizeof rays_after, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(&rays_after, h->d_rays, sizeof rays_after, hipMemcpyDeviceToHost));
   if (ray_count) *ray_count = rays_after - rays_before;
-  *n_out = produced;
-  if (produced > capacity) return Fail(AMBER_ENOMEM, "splat buffer too small: " + std::to_string(produced) + " splats produced");
-  if (produced) {
-    static_assert(sizeof(AmberSplat) == sizeof(DevSplat), "splat layouts must agree");
-    HIP_TRY(hipMemcpy(out, h->d_splats, static_cast<size_t>(produced) * sizeof(DevSplat), hipMemcpyDeviceToHost));
-    // the reference adds the splats of pass s in path order (algorithm_lt.cc:112-123): restore that order
-    std::sort(out, out + produced, [](const AmberSplat& x, const AmberSplat& y) {
-      if (x.sample != y.sample) return x.sample < y.sample;
-      if (x.path != y.path) return x.path < y.path;
-      return x.bounce < y.bounce;
-    });
-  }
+  *n_out = total > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(total);
+  if (total > capacity) return Fail(AMBER_ENOMEM, "splat buffer too small: " + std::to_string(total) + " splats produced");
   return AMBER_OK;
+}
+
+int amber_hip_lt_trace(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, AmberSplat* out, uint32_t capacity,
+                       uint32_t* n_out, uint64_t* ray_count) {
+  if (!h) return Fail(AMBER_EINVAL, "null argument");
+  return amber_hip_lt_trace_range(h, first_sample, n_samples, 0u, h->scene.sensor.w * h->scene.sensor.h, out, capacity, n_out, ray_count);
 }
 
 int amber_hip_pt_clear(amber_hip_pt* h) {
   if (!h) return Fail(AMBER_EINVAL, "null handle");
   HIP_TRY(hipSetDevice(h->device));
+  { const int rc = ResolvePending(h); if (rc != AMBER_OK) return rc; }
   const size_t fb_floats = static_cast<size_t>(h->local_rows) * h->scene.sensor.w * 3;
   HIP_TRY(hipMemsetAsync(h->d_fb, 0, fb_floats * sizeof(float), h->stream));
   HIP_TRY(hipMemsetAsync(h->d_rays, 0, sizeof(unsigned long long), h->stream));
@@ -1189,6 +1511,7 @@ int amber_hip_pt_clear(amber_hip_pt* h) {
 int amber_hip_pt_sync(amber_hip_pt* h) {
   if (!h) return Fail(AMBER_EINVAL, "null handle");
   HIP_TRY(hipSetDevice(h->device));
+  { const int rc = ResolvePending(h); if (rc != AMBER_OK) return rc; }
   HIP_TRY(hipStreamSynchronize(h->stream));
   return AMBER_OK;
 }
@@ -1196,6 +1519,7 @@ int amber_hip_pt_sync(amber_hip_pt* h) {
 int amber_hip_pt_download(amber_hip_pt* h, float* rgb_sum, uint64_t* ray_count) {
   if (!h) return Fail(AMBER_EINVAL, "null handle");
   HIP_TRY(hipSetDevice(h->device));
+  { const int rc = ResolvePending(h); if (rc != AMBER_OK) return rc; }
   const size_t fb_floats = static_cast<size_t>(h->local_rows) * h->scene.sensor.w * 3;
   if (rgb_sum) HIP_TRY(hipMemcpyAsync(rgb_sum, h->d_fb, fb_floats * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   unsigned long long r = 0;
@@ -1227,6 +1551,7 @@ int amber_hip_pt_local_rows(amber_hip_pt* h, uint32_t* n_rows) {
 int amber_hip_pt_kernel_time(amber_hip_pt* h, uint32_t* n_launches, double* total_ms) {
   if (!h) return Fail(AMBER_EINVAL, "null handle");
   HIP_TRY(hipSetDevice(h->device));
+  { const int rc = ResolvePending(h); if (rc != AMBER_OK) return rc; }
   HIP_TRY(hipStreamSynchronize(h->stream));
   double tot = h->timed_ms;
   for (size_t i = 0; i < h->events_used; i++) {
@@ -1275,7 +1600,17 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_splat_count) (void)hipFree(h->d_splat_count);
   if (h->d_partial) (void)hipFree(h->d_partial);
   if (h->d_flags) (void)hipFree(h->d_flags);
-  if (h->d_values) (void)hipFree(h->d_values);
+  if (h->d_records) (void)hipFree(h->d_records);
+  if (h->d_sorted) (void)hipFree(h->d_sorted);
+  if (h->d_rec_count) (void)hipFree(h->d_rec_count);
+  if (h->d_rays_launch) (void)hipFree(h->d_rays_launch);
+  if (h->d_excl) (void)hipFree(h->d_excl);
+  if (h->d_block_sum) (void)hipFree(h->d_block_sum);
+  if (h->h_rec_count) (void)hipHostFree(h->h_rec_count);
+  if (h->pending_event) (void)hipEventDestroy(h->pending_event);
+  if (h->d_bvh_stack) (void)hipFree(h->d_bvh_stack);
+  if (h->d_carried) (void)hipFree(h->d_carried);
+  if (h->d_sig) (void)hipFree(h->d_sig);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -1380,6 +1715,31 @@ int amber_hip_kat_signatures(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out, d_out.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return AMBER_OK;
+}
+
+int amber_hip_pt_signatures(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint64_t* out) {
+  if (!h || !out || n_samples == 0) return Fail(AMBER_EINVAL, "bad argument");
+  if (static_cast<uint64_t>(first_sample) + n_samples > 0xffffffffull) return Fail(AMBER_EINVAL, "sample index overflow");
+  if (h->engine == AMBER_ENGINE_WAVEFRONT || (h->hit_engine == AMBER_ENGINE_BVH && !h->bvh_pool)) return Fail(AMBER_EINVAL, "signatures come from the path-granular kernels (engines list / two_phase, or bvh with AMBER_PT_FLAG_BVH_POOL)");
+  const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
+  const uint64_t n = static_cast<uint64_t>(n_pixels) * n_samples;
+  if (n == 0) return AMBER_OK;
+  if (n > kMaxPathsPerLaunch) return Fail(AMBER_EINVAL, "too many paths for one call");
+  HIP_TRY(hipSetDevice(h->device));
+  { const int rc = ResolvePending(h); if (rc != AMBER_OK) return rc; }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (n > h->sig_paths) {
+    if (h->d_sig) { HIP_TRY(hipFree(h->d_sig)); h->d_sig = nullptr; h->sig_paths = 0; }
+    hipError_t e = hipMalloc(&h->d_sig, n * sizeof(unsigned long long));
+    if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(signatures): ") + hipGetErrorString(e));
+    h->sig_paths = n;
+  }
+  { const int rc = EnsureRecordCapacity(h, RecordSlack(h)); if (rc != AMBER_OK) return rc; }   // records of this launch are discarded
+  HIP_TRY(hipMemsetAsync(h->d_sig, 0, n * sizeof(unsigned long long), h->stream));
+  { const int rc = LaunchPaths(h, first_sample, n_samples, n_pixels, h->d_sig); if (rc != AMBER_OK) return rc; }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out, h->d_sig, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return AMBER_OK;
 }
 

@@ -133,7 +133,11 @@ typedef struct {
   uint32_t reserved;    /* row_begin = r*S, row_end = height, stripe_period = N*S).  Local rows are compact.      */
                         /* `reserved` carries AMBER_PT_FLAG_* bits (0 = none). row_begin == row_end != 0: empty band.   */
 } AmberPtParams;
-enum { AMBER_PT_FLAG_NULL_STREAM = 1u };
+enum {
+  AMBER_PT_FLAG_NULL_STREAM = 1u,
+  AMBER_PT_FLAG_BVH_POOL = 2u     /* engine BVH: schedule with the per-wave ray pool (pt_bvh_pool_kernel) instead of the default
+                                     (pt_bvh_megakernel).  Same results bit for bit; measured slower on the 1M-sphere scene. */
+};
 
 /* All engines are the same persistent work-queue kernel; they differ in how a lane finds its closest hit.
  * Every engine returns the List-semantics answer (closest finite hit, ties to the lower object index). */
@@ -181,6 +185,11 @@ void amber_hip_pt_destroy(amber_hip_pt*);
 typedef struct { uint32_t path, sample, bounce, pixel; float rgb[3]; uint32_t pad; } AmberSplat;
 int amber_hip_lt_trace(amber_hip_pt*, uint32_t first_sample, uint32_t n_samples, AmberSplat* out, uint32_t capacity,
                        uint32_t* n_out, uint64_t* ray_count);
+/* The same for the light paths [path_begin, path_end) only: light paths are independent, so the path index shards across
+ * devices the way pixels do for path tracing -- every device traces its range of every pass, the caller merges the sorted
+ * lists (HipLightTracing::Render; reference: algorithm_lt.cc:82-95 parallelises lt exactly like pt). */
+int amber_hip_lt_trace_range(amber_hip_pt*, uint32_t first_sample, uint32_t n_samples, uint32_t path_begin, uint32_t path_end,
+                             AmberSplat* out, uint32_t capacity, uint32_t* n_out, uint64_t* ray_count);
 
 const char* amber_hip_last_error(void);
 int         amber_hip_abi_version(void);
@@ -211,6 +220,11 @@ int amber_hip_kat_trace(amber_hip_pt*, uint32_t n, const uint32_t* pixel, const 
  * DIVERGED iff these differ -- and FNV-1a-32 over the bits of every hit distance in the high word.  out: host pointer,
  * local_rows * width * n_samples entries. */
 int amber_hip_kat_signatures(amber_hip_pt*, uint32_t first_sample, uint32_t n_samples, uint64_t* out);
+/* The same signatures from the PRODUCT render kernel (pt_megakernel / pt_bvh_pool_kernel instantiated with the hashing
+ * switched on: identical scheduling, work queue, ray pool and device functions), so that the kernel that renders -- not
+ * only the per-thread known-answer kernel above -- is compared with the oracle path by path
+ * (algorithm_pt.cc:125-160).  Same layout as amber_hip_kat_signatures.  Leaves the framebuffer and the ray count untouched. */
+int amber_hip_pt_signatures(amber_hip_pt*, uint32_t first_sample, uint32_t n_samples, uint64_t* out);
 /* the engine's sin/cos/pow on device: mode 0 = sincos(x[i]) -> out[2i], out[2i+1] ; mode 1 = pow(x[2i], x[2i+1]) -> out[i] ;
  * mode 2 / 3 = x[i]^4 / x[i]^5 in binary64 -> out[2i], out[2i+1] = low, high word of the double */
 int amber_hip_kat_math(int device, int mode, uint32_t n, const float* x, float* out);

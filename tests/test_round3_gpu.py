@@ -1,0 +1,321 @@
+"""GPU parity tests added in round 3 (all through the C ABI, all bit-exact against the oracle):
+
+  * the PRODUCT render kernels' own path signatures (amber_hip_pt_signatures) against the oracle's, path by path;
+  * BASELINE config 2's whole 1024x1024 frame at 64 spp against oracle(XorShift, reference BVH, live libm);
+  * BASELINE config 5's max_depth = 16 against the oracle on full-width rows of the 3840x2160 frame;
+  * path records (accumulation without owners): scenes where most paths end on a light, launches that need the density probe,
+    launches that run out of record slots and are repeated;
+  * engine BVH's second scheduler (AMBER_PT_FLAG_BVH_POOL, pt_bvh_pool_kernel) against the default and the oracle;
+  * light tracing sharded by light-path index (N handles) and long pass ranges (more than 2^31 work units);
+  * time-adaptive launch batches of Algorithm::Render;
+  * 200 fresh fuzz scenes per round (the first seed advances with tests/golden/fuzz_round.json).
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_binding as O
+from test_gpu_parity import _mixed_scene, bits
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent
+
+
+@pytest.fixture(scope="module")
+def cornell(amber):
+    return amber.HostScene.cornell_box(), O.Scene.cornell(O.ACCEL_LIST)
+
+
+def _split(sig):
+    return sig & np.uint64(0xffffffff), sig >> np.uint64(32)
+
+
+def test_product_kernel_signatures_against_the_oracle(amber, cornell):
+    """algorithm_pt.cc:125-160, path by path, from the kernels that RENDER: pt_megakernel (two-phase and list) and
+    pt_bvh_pool_kernel instantiated with the hashing on -- same work queue, ray pool and device functions as the product
+    instantiation.  Object sequence and hit distances of every path == oracle (List), == the per-thread KAT kernel."""
+    hs, osc = cornell
+    W = H = 256
+    rows, spp, seed = (100, 108), 64, 12345
+    so = osc.path_signatures(W, H, seed, 0, spp, rows, threads=16)
+    for engine, flags in ((amber.ENGINE_TWO_PHASE, 0), (amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_POOL)):
+        pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=seed, rows=rows, engine=engine, flags=flags)
+        pt.render_pass(0, 8)                                           # state left by a render must not matter
+        img0, rays0 = pt.download()
+        sp = pt.render_signatures(0, spp)
+        img1, rays1 = pt.download()
+        assert rays0 == rays1 and np.array_equal(bits(img0), bits(img1))   # the signature launch leaves framebuffer and ray count alone
+        assert np.array_equal(sp, so), engine
+        assert np.array_equal(sp, pt.kat_signatures(0, spp)), engine
+        # a later sample range, an odd count
+        assert np.array_equal(pt.render_signatures(1000, 13), osc.path_signatures(W, H, seed, 1000, 13, rows, threads=16)), engine
+        pt.close()
+    # a scene of all four primitive kinds and every material, through the pool kernel (triangle hits carry u, v through LDS)
+    from amber_amd import scenes
+    k = _mixed_scene(3000, 11)
+    hm, om = amber.HostScene.create_arrays(**k), O.Scene.create(**scenes.as_tuples(k), accel=O.ACCEL_LIST)
+    pt = amber.PathTracer(hm, amber.Sensor.default(40, 40), seed=21, flags=amber.api.PT_FLAG_BVH_POOL)
+    assert np.array_equal(pt.render_signatures(0, 24), om.path_signatures(40, 40, 21, 0, 24, (0, 40), threads=16))
+
+
+def test_config2_whole_frame_at_64spp_against_the_oracle(amber, cornell):
+    """BASELINE config 2's frame, every one of the 1024 rows, 64 samples per pixel: image bits and ray count against
+    oracle(XorShift sampler, the reference's BVH, the host's live libm) -- 6.7e7 paths, 1.4e8 rays."""
+    hs, _ = cornell
+    W = H = 1024
+    spp, seed = 64, 12345
+    pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=seed)
+    pt.render_pass(0, spp)
+    img, rays = pt.download()
+    ref, cnt = O.Scene.cornell(O.ACCEL_BVH).render_xorshift(W, H, seed, 0, spp, math=O.MATH_LIBM, threads=16)
+    differing = int((bits(img) != bits(ref)).any(axis=2).sum())
+    assert rays == cnt.casts, (rays, cnt.casts)
+    assert differing == 0, differing
+
+
+def test_config5_max_depth_16_against_the_oracle(amber, cornell):
+    """BASELINE config 5 (3840x2160, max depth 16): 8 full-width rows at 16 spp against oracle.render_xorshift(max_depth=16)
+    -- image bits, ray count, path signatures -- and per-bounce traces with the same truncation."""
+    from test_gpu_parity import _compare_traces
+    hs, osc = cornell
+    W, H, depth, spp, seed = 3840, 2160, 16, 16, 12345
+    sn = amber.Sensor.default(W, H)
+    for rows in ((1076, 1080), (1500, 1504)):                          # light row / spheres and water (long refraction chains)
+        pt = amber.PathTracer(hs, sn, seed=seed, max_depth=depth, rows=rows)
+        pt.render_pass(0, spp)
+        img, rays = pt.download()
+        full = np.zeros((H, W, 3), np.float32)
+        _, cnt = osc.render_xorshift(W, H, seed, 0, spp, max_depth=depth, threads=16, rows=rows, out=full)
+        assert rays == cnt.casts and np.array_equal(bits(img), bits(full[rows[0]:rows[1]]))
+        assert np.array_equal(pt.render_signatures(0, spp), osc.path_signatures(W, H, seed, 0, spp, rows, max_depth=depth, threads=16))
+        _, cnt_free = osc.render_xorshift(W, H, seed, 0, spp, threads=16, rows=rows)
+        assert cnt.casts < cnt_free.casts                               # the truncation bites on these rows
+        pt.close()
+    pt = amber.PathTracer(hs, sn, seed=seed, max_depth=depth)
+    rng = np.random.default_rng(16)
+    px = (rng.integers(1400, 1700, 500) * W + rng.integers(0, W, 500)).astype(np.uint32)
+    sm = rng.integers(0, 8192, 500).astype(np.uint32)
+    casts = _compare_traces(pt, osc, W, H, seed, px, sm, maxb=depth, max_depth=depth)
+    assert casts.max() == depth
+
+
+LIGHT_BOX = dict(
+    # a room whose ceiling and two walls are lights: most paths end on one
+    materials=[(4, (3.0, 2.0, 1.0), 0.0), (0, (0.7, 0.7, 0.7), 0.0), (2, (0.9, 0.9, 0.9), 0.0), (3, (1.0, 1.0, 1.0), 1.5), (4, (0.5, 1.5, 2.5), 0.0)],
+    objects=[
+        (0, 0, [-2, 1.5, -2, 2, 1.5, 2, 2, 1.5, -2]), (0, 0, [-2, 1.5, -2, -2, 1.5, 2, 2, 1.5, 2]),            # ceiling light (facing down)
+        (0, 4, [-2, -1, -2, -2, 1.5, -2, 2, 1.5, -2]), (0, 4, [-2, -1, -2, 2, 1.5, -2, 2, -1, -2]),            # back wall light
+        (0, 1, [-2, -1, -2, 2, -1, 2, 2, -1, -2]), (0, 1, [-2, -1, -2, -2, -1, 2, 2, -1, 2]),                  # floor
+        (1, 2, [0.6, -0.5, 0.0, 0.5]), (1, 3, [-0.7, -0.55, 0.4, 0.45]), (1, 4, [0.0, 0.9, 0.0, 0.3]),
+        (2, 0, [-1.9, 0.2, 0.0, 1.0, 0.0, 0.0, 0.9]), (3, 1, [1.5, -1.0, -1.0, 0.0, 1.0, 0.0, 0.2, 1.2]),
+    ],
+    transform=[1, 0, 0, 0, 0, 1, 0, 0.1, 0, 0, 1, 3.2, 0, 0, 0, 1], focal_length=0.05, focus_distance=3.2, radius=0.02, n_blades=6,
+)
+
+
+def test_path_records_when_most_paths_reach_a_light(amber):
+    """Accumulation without owners under load: > 50 % of the paths end with a non-zero measurement, so every wave appends
+    records all the time.  Small frame: all engines against the oracle.  Larger frame (2.8e7 paths per pass range): the first
+    launch is the one-chunk density probe, the rest is sized from it; repeated renders and split passes stay bit-identical."""
+    hs, osc = amber.HostScene.create(**LIGHT_BOX), O.Scene.create(**LIGHT_BOX)
+    W, H, spp = 96, 64, 40
+    ref, cnt = osc.render_xorshift(W, H, 5, 0, spp)
+    assert (ref.sum(axis=2) > 0).mean() > 0.9
+    lit_paths = None
+    for engine, flags in ((amber.ENGINE_TWO_PHASE, 0), (amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_POOL),
+                          (amber.ENGINE_WAVEFRONT, 0)):
+        pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=5, engine=engine, flags=flags)
+        pt.render_pass(0, spp)
+        img, rays = pt.download()
+        assert rays == cnt.casts and np.array_equal(bits(img), bits(ref)), (engine, flags)
+        pt.close()
+    # fraction of paths that carry a measurement: from single-sample renders of the oracle
+    one, _ = osc.render_xorshift(W, H, 5, 0, 1, chunk=1)
+    lit_paths = (one.sum(axis=2) > 0).mean()
+    assert lit_paths > 0.5, lit_paths
+    # the large frame: probe launch + density-sized launches, against the oracle and against itself
+    W, H, spp = 768, 768, 48
+    sn = amber.Sensor.default(W, H)
+    ref, cnt = osc.render_xorshift(W, H, 7, 0, spp, threads=16)
+    for engine, flags in ((amber.ENGINE_AUTO, 0), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_POOL)):
+        pt = amber.PathTracer(hs, sn, seed=7, engine=engine, flags=flags)
+        pt.render_pass(0, spp)
+        img, rays = pt.download()
+        n_launch, _ = pt.kernel_time()
+        assert n_launch >= 2                                            # the probe chunk, then the rest
+        assert rays == cnt.casts and np.array_equal(bits(img), bits(ref)), (engine, flags)
+        pt.clear()
+        pt.render_pass(0, 16); pt.render_pass(16, 32)                   # split on a chunk boundary: the same sums
+        img2, rays2 = pt.download()
+        assert rays2 == rays and np.array_equal(bits(img2), bits(img))
+        pt.close()
+
+
+def test_a_launch_that_runs_out_of_record_slots_is_repeated(amber, cornell):
+    """The record buffer is sized from the PREVIOUS launch's density.  A handle that has only seen the Cornell box's dark
+    rows (no path reaches the light) and then renders... the same handle cannot change scene, so the density is made wrong
+    the other way round: a first launch over sample indices whose paths all miss the light, then a launch 100x longer.  Whatever
+    the sizing, a launch that needs more slots than it was given must leave no trace and be repeated: image and ray count equal
+    the oracle's."""
+    hs, osc = amber.HostScene.create(**LIGHT_BOX), O.Scene.create(**LIGHT_BOX)
+    W, H = 640, 512
+    sn = amber.Sensor.default(W, H)
+    # rows that look at the floor only see light by reflection; rows at the top look straight at the ceiling light: a band
+    # handle over the whole frame whose first launch is ONE sample (density of that one sample), then 63 more
+    pt = amber.PathTracer(hs, sn, seed=11)
+    import os
+    os.environ["AMBER_TEST_RECORD_DENSITY_SCALE"] = "0.02"              # test hook: pretend the measured density was 50x lower
+    try:
+        pt.render_pass(0, 8)
+        pt.render_pass(8, 56)                                           # sized 50x too small: runs out of slots, is repeated
+        img, rays = pt.download()
+    finally:
+        os.environ.pop("AMBER_TEST_RECORD_DENSITY_SCALE", None)
+    n_launch, _ = pt.kernel_time()
+    assert n_launch >= 3                                                # probe, the failed launch, its repetition
+    ref, cnt = osc.render_xorshift(W, H, 11, 0, 64, threads=16)
+    assert rays == cnt.casts and np.array_equal(bits(img), bits(ref))
+
+
+def test_bvh_pool_scheduler_is_bit_identical(amber):
+    """Engine BVH's two schedulers -- lanes own work items (pt_bvh_megakernel, the default) / per-wave ray pool with in-place
+    swaps (pt_bvh_pool_kernel, AMBER_PT_FLAG_BVH_POOL) -- against each other and the oracle: all primitive kinds, several
+    passes, sample offsets, a one-row band, stripes; then the 1M-sphere scene of BASELINE config 3 (deep stacks: the levels
+    beyond the LDS part live in global memory) and fuzz scenes with degenerate directions (carried NaN measurements)."""
+    from amber_amd import scenes
+    from fuzz_scenes import scene_for_seed
+    POOL = amber.api.PT_FLAG_BVH_POOL
+    k = _mixed_scene(3000, 11)
+    hs = amber.HostScene.create_arrays(**k)
+    osc = O.Scene.create(**scenes.as_tuples(k), accel=O.ACCEL_LIST)
+    W, H = 61, 45
+    sn = amber.Sensor.default(W, H)
+    pool, dflt = amber.PathTracer(hs, sn, seed=21, flags=POOL), amber.PathTracer(hs, sn, seed=21)
+    ref = np.zeros((H, W, 3), np.float32); casts = 0
+    for first, n in ((0, 5), (5, 11), (1000, 3)):
+        pool.render_pass(first, n); dflt.render_pass(first, n)
+        _, c = osc.render_xorshift(W, H, 21, first, n, out=ref); casts += c.casts
+    (ip, rp), (idf, rd) = pool.download(), dflt.download()
+    assert rp == rd == casts and np.array_equal(bits(ip), bits(idf)) and np.array_equal(bits(ip), bits(ref))
+    band = amber.PathTracer(hs, sn, seed=21, flags=POOL, rows=(17, 18)); band.render_pass(0, 9)
+    b, _ = band.download()
+    rb, _ = osc.render_xorshift(W, H, 21, 0, 9, rows=(17, 18))
+    assert np.array_equal(bits(b[0]), bits(rb[17]))
+    st = amber.PathTracer(hs, sn, seed=21, flags=POOL, rows=(8, H), stripe=(8, 16)); st.render_pass(0, 9)
+    s_img, _ = st.download()
+    full, _ = osc.render_xorshift(W, H, 21, 0, 9)
+    assert np.array_equal(bits(s_img), bits(full[st.row_index]))
+    # BASELINE config 3's scene at a reduced frame
+    hm = amber.HostScene.create_arrays(**scenes.random_spheres(1_000_000, 7))
+    sm = amber.Sensor.default(480, 270)
+    a, b2 = amber.PathTracer(hm, sm, seed=1, flags=POOL), amber.PathTracer(hm, sm, seed=1)
+    a.render_pass(0, 16); b2.render_pass(0, 16)
+    (ia, ra), (ib, rb2) = a.download(), b2.download()
+    assert ra == rb2 and np.array_equal(bits(ia), bits(ib)) and (ia > 0).mean() > 0.02
+    a.close(); b2.close()
+    # degenerate fuzz scenes (non-unit normals: NaN / inf weights travel along the path)
+    for seed, scaled, extreme in ((5, 0, 0), (1037, 0, 0), (31296, 0, 1), (209769, 1, 1), (7, 0, 1), (23, 0, 1)):
+        sc, _ = scene_for_seed(seed, scaled=bool(scaled), extreme=bool(extreme))
+        hf = amber.HostScene.create(**sc)
+        res = []
+        for eng, fl in ((amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, POOL)):
+            pt = amber.PathTracer(hf, amber.Sensor.default(48, 40), seed=seed, engine=eng, flags=fl)
+            pt.render_pass(0, 6); res.append(pt.download()); pt.close()
+        for img, rays in res[1:]:
+            assert rays == res[0][1] and np.array_equal(bits(img), bits(res[0][0])), seed
+
+
+def test_light_tracing_shards_by_path_index_and_splits_long_ranges(amber, cornell):
+    """(a) amber_hip_lt_trace_range: the splats of disjoint light-path ranges, merged, are the splats of the whole pass.
+    (b) HipLightTracing::Render with several handles (here on one device) == one handle, bit for bit (algorithm_lt.cc:82-95
+    parallelises lt like pt).  (c) a range of passes with more than 2^31 (light path, pass) units is traced in several
+    launches instead of failing."""
+    lights = dict(
+        materials=[(4, (30.0, 20.0, 10.0), 0.0), (0, (0.7, 0.6, 0.5), 0.0), (2, (0.8, 0.8, 0.8), 0.0), (3, (1.0, 1.0, 1.0), 1.5)],
+        objects=[(2, 0, [0.0, 1.5, 0.0, 0.0, -1.0, 0.0, 0.6]), (1, 0, [1.2, 0.8, 0.0, 0.15]),
+                 (0, 1, [-3, -1, -3, 3, -1, 3, 3, -1, -3]), (0, 1, [-3, -1, -3, -3, -1, 3, 3, -1, 3]),
+                 (1, 2, [0.7, -0.6, -0.3, 0.4]), (1, 3, [0.0, -0.5, 0.8, 0.45])],
+        transform=[1, 0, 0, 0, 0, 1, 0, 0.2, 0, 0, 1, 2.6, 0, 0, 0, 1], focal_length=0.05, focus_distance=2.6, radius=0.45, n_blades=5)
+    hs, osc = amber.HostScene.create(**lights), O.Scene.create(**lights)
+    W, H = 48, 36
+    sn = amber.Sensor.default(W, H)
+    pt = amber.PathTracer(hs, sn, seed=13)
+    whole, rays = pt.lt_trace(2, 200)
+    parts, tot = [], 0
+    for p0, p1 in ((0, 500), (500, 501), (501, W * H)):
+        rec, r = pt.lt_trace(2, 200, paths=(p0, p1))
+        assert len(rec) == 0 or (rec["path"].min() >= p0 and rec["path"].max() < p1)
+        parts.append(rec); tot += r
+    merged = np.concatenate(parts)
+    merged = merged[np.lexsort((merged["bounce"], merged["path"], merged["sample"]))]
+    assert tot == rays and len(whole) > 20 and merged.tobytes() == whole.tobytes()
+    for engine in (amber.ENGINE_AUTO, amber.ENGINE_BVH):
+        one, st1 = hs.render(sn, 96, seed=13, samples_per_launch=40, algorithm="lt", devices=[0])
+        many, stn = hs.render(sn, 96, seed=13, samples_per_launch=40, algorithm="lt", devices=[0, 0, 0])
+        assert st1["rays"] == stn["rays"] and st1["passes"] == stn["passes"] == 96
+        assert np.array_equal(bits(one), bits(many)) and (one > 0).any()
+    oimg, ocnt, _ = osc.render_lt(W, H, 13, 0, 96)
+    assert st1["rays"] == ocnt.casts and np.array_equal(bits(one), bits(oimg / np.float32(96)))
+    # (c) 1920 x 1080 light paths x 1100 passes = 2.28e9 units > 2^31: several launches inside one call
+    hc, _ = cornell
+    big = amber.PathTracer(hc, amber.Sensor.default(1920, 1080), seed=3)
+    rec, rays_big = big.lt_trace(0, 1100, capacity=1 << 20)
+    a, ra = big.lt_trace(0, 1096, capacity=1 << 20)
+    b, rb = big.lt_trace(1096, 4, capacity=1 << 20)
+    assert rays_big == ra + rb and len(rec) == len(a) + len(b) and rec.tobytes() == np.concatenate([a, b]).tobytes()
+    assert rays_big > 2 ** 31
+
+
+def test_render_batches_adapt_to_time(amber, cornell):
+    """HipPathTracingOptions.samples_per_launch = 0 (the default): Algorithm::Render grows its batches while they are short.
+    All batches are multiples of the accumulation chunk, so the image is that of one launch -- bit for bit -- and of the oracle."""
+    hs, osc = cornell
+    W, H, spp = 96, 64, 200
+    auto, st = hs.render(amber.Sensor.default(W, H), spp, seed=9)                          # samples_per_launch = 0: adaptive
+    one, st1 = hs.render(amber.Sensor.default(W, H), spp, seed=9, samples_per_launch=spp)
+    assert st["passes"] == st1["passes"] == spp and st["rays"] == st1["rays"]
+    assert 3 <= st["launches"] < 20                                                          # 8, 16, 32, 64, 80: not 25 launches of 8
+    assert np.array_equal(bits(auto), bits(one))
+    ref, cnt = osc.render_xorshift(W, H, 9, 0, spp)
+    assert st["rays"] == cnt.casts and np.array_equal(bits(auto), bits(ref / np.float32(spp)))
+
+
+def test_fresh_fuzz_scenes(amber):
+    """200 fuzz scenes nobody has rendered before: the first seed comes from tests/golden/fuzz_round.json, which every round
+    advances.  The flag set rotates over plain / --scaled / --extreme / --heavy; every engine that accepts the scene (LIST, BVH
+    with both schedulers, WAVEFRONT, TWO_PHASE) must agree bit for bit, light tracing between the work-queue engines on every
+    4th scene, and the oracle on three of every eight scenes (one each of plain, --scaled, --extreme)."""
+    from fuzz_scenes import scene_for_seed
+    cfg = json.loads((ROOT / "golden" / "fuzz_round.json").read_text())
+    first = int(cfg["first_seed"])
+    n = int(cfg.get("n_scenes", 200))
+    POOL = amber.api.PT_FLAG_BVH_POOL
+    for seed in range(first, first + n):
+        mode = seed % 4
+        scaled, extreme, heavy = mode == 1, mode == 2, (mode == 3 and seed % 16 == 3)
+        W, H, spp = (128, 96, 12) if heavy else (48, 40, 6)
+        sc, rng = scene_for_seed(seed, scaled=scaled, extreme=extreme)
+        n_obj = len(sc["objects"]) + max(1, sc["n_blades"])
+        hs = amber.HostScene.create(**sc)
+        engines = [(amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, POOL), (amber.ENGINE_WAVEFRONT, 0)] + ([(amber.ENGINE_TWO_PHASE, 0)] if n_obj <= 32 else [])
+        ref = None
+        for e, fl in engines:
+            pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=seed, engine=e, flags=fl)
+            pt.render_pass(0, spp)
+            img, rays = pt.download(); pt.close()
+            if ref is None:
+                ref = (bits(img).copy(), rays)
+            assert rays == ref[1] and np.array_equal(bits(img), ref[0]), (seed, e, fl)
+        if seed % 4 == 0:
+            lref = None
+            for e in [x for x, fl in engines if x != amber.ENGINE_WAVEFRONT and fl == 0]:
+                pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=seed, engine=e)
+                rec, lrays = pt.lt_trace(0, 3, capacity=1 << 14); pt.close()
+                if lref is None:
+                    lref = (rec.tobytes(), lrays)
+                assert lrays == lref[1] and rec.tobytes() == lref[0], (seed, e)
+        if seed % 8 < 3:                                               # plain, --scaled and --extreme scenes of the small kind
+            oimg, cnt = O.Scene.create(**sc).render_xorshift(W, H, seed, 0, spp)
+            assert cnt.casts == ref[1] and np.array_equal(bits(oimg), ref[0]), seed
