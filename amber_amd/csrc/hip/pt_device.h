@@ -395,6 +395,17 @@ __device__ __forceinline__ int GlibcCheckInt(uint32_t iy) {
   if (iy & (1u << (0x7f + 23 - e))) return 1;
   return 2;
 }
+// A double constant that is the ADDEND of an fma must sit in a VGPR pair (one SGPR operand per VOP3 instruction).  Left to
+// itself the compiler materialises such constants once, outside the persistent loop, and -- under the kernels' register
+// caps -- spills them to scratch, reloading them on every evaluation (pt_megakernel: three 8-byte scratch loads per Pow).
+// Passing the constant through an empty asm next to its use makes it two v_mov instead.
+#define AMBER_NEAR_CONSTANT(bits64_) NearConstantBits<static_cast<uint32_t>((bits64_) & 0xffffffffull), static_cast<uint32_t>((bits64_) >> 32)>()
+template <uint32_t kLo, uint32_t kHi>
+__device__ __forceinline__ double NearConstantBits() {
+  uint32_t lo, hi;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(lo), "=v"(hi) : "n"(kLo), "n"(kHi));
+  return __hiloint2double(static_cast<int>(hi), static_cast<int>(lo));
+}
 __device__ __forceinline__ float Pow(float x, float y) {
   uint32_t sign_bias = 0u;
   uint32_t ix = __float_as_uint(x);
@@ -431,8 +442,8 @@ __device__ __forceinline__ float Pow(float x, float y) {
   const double r = __builtin_fma(z, t_log.x, -1.0);
   const double y0 = t_log.y + static_cast<double>(k);
   const double r2 = r * r;
-  double yy = __builtin_fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
-  const double pp = __builtin_fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+  double yy = __builtin_fma(0x1.27616c9496e0bp-2, r, AMBER_NEAR_CONSTANT(0xbfd71969a075c67aull) /* -0x1.71969a075c67ap-2 */);
+  const double pp = __builtin_fma(0x1.ec70a6ca7baddp-2, r, AMBER_NEAR_CONSTANT(0xbfe7154748bef6c8ull) /* -0x1.7154748bef6c8p-1 */);
   const double r4 = r2 * r2;
   double q = __builtin_fma(0x1.71547652ab82bp0, r, y0);
   q = __builtin_fma(pp, r2, q);
@@ -453,7 +464,7 @@ __device__ __forceinline__ float Pow(float x, float y) {
   uint64_t t = kGlibcExp2Tab[ki & 31ull];
   t += (ki + sign_bias) << 47;
   const double sc = __longlong_as_double(static_cast<long long>(t));
-  const double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
+  const double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, AMBER_NEAR_CONSTANT(0x3fcebfce50fac4f3ull) /* 0x1.ebfce50fac4f3p-3 */);
   const double rr2 = rr * rr;
   double e = __builtin_fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
   e = __builtin_fma(zz, rr2, e);
@@ -1174,6 +1185,15 @@ __device__ __forceinline__ V3 Radiance(const DevMaterial& m, V3 normal, V3 dir_o
 __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 dir_out, uint64_t& rng, V3& dir_in, V3& weight) {
   const V3 rho = ld3(m.rho);
   const uint32_t kind = m.kind;
+#ifdef AMBER_HOIST_MIRROR   /* diagnostic only ("the stamps build that lost rays"): the common-subexpression form of commit 778d0a2 */
+  const float hoisted_cos_o = Dot(dir_out, normal);
+  const V3 hoisted_mirror = PerfectReflection(dir_out, normal, hoisted_cos_o);
+#define AMBER_COS_O() hoisted_cos_o
+#define AMBER_MIRROR(c_) hoisted_mirror
+#else
+#define AMBER_COS_O() Dot(dir_out, normal)
+#define AMBER_MIRROR(c_) PerfectReflection(dir_out, normal, c_)
+#endif
   if (kind == MAT_LAMBERTIAN || kind == MAT_PHONG) {
     // Lambertian (material_lambertian.cc:61-70, HemispherePSA sampling.h:234-265) and Phong (material_phong.cc:81-106,
     // CosinePower sampling.h:267-300) share the lobe construction -- orthonormal basis, two uniforms, sin/cos of phi,
@@ -1181,8 +1201,8 @@ __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 
     // so a wave with lanes on both materials pays for the shared part once; each lane still executes exactly the
     // operations of its own material (Phong re-samples until the direction is on the side of dir_out).
     const bool phong = kind == MAT_PHONG;
-    const float signed_cos_o = Dot(dir_out, normal);
-    const V3 w = phong ? PerfectReflection(dir_out, normal, signed_cos_o) : (signed_cos_o > 0.0f ? normal : -normal);
+    const float signed_cos_o = AMBER_COS_O();
+    const V3 w = phong ? AMBER_MIRROR(signed_cos_o) : (signed_cos_o > 0.0f ? normal : -normal);
     V3 u, v; OrthonormalBasis(w, u, v);                  // CosinePower rebuilds the same basis on every attempt
     // The reference's Phong loop re-samples forever when no direction of the lobe lies on dir_out's side (possible with a
     // normal that is not of unit length); a kernel must terminate, so attempt AMBER_PHONG_MAX_TRIES is accepted as it
@@ -1209,13 +1229,13 @@ __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 
       break;
     }
   } else if (kind == MAT_SPECULAR) {                     // material_specular.cc:62-70
-    dir_in = PerfectReflection(dir_out, normal, Dot(dir_out, normal));
+    dir_in = AMBER_MIRROR(AMBER_COS_O());
     weight = 1.0f * rho;
   } else if (kind == MAT_REFRACTION) {                   // material_refraction.cc:177-220
-    const float signed_cos_alpha = Dot(dir_out, normal);
+    const float signed_cos_alpha = AMBER_COS_O();
     const float ior = signed_cos_alpha > 0.0f ? m.aux0 : m.param;   // 1 / ior when entering
     const float squared_cos_beta = 1.0f - (1.0f - signed_cos_alpha * signed_cos_alpha) * (ior * ior);
-    const V3 dir_r = PerfectReflection(dir_out, normal, signed_cos_alpha);
+    const V3 dir_r = AMBER_MIRROR(signed_cos_alpha);
     if (squared_cos_beta < 0.0f) {
       dir_in = dir_r; weight = 1.0f * rho;
     } else {
@@ -1238,6 +1258,8 @@ __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 
   } else {                                               // DiffuseLight: Scatter() (material_diffuse_light.h:185-194)
     dir_in = v3(0.f, 0.f, 0.f); weight = v3(0.f, 0.f, 0.f);
   }
+#undef AMBER_COS_O
+#undef AMBER_MIRROR
 }
 
 // Scene::SampleImportance: identical to SampleLight for the symmetric forwarders, Eye and DiffuseLight

@@ -155,7 +155,8 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
   __shared__ DevObject lds_objects[kTwoPhase ? AMBER_MAX_LDS_OBJECTS : 1];
   __shared__ uint4 lds_pool[4][64 * kChunks];                 // [wave][slot * kChunks + chunk]
   if (kTwoPhase) StageObjects(sc, lds_objects);
-  uint4* pool = lds_pool[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];   // wave-uniform, and the compiler knows it: the pool address stays in an SGPR
+  const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, and the compiler knows it: what derives from it stays in SGPRs
+  uint4* pool = lds_pool[wave_in_block];
 
   uint32_t claim_next = 0, claim_end = 0;    // wave-uniform: paths claimed from the global queue, not yet generated
   uint32_t pool_count = 0;                   // wave-uniform: rays in the pool (slots [0, pool_count))
@@ -163,7 +164,17 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
   bool exhausted = false;                    // wave-uniform: the global queue is empty
   bool retired = false, alive = false;
   uint32_t q = 0;                            // path of this lane
-  V3 meas = v3(0.f, 0.f, 0.f);
+  // The measurement is NOT kept in registers between bounces: emitted radiance is non-zero only on a DiffuseLight, whose
+  // scatter weight 0 ends the path, so a path that continues has measurement +0 -- unless a weight has become inf or NaN
+  // (inf * 0 = NaN: degenerate scenes), and such a path parks its measurement in global memory and sets `carries`.
+  bool carries = false;
+  // (its address is formed where it is used, from a thread index the optimiser cannot see through: hoisted out of the
+  //  persistent loop, the pointer is the one value the register cap pushes into scratch)
+  auto carried_slot = [&]() -> float* {
+    const uint32_t t = wave_in_block * 64u + BvhStackHybrid::LaneId();     // = threadIdx.x, from an SGPR and two v_mbcnt
+    return a.carried + (static_cast<size_t>(blockIdx.x) * 256u + t) * 3u;
+  };
+#define AMBER_CARRIED() carried_slot()
   V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), w = v3(0.f, 0.f, 0.f);
   uint64_t rng = 1;
   uint32_t casts = 0;
@@ -240,7 +251,7 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
           const float wx = __uint_as_float(c1.z);
           if (kLight) { const uint4 c3 = pool[sl * kChunks + (kChunks - 1)]; w = v3(wx, __uint_as_float(c3.x), __uint_as_float(c3.y)); }
           else w = v3(wx, wx, wx);
-          meas = v3(0.f, 0.f, 0.f);
+          carries = false;
           casts = 0;
           if (kSig) { sig_obj = 2166136261u; sig_t = 2166136261u; }
           alive = true;
@@ -255,7 +266,9 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
 
     rays_wave += static_cast<uint32_t>(__popcll(__ballot(alive)));
     bool emit = false;
+    V3 meas = v3(0.f, 0.f, 0.f);
     if (alive) {
+      if (!kLight && carries) meas = ld3(AMBER_CARRIED());
       if (kLight) {
         const uint32_t plocal = q / a.n_samples;
         const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, a.path_offset + plocal, a.first_sample + (q - plocal * a.n_samples), sc.sensor.size_f};
@@ -269,11 +282,16 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
       } else {
         alive = PathStep<false, kEngine>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG);
       }
-      emit = !kLight && !alive && ((__float_as_uint(meas.x) | __float_as_uint(meas.y) | __float_as_uint(meas.z)) != 0u);   // anything but +0 (RGB)
+      if (!kLight) {
+        const bool nz = (__float_as_uint(meas.x) | __float_as_uint(meas.y) | __float_as_uint(meas.z)) != 0u;   // anything but +0 (RGB)
+        emit = !alive && nz;
+        if (alive && nz) { float* c = AMBER_CARRIED(); c[0] = meas.x; c[1] = meas.y; c[2] = meas.z; carries = true; }
+      }
     }
     if (!kLight) EmitRecords(a, emit, q, meas, rec_next, rec_end);
   }
 
+#undef AMBER_CARRIED
   if (!kLight) CloseRecords(a, rec_next, rec_end);
 #ifdef AMBER_STAMPS
   if (lane == 0 && a.stamps) for (int k = 0; k < 8; k++) atomicAdd(a.stamps + k, stamp_ctx->acc[k]);
@@ -1232,20 +1250,25 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
   if (!h->h_rec_count) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_rec_count), sizeof(unsigned int), hipHostMallocDefault));
   if (!h->pending_event) HIP_TRY(hipEventCreateWithFlags(&h->pending_event, hipEventDisableTiming));
   const uint32_t n_blocks = PathBlocks(h, n_paths);
+  {
+    // measurements carried across bounces (degenerate paths only): pt_megakernel 3 floats per thread of the grid, pt_bvh_pool_kernel per ray of a wave
+    const size_t carried = bvh ? static_cast<size_t>(h->n_cus) * AMBER_BVH_POOL_WGS * 4u * AMBER_BVH_POOL_CARRIED_PER_WAVE
+                               : static_cast<size_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth) * 256u * 3u;
+    if (carried > h->carried_floats) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (h->d_carried) { HIP_TRY(hipFree(h->d_carried)); h->d_carried = nullptr; h->carried_floats = 0; }
+      hipError_t e = hipMalloc(&h->d_carried, carried * sizeof(float));
+      if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(carried measurements): ") + hipGetErrorString(e));
+      h->carried_floats = carried;
+    }
+  }
   if (bvh) {
     const size_t stack_ints = static_cast<size_t>(h->n_cus) * AMBER_BVH_POOL_WGS * 256u * AMBER_BVH_POOL_GLOBAL_LEVELS;
-    const size_t carried = static_cast<size_t>(h->n_cus) * AMBER_BVH_POOL_WGS * 4u * AMBER_BVH_POOL_CARRIED_PER_WAVE;
     if (stack_ints > h->bvh_stack_ints) {
       if (h->d_bvh_stack) { HIP_TRY(hipFree(h->d_bvh_stack)); h->d_bvh_stack = nullptr; h->bvh_stack_ints = 0; }
       hipError_t e = hipMalloc(&h->d_bvh_stack, stack_ints * sizeof(int32_t));
       if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(traversal stacks): ") + hipGetErrorString(e));
       h->bvh_stack_ints = stack_ints;
-    }
-    if (carried > h->carried_floats) {
-      if (h->d_carried) { HIP_TRY(hipFree(h->d_carried)); h->d_carried = nullptr; h->carried_floats = 0; }
-      hipError_t e = hipMalloc(&h->d_carried, carried * sizeof(float));
-      if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(carried measurements): ") + hipGetErrorString(e));
-      h->carried_floats = carried;
     }
   }
   RenderArgs a{};

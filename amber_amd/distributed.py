@@ -50,8 +50,10 @@ def stripe_partition(height: int, world_size: int, stripe_rows: int = STRIPE_ROW
 
 class RowGatherer:
     """The job's single collective with its buffers and index tensors allocated once: gathers every rank's rows
-    (tensor (n_r, width, 3) on the backend's device) to rank `dst` and scatters them to their global row positions.
-    At 8 ranks a Cornell step is 13 ms per rank, so per-step allocations and index uploads would show."""
+    (tensor (n_r, width, 3) on the backend's device) to rank `dst` and puts them at their global row positions.
+    At 8 ranks a Cornell step is ~8 ms per rank, so per-step allocations, index uploads and small launches would show:
+    the ranks' rows land in ONE buffer (world, max_rows, width, 3) and ONE index_select with a permutation built here
+    moves them into global row order; a rank whose band fills its slot sends the band tensor itself (no staging copy)."""
 
     def __init__(self, parts, width: int, rank: int, world_size: int, device, dst: int = 0, force_collective: bool = False):
         import torch
@@ -62,26 +64,36 @@ class RowGatherer:
         self.height = sum(len(p["index"]) for p in parts)
         self.collective = world_size > 1 or force_collective     # force_collective: run the gather even for one rank (RCCL smoke test)
         if self.collective:
-            self.send = torch.zeros((self.max_rows, width, 3), dtype=torch.float32, device=device)
+            self.send = None if self.n == self.max_rows else torch.zeros((self.max_rows, width, 3), dtype=torch.float32, device=device)
             if rank == dst:
-                self.recv = [torch.empty_like(self.send) for _ in range(world_size)]
+                self.recv_all = torch.empty((world_size, self.max_rows, width, 3), dtype=torch.float32, device=device)
+                self.recv = [self.recv_all[r] for r in range(world_size)]
                 self.full = torch.empty((self.height, width, 3), dtype=torch.float32, device=device)
-                self.index = [torch.as_tensor(np.asarray(p["index"]), dtype=torch.long, device=device) for p in parts]
+                perm = np.empty(self.height, np.int64)                   # global row y <- slot r * max_rows + its local row
+                for r, p in enumerate(parts):
+                    perm[np.asarray(p["index"], np.int64)] = r * self.max_rows + np.arange(len(p["index"]), dtype=np.int64)
+                self.perm = torch.as_tensor(perm, dtype=torch.long, device=device)
 
     def __call__(self, local_rows):
         """Returns the (height, width, 3) image on `dst` (a buffer reused by the next call), None elsewhere."""
+        import torch
         import torch.distributed as dist
 
         if not self.collective:
             return local_rows.reshape(self.n, self.width, 3)
-        if self.n:
-            self.send[: self.n].copy_(local_rows.reshape(self.n, self.width, 3))
-        dist.gather(self.send, gather_list=self.recv if self.rank == self.dst else None, dst=self.dst)
+        rows = local_rows.reshape(self.n, self.width, 3)
+        if self.send is None and rows.is_contiguous():
+            send = rows
+        else:
+            if self.send is None:
+                self.send = torch.zeros((self.max_rows, self.width, 3), dtype=torch.float32, device=rows.device)
+            if self.n:
+                self.send[: self.n].copy_(rows)
+            send = self.send
+        dist.gather(send, gather_list=self.recv if self.rank == self.dst else None, dst=self.dst)
         if self.rank != self.dst:
             return None
-        for r, p in enumerate(self.parts):
-            if len(p["index"]):
-                self.full.index_copy_(0, self.index[r], self.recv[r][: len(p["index"])])
+        torch.index_select(self.recv_all.view(self.world * self.max_rows, self.width, 3), 0, self.perm, out=self.full)
         return self.full
 
 

@@ -12,6 +12,10 @@ started by a launcher; under a launcher (RANK / WORLD_SIZE in the environment) i
 
 Prints ONE JSON line on rank 0.  `value` = rays of all ranks / max-over-ranks wall time of the K timed
 steps (inputs resident in HBM; barrier + synchronize on both sides).
+
+After the timed steps, and outside `value`, the N = 1 run also measures the other BASELINE configurations on this one GPU
+(`secondary`): config 3 at its full size, and ONE rank's share of configs 4 and 5 (its stripes of the real frame, one launch
+of the real samples-per-launch; config 5 with max depth 16).
 """
 from __future__ import annotations
 
@@ -119,9 +123,54 @@ def latest_profile_summary():
             d = json.loads(p.read_text())
         except Exception:
             continue
-        if isinstance(d, dict) and "valu" in d:
+        if isinstance(d, dict) and "valu" in d and d.get("kernel") == "pt_megakernel":
             best = (p.name, d)
     return best
+
+
+def secondary_workloads(amber_amd, np, seed: int, device: int):
+    """BASELINE configs 3, 4 and 5 on THIS GPU, after the timed steps and outside `value` (VERDICT r02 item 2): config 3 whole;
+    for the multi-GPU configs the share of rank 0 -- its interleaved 8-row stripes of the real frame -- for ONE launch of the
+    real samples-per-launch (1024).  Every entry: kernel time by hipEvents, rays, Mrays/s, the section-8(d) contract fraction."""
+    from amber_amd import scenes
+    from amber_amd.distributed import stripe_partition
+    out = []
+
+    def run(name, scene, W, H, spp, engine_name, max_depth=0, world=1, warm=8):
+        part = stripe_partition(H, world)[0]
+        t0 = time.perf_counter()
+        pt = amber_amd.PathTracer(scene, amber_amd.Sensor.default(W, H), seed=seed, device=device, max_depth=max_depth,
+                                  rows=part["rows"], stripe=part["stripe"])
+        t_create = time.perf_counter() - t0
+        pt.render_pass(0, warm); pt.sync(); pt.clear()                       # first launch of a handle: page-in + record-density probe
+        t0 = time.perf_counter()
+        pt.render_pass(0, spp); pt.sync()
+        wall = time.perf_counter() - t0
+        n_launch, ms = pt.kernel_time()
+        rays = pt.ray_count()
+        rows = len(part["index"])
+        entry = {"workload": name, "frame": [W, H], "rows_of_this_rank": rows, "ranks_of_the_config": world, "spp_in_launch": spp, "max_depth": max_depth,
+                 "engine": engine_name, "launches": n_launch, "kernel_ms": round(ms, 3), "wall_ms": round(wall * 1e3, 3), "rays": int(rays),
+                 "paths": rows * W * spp, "Mrays_s": round(rays / ms / 1e3, 1) if ms > 0 else None,
+                 "roofline_frac": round(rays * BYTES_PER_RAY / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None,
+                 "create_s": round(t_create, 3)}
+        pt.close()
+        return entry
+
+    t0 = time.perf_counter()
+    spheres = amber_amd.HostScene.create_arrays(**scenes.random_spheres(1_000_000, 7))
+    t_scene = time.perf_counter() - t0
+    e = run("config 3: 1M random spheres (deep BVH) 1920x1080 @ 256 spp, 1 GPU", spheres, 1920, 1080, 256,
+            "work-queue megakernel, engine BVH (16-bit quantised 2-wide tree, resumable LDS-stack traversal)")
+    e["host_scene_s"] = round(t_scene, 3)
+    out.append(e)
+    spheres.close()
+    cornell = amber_amd.HostScene.cornell_box()
+    out.append(run("config 4: Cornell + glass/refractive 2048x2048 @ 4096 spp on 4 GPUs -- rank 0's stripes, one 1024-spp launch of its 4",
+                   cornell, 2048, 2048, 1024, "work-queue megakernel, two-phase closest hit", world=4))
+    out.append(run("config 5: 3840x2160 @ 8192 spp, max depth 16, on 8 GPUs -- rank 0's stripes, one 1024-spp launch of its 8",
+                   cornell, 3840, 2160, 1024, "work-queue megakernel, two-phase closest hit", max_depth=16, world=8))
+    return out
 
 
 def free_port() -> int:
@@ -162,6 +211,7 @@ def main():
     ap.add_argument("--spp-per-launch", type=int, default=1024)
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs 3 / 4 / 5 measurements that follow the timed steps (N = 1)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single GPU: every rank uses device 0 and the gather runs over gloo on host copies")
     ap.add_argument("--engine", default="auto", choices=["auto", "list", "two_phase", "bvh", "wavefront"],
@@ -221,7 +271,10 @@ def main():
     launches = [(s, min(args.spp_per_launch, args.spp - s)) for s in range(0, args.spp, args.spp_per_launch)]
     gather = RowGatherer(parts, W, rank, world, "cpu" if (args.rehearse_on_one_gpu and world > 1) else fb.device, force_collective=force_collective)   # buffers allocated once
 
-    def step():
+    collective = world > 1 or force_collective
+    gather_events = []                                                 # (start, end) on the render stream: the gather + row re-ordering of a step
+
+    def step(timed=False):
         tracer.clear()
         for first, n in launches:
             tracer.render_pass(first, n)
@@ -229,7 +282,14 @@ def main():
             tracer.sync()
             return gather(fb.cpu())                                # gloo: host tensors
         with torch.cuda.stream(render_stream):
-            return gather(fb)                                      # the single collective of the job
+            if timed and collective:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(render_stream)
+                img_ = gather(fb)                                  # the single collective of the job
+                e1.record(render_stream)
+                gather_events.append((e0, e1))
+                return img_
+            return gather(fb)
 
     def fence():
         torch.cuda.synchronize()
@@ -244,7 +304,7 @@ def main():
     total_rays_local, kernel_ms, n_launch = 0, 0.0, 0
     img = None
     for _ in range(args.steps):
-        img = step()
+        img = step(timed=True)
         # ray counter and kernel times are read after the step's work is enqueued; download syncs the stream
         total_rays_local += tracer.ray_count()
         nl, ms = tracer.kernel_time()
@@ -256,11 +316,14 @@ def main():
     t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     r = torch.tensor([total_rays_local], dtype=torch.int64, device=red_dev)
     k = torch.tensor([kernel_ms / max(n_launch, 1)], dtype=torch.float64, device=red_dev)
+    gms = [a_.elapsed_time(b_) for a_, b_ in gather_events]            # (the fence above has synchronised them)
+    g = torch.tensor([sum(gms) / len(gms) if gms else 0.0], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
-    dt_max, rays, kern_ms = float(t.item()), int(r.item()), float(k.item())
+        dist.all_reduce(g, op=dist.ReduceOp.MAX)
+    dt_max, rays, kern_ms, gather_ms = float(t.item()), int(r.item()), float(k.item()), float(g.item())
 
     if rank == 0 and os.environ.get("AMBER_BENCH_SAVE_IMAGE") and img is not None:
         torch.cuda.synchronize()
@@ -285,17 +348,20 @@ def main():
                        "parallelism": f"stripes{world}x8rows", "launches_per_step": len(launches), "engine": "work-queue megakernel, two-phase closest hit" if args.engine == "auto" else args.engine,
                        "math": {amber_amd.MATH_GLIBC: "glibc 2.35 sincosf/powf kernels (the reference's libm)", amber_amd.MATH_PORTABLE: "portable (measurement build)"}[amber_amd.math_mode()]},
             "ranks": world, "collective_backend": ("rccl" if backend == "nccl" else backend),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "valu-issue", "contract": "hbm-equivalent (SURVEY 8(d): rays x 96 B of algorithmic ray state / kernel time, against the 8 TB/s HBM peak)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel": "pt_megakernel" if args.engine != "wavefront" else "wf_generate + wf_bounce launches of one batch", "kernel_ms": round(kern_ms, 3),
-                         "note": "contractual figure (SURVEY 8(d)): achieved = rays per launch (rank 0) x 96 B algorithmic ray-state bytes / mean launch "
-                                 "duration (hipEvents). The kernel keeps ray state in VGPRs: its measured HBM traffic is `traffic` bytes per launch and the "
-                                 "resource that binds it is VALU issue -- see `valu`"},
+                         "note": "achieved = rays per launch (rank 0) x 96 B / mean launch duration (hipEvents on the render stream), frac = achieved / 8000: the contractual "
+                                 "figure.  The kernel keeps ray state in VGPRs and never touches that roof: its measured HBM traffic is `traffic` bytes per launch; what binds "
+                                 "it is VALU instruction issue -- see `valu` (from the committed rocprofv3 profile, printed only while that profile's kernel time matches this run's)"},
         }
+        if collective:
+            out["gather_ms"] = round(gather_ms, 4)                     # per step: the gather + re-ordering into global row order, on the render stream (max over ranks)
         if backend == "nccl":
             out["rccl_ranks"] = world
         profs = sorted((ROOT / "profiles").glob("r*_hbm_traffic.json"))      # latest committed rocprofv3 PMC summary
-        if profs:
+        if profs and args.engine == "auto" and args.spp == 1024 and args.width == 1024:
             try:
                 out["roofline"]["traffic"] = json.loads(profs[-1].read_text()).get("hbm_bytes_per_launch")
                 out["roofline"]["traffic_source"] = f"profiles/{profs[-1].name}"
@@ -304,8 +370,15 @@ def main():
             except Exception:
                 pass
         summ = latest_profile_summary()
-        if summ:
-            out["roofline"]["valu"] = dict(summ[1]["valu"], source=f"profiles/{summ[0]}")
+        if summ and args.engine == "auto":
+            prof_ms = summ[1].get("kernel_trace", {}).get("average_ns", 0.0) * 1e-6
+            # the counters describe the kernel of THAT profile: a kernel that has changed since must not inherit them
+            if world == 1 and args.spp == 1024 and args.width == 1024 and prof_ms > 0 and abs(prof_ms - kern_ms) <= 0.05 * kern_ms:
+                out["roofline"]["valu"] = dict(summ[1]["valu"], source=f"profiles/{summ[0]}", profile_kernel_ms=round(prof_ms, 3))
+            else:
+                out["roofline"]["valu"] = None
+                out["roofline"]["valu_withheld"] = (f"profiles/{summ[0]} measured {prof_ms:.3f} ms per launch, this run {kern_ms:.3f} ms (or another workload / rank count): "
+                                                    "more than 5 % apart, the profile is stale for this kernel -- re-run tools/profile.sh")
         if world == 1:
             try:
                 bw = measured_copy_bandwidth(torch, f"cuda:{local_rank}")
@@ -314,6 +387,13 @@ def main():
             except Exception as e:                                     # never lose the bench line over the side measurement
                 out["roofline"]["measured_copy_bw"] = None
                 out["roofline"]["measured_copy_bw_error"] = str(e)[:120]
+        if world == 1 and not args.no_secondary:
+            try:
+                tracer.close()                                         # free the headline handle's buffers first
+                out["secondary"] = secondary_workloads(amber_amd, np, args.seed, local_rank)
+            except Exception as e:                                     # never lose the bench line over the side measurements
+                out["secondary"] = None
+                out["secondary_error"] = str(e)[:200]
         if not args.no_cpu_baseline and world == 1:                    # reported at N = 1 only
             out["cpu_baseline"], out["parity"] = cpu_baseline(amber_amd, W, args.spp, args.seed)
         sys.stdout.flush()

@@ -9,8 +9,8 @@ For every band of rows:
   * image: the GPU's row sums against oracle(XorShift sampler, reference BVH, MATH_LIBM) -- bits, and the north star's
     tolerance (per-pixel relative L2 <= 1e-4; a pixel whose oracle value is 0 must be 0);
   * rays: Scene::Cast counts;
-  * paths: per-path signatures (hash of the hit-object sequence | hash of the hit distances) from
-    amber_hip_kat_signatures and oracle_path_signatures: `diverged_paths` = paths whose object sequences AND hit
+  * paths: per-path signatures (hash of the hit-object sequence | hash of the hit distances) from the PRODUCT kernel
+    (amber_hip_pt_signatures; cross-checked against amber_hip_kat_signatures) and oracle_path_signatures: `diverged_paths` = paths whose object sequences AND hit
     distances differ, `inexact_paths` = same objects but some hit distance differs in a bit, `tie_paths` = every hit
     distance identical but a different object index somewhere: an exact distance tie between two objects (a ray through
     the shared edge of two triangles), which the reference's BVH and its List acceleration resolve differently
@@ -67,7 +67,10 @@ def compare_rows(amber, width: int = 1024, spp: int = 1024, seed: int = 12345, b
         out["pixels_over_tol"] += int((rel > tol).sum())
         out["max_rel_l2"] = float(max(out["max_rel_l2"], rel.max()))
         if signatures:
-            sg = pt.kat_signatures(0, spp)
+            # from the kernel that rendered the rows above (pt_megakernel's signature instantiation), not only from the per-thread
+            # known-answer kernel: both must tell the same story
+            sg = pt.render_signatures(0, spp)
+            out["signature_kernel_mismatches"] = out.get("signature_kernel_mismatches", 0) + int((sg != pt.kat_signatures(0, spp)).sum())
             so = osc.path_signatures(width, width, seed, 0, spp, (y0, y1), math=math, threads=threads)
             lo_g, lo_o = sg & np.uint64(0xffffffff), so & np.uint64(0xffffffff)
             hi_g, hi_o = sg >> np.uint64(32), so >> np.uint64(32)

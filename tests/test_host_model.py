@@ -147,3 +147,23 @@ def test_stripe_partition_covers_every_row_once():
                 assert np.array_equal(ys, p["index"])
         counts = [len(p["index"]) for p in parts]
         assert max(counts) - min(counts) <= s
+
+
+def test_no_spill_code_in_front_of_an_exec_restore():
+    """The compiled product kernels are free of the one hipcc miscompile this code base has met (tools/check_spill_placement.py,
+    DESIGN.md section 7): VGPR spill stores / reloads placed before the `s_or_b64 exec` of a join block run for the lanes of the
+    `if` body only, and the others later read stale scratch -- round 2's diagnostic build lost 5 % of its rays that way.
+    hipcc cross-compiles without a GPU, so this runs everywhere; the known-bad pattern itself is a fixture."""
+    import shutil
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "tools"))
+    import check_spill_placement as lint
+    bad = (Path(__file__).parent / "golden" / "misplaced_spill_r02_stamps.s").read_text()
+    found = list(lint.scan(bad))
+    assert len(found) == 3 and all("Folded Spill" in t for _, _, _, t in found)          # the lint sees the real thing
+    if shutil.which("hipcc") is None:
+        import pytest
+        pytest.skip("no hipcc on this box")
+    assert list(lint.scan(lint.compile_to_asm([]))) == []
