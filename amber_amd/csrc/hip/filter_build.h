@@ -154,9 +154,15 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, const float c
       for (size_t c = 0; c < cls_first.size() && cls[gi] < 0; c++) {
         const Group& f = groups[cls_first[c]];
         const double dot = f.n[0] * groups[gi].n[0] + f.n[1] * groups[gi].n[1] + f.n[2] * groups[gi].n[2];
-        if (std::fabs(std::fabs(dot) - 1.0) <= 1e-12) {       // numerically the same direction: the float normals are then made identical
+        const double sgn = dot < 0 ? -1.0 : 1.0;
+        // The same direction only if the BINARY32 normals the device will use are identical up to sign: the member then
+        // adopts the class's normal without moving its plane (its d0 was computed with its own normal; a merely nearly
+        // parallel plane -- 1e-6 rad passes a 1e-12 test on the dot product -- would be tilted by that angle times the scene
+        // size, which the rounding-only tolerances kt / ktol do not cover).
+        bool same = true;
+        for (int k = 0; k < 3; k++) same = same && static_cast<float>(groups[gi].n[k]) == static_cast<float>(sgn * f.n[k]);
+        if (same) {
           cls[gi] = static_cast<int>(c);
-          const double sgn = dot < 0 ? -1.0 : 1.0;
           for (int k = 0; k < 3; k++) groups[gi].n[k] = sgn * f.n[k];
           groups[gi].flip = dot < 0;
         }

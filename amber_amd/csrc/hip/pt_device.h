@@ -885,6 +885,10 @@ __device__ __forceinline__ void BvhBegin(const DevScene& sc, V3 o, V3 d, BvhTrav
 // the object index (tie rule, reported hit) is fetched only when the distance can win.  A lane runs stage 2 once per
 // surviving sphere, so a wave makes as many trips through it as its worst lane has survivors (mostly one) instead of one
 // per sphere of the leaf.  The operations on each sphere are those of IntersectSphere; only their grouping differs.
+#define AMBER_IDX_LAZY 0x7ffffffe   /* HitRec.idx of engine BVH: "slot is valid, the scene index has not been looked up" (> every real index) */
+__device__ __forceinline__ void BvhResolveIndex(const DevScene& sc, HitRec& h) {
+  if (h.idx == AMBER_IDX_LAZY) h.idx = static_cast<int>(sc.bvh_prims[h.slot]);
+}
 __device__ __forceinline__ void SphereCoefficients(float4 s, V3 o, V3 d, float& b, float& c) {
   const V3 co = v3(s.x, s.y, s.z) - o;
   b = -2.0f * Dot(co, d);
@@ -909,8 +913,16 @@ __device__ __forceinline__ void IntersectSphereLeaf(const DevScene& sc, uint32_t
       bool ok = true;
       if (alpha > AMBER_KEPS) t = alpha; else if (beta > AMBER_KEPS) t = beta; else { ok = false; t = 0.f; }
       if (ok && IsFinite(t) && !(t > best.t)) {
-        const int i = static_cast<int>(sc.bvh_prims[first + k]);
-        if (Closer<true>(t, i, best)) { best.t = t; best.idx = i; best.slot = static_cast<int>(first + k); }
+        // The scene index of a sphere matters only for the tie rule: a strictly closer hit wins whatever its index, so the
+        // dependent load of bvh_prims[] -- one more memory round trip per accepted hit, on the traversal's critical path --
+        // is left out and the index marked unknown (AMBER_IDX_LAZY); an exact tie, or a consumer that reports the object
+        // (traces, signatures, known-answer kernels: BvhResolveIndex), looks it up then.
+        if (t < best.t) { best.t = t; best.idx = AMBER_IDX_LAZY; best.slot = static_cast<int>(first + k); }
+        else {
+          BvhResolveIndex(sc, best);
+          const int i = static_cast<int>(sc.bvh_prims[first + k]);
+          if (i < best.idx) { best.idx = i; best.slot = static_cast<int>(first + k); }
+        }
       }
     }
   }
@@ -1065,6 +1077,7 @@ __device__ __forceinline__ void BvhLeafPrivate(const DevScene& sc, int32_t leaf,
   if (ref & 4u) {                                           // spheres only: one 16-byte record each
     IntersectSphereLeaf(sc, first, count, o, d, best AMBER_STAMP_ARG);
   } else {
+    BvhResolveIndex(sc, best);                                     // the tie rule of Closer<true> compares real indices
     for (uint32_t k = 0; k < count; ++k) {
       const uint32_t oi = sc.bvh_prims[first + k];                 // scene index (tie rule, reported hit); independent of ...
       const DevObject& ob = sc.bvh_objects[first + k];             // ... the record itself, stored in leaf order: no dependent load
@@ -1103,6 +1116,7 @@ __device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_s
   BvhBegin(sc, o, d, tr, best);
   while (BvhRound(sc, lds_stack, o, d, tr, best)) {}
   if (__any(tr.overflow)) { if (tr.overflow) ClosestHitLeafList(sc, o, d, best); }
+  BvhResolveIndex(sc, best);                                       // callers of this form report the object
 }
 
 enum { ENGINE_LIST = 1, ENGINE_TWO_PHASE = 2, ENGINE_BVH = 3 };
