@@ -78,7 +78,7 @@ ABI_SYMBOLS = [
     "amber_hip_pt_create", "amber_hip_pt_render_pass", "amber_hip_pt_clear", "amber_hip_pt_sync",
     "amber_hip_pt_download", "amber_hip_pt_device_framebuffer", "amber_hip_pt_stream", "amber_hip_pt_local_rows", "amber_hip_pt_kernel_time", "amber_hip_pt_destroy",
     "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_math_mode", "amber_hip_device_count", "amber_hip_lt_trace", "amber_hip_lt_trace_range",
-    "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math", "amber_hip_kat_signatures", "amber_hip_pt_signatures",
+    "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math", "amber_hip_kat_signatures", "amber_hip_pt_signatures", "amber_hip_kat_traversal_rate",
     "amber_host_cornell_box", "amber_host_scene_import", "amber_host_scene_create", "amber_host_scene_destroy", "amber_host_scene_flatten",
     "amber_host_pt_create", "amber_host_render", "amber_host_render_devices", "amber_host_last_error", "amber_host_tonemap", "amber_host_export",
 ]
@@ -131,6 +131,8 @@ def load_library() -> C.CDLL:
     lib.amber_hip_kat_trace.argtypes = [vp, u32, vp, vp, u32, vp, vp]
     lib.amber_hip_kat_math.argtypes = [i32, i32, u32, vp, vp]
     lib.amber_hip_kat_signatures.argtypes = [vp, u32, u32, vp]
+    if hasattr(lib, "amber_hip_kat_traversal_rate"):
+        lib.amber_hip_kat_traversal_rate.argtypes = [vp, u32, vp, vp, u32, u32, u32, vp, vp, C.POINTER(C.c_double)]
     if hasattr(lib, "amber_hip_pt_signatures"):    # absent only in older builds loaded by tools/ab_lib.py
         lib.amber_hip_pt_signatures.argtypes = [vp, u32, u32, vp]
     lib.amber_host_cornell_box.restype = vp
@@ -369,6 +371,15 @@ class PathTracer:
         _check(load_library().amber_hip_kat_trace(self._h, len(p), p.ctypes.data, s.ctypes.data, max_bounces, rec.ctypes.data,
                                                   casts.ctypes.data))
         return rec, casts
+
+    def kat_traversal_rate(self, origins, dirs, waves: int = 5, refill_min: int = 16, repeats: int = 3):
+        """Engine BVH's traversal alone: returns (object index, t, best kernel ms) for the rays."""
+        o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+        n = len(o)
+        obj, t, ms = np.empty(n, np.int32), np.empty(n, np.float32), C.c_double()
+        _check(load_library().amber_hip_kat_traversal_rate(self._h, n, o.ctypes.data, d.ctypes.data, waves, refill_min, repeats, t.ctypes.data,
+                                                           obj.ctypes.data, C.byref(ms)))
+        return obj, t, ms.value
 
     def kat_signatures(self, first_sample: int, n_samples: int) -> np.ndarray:
         """(rows, width, n_samples) uint64: low word = hash of the path's hit-object sequence, high word = hash of its hit distances."""

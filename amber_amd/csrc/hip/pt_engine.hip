@@ -570,6 +570,7 @@ __global__ void reduce_partials_kernel(float* __restrict__ fb, const float* __re
 }
 
 #include "bvh_pool.inc"
+#include "bvh_stream.inc"
 #include "wavefront.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -1738,6 +1739,62 @@ int amber_hip_kat_signatures(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out, d_out.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return AMBER_OK;
+}
+
+// Traversal alone (bvh_stream.inc): closest hits of n rays through engine BVH's resumable traversal in a kernel that does nothing
+// else, `waves` resident waves per SIMD (4, 5, 6 or 8), idle lanes refilled once `refill_min` of a wave's lanes are idle.
+// Returns t (NaN = miss) and the object index per ray, and the kernel time of `repeats` launches (the best one).
+int amber_hip_kat_traversal_rate(amber_hip_pt* h, uint32_t n, const float* origins, const float* dirs, uint32_t waves, uint32_t refill_min, uint32_t repeats,
+                                 float* out_t, int32_t* out_object, double* best_ms) {
+  // one launch walks the ray array `repeats` times (a launch of n * repeats rays); best_ms is the time of that launch
+  if (!h || !origins || !dirs || !out_t || !out_object || n == 0) return Fail(AMBER_EINVAL, "bad argument");
+  if (h->hit_engine != AMBER_ENGINE_BVH) return Fail(AMBER_EINVAL, "the handle's engine is not BVH");
+  if (refill_min == 0 || refill_min > 64) return Fail(AMBER_EINVAL, "refill_min must be in [1, 64]");
+  HIP_TRY(hipSetDevice(h->device));
+  { const int rc = ResolvePending(h); if (rc != AMBER_OK) return rc; }
+  std::vector<float4> packed(2ull * n);
+  for (uint32_t i = 0; i < n; i++) {
+    packed[2ull * i] = make_float4(origins[3ull * i], origins[3ull * i + 1], origins[3ull * i + 2], 0.f);
+    packed[2ull * i + 1] = make_float4(dirs[3ull * i], dirs[3ull * i + 1], dirs[3ull * i + 2], 0.f);
+  }
+  DevBuf<float4> d_rays; DevBuf<float2> d_out; DevBuf<unsigned int> d_next; DevBuf<int32_t> d_stack;
+  HIP_TRY(d_rays.alloc(2ull * n)); HIP_TRY(d_out.alloc(n)); HIP_TRY(d_next.alloc(1));
+  const uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * (waves >= 4 && waves <= 8 ? waves : 5u);
+  HIP_TRY(d_stack.alloc(static_cast<size_t>(n_blocks) * 256u * AMBER_BVH_STACK));
+  HIP_TRY(hipMemcpy(d_rays.p, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  double best = 1e300;
+  const uint64_t n_virtual = static_cast<uint64_t>(n) * (repeats ? repeats : 1u);
+  if (n_virtual > 0xfffffeffull) return Fail(AMBER_EINVAL, "n * repeats must stay below 2^32");
+  const uint32_t nv = static_cast<uint32_t>(n_virtual);
+  for (uint32_t rep = 0; rep < 2u; rep++) {                              // a warm-up launch and the measured one
+    HIP_TRY(hipMemsetAsync(d_next.p, 0, sizeof(unsigned int), h->stream));
+    HIP_TRY(hipEventRecord(e0, h->stream));
+    switch (waves) {
+      case 4: hipLaunchKernelGGL((bvh_trace_rate_kernel<4, 24>), dim3(n_blocks), dim3(256), 0, h->stream, h->scene, nv, d_rays.p, d_out.p, d_next.p, d_stack.p, refill_min, n); break;
+      case 6: hipLaunchKernelGGL((bvh_trace_rate_kernel<6, 24>), dim3(n_blocks), dim3(256), 0, h->stream, h->scene, nv, d_rays.p, d_out.p, d_next.p, d_stack.p, refill_min, n); break;
+      case 8: hipLaunchKernelGGL((bvh_trace_rate_kernel<8, 16>), dim3(n_blocks), dim3(256), 0, h->stream, h->scene, nv, d_rays.p, d_out.p, d_next.p, d_stack.p, refill_min, n); break;
+      default: hipLaunchKernelGGL((bvh_trace_rate_kernel<5, 24>), dim3(n_blocks), dim3(256), 0, h->stream, h->scene, nv, d_rays.p, d_out.p, d_next.p, d_stack.p, refill_min, n); break;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (rep == 1u || ms < best) best = ms;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  std::vector<float2> res(n);
+  HIP_TRY(hipMemcpy(res.data(), d_out.p, n * sizeof(float2), hipMemcpyDeviceToHost));
+  std::vector<uint32_t> prims(h->scene.n_objects);
+  HIP_TRY(hipMemcpy(prims.data(), h->d_bvh_prims, prims.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < n; i++) {
+    int32_t slot; std::memcpy(&slot, &res[i].y, 4);
+    out_object[i] = slot < 0 ? -1 : static_cast<int32_t>(prims[slot]);
+    out_t[i] = slot < 0 ? std::nanf("") : res[i].x;
+  }
+  if (best_ms) *best_ms = best;
   return AMBER_OK;
 }
 

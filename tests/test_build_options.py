@@ -41,25 +41,30 @@ def test_four_wide_bvh_build_matches_engine_list():
 
 
 STAMPS_SCRIPT = r"""
-import sys
+import sys, hashlib
 sys.path.insert(0, %r)
 import amber_amd as A
-assert str(A.library_path()).endswith("libamber_hip_stamps.so")
+assert str(A.library_path()).endswith(%r)
 sc = A.HostScene.cornell_box(); sn = A.Sensor.default(256, 256)
-rays = {}
-for e in (A.ENGINE_TWO_PHASE, A.ENGINE_LIST, A.ENGINE_BVH):
-    pt = A.PathTracer(sc, sn, engine=e); pt.render_pass(0, 32); pt.sync(); rays[e] = pt.ray_count(); pt.close()
-assert len(set(rays.values())) == 1, rays
-print("STAMPS OK", rays)
+seen = set()
+for rnd in range(4):                      # the miscompile this guards against showed as run-to-run differences (stale scratch)
+    for e in (A.ENGINE_TWO_PHASE, A.ENGINE_LIST, A.ENGINE_BVH):
+        pt = A.PathTracer(sc, sn, engine=e); pt.render_pass(0, 32); img, rays = pt.download(); pt.close()
+        seen.add((rays, hashlib.sha1(img.tobytes()).hexdigest()))
+assert len(seen) == 1, seen
+print("SAME PATHS", seen)
 """
 
 
 @pytest.mark.gpu
 def test_diagnostic_build_renders_the_same_paths():
     """The -DAMBER_STAMPS build (tools/stamps.py, tools/bvh_counters.py) adds clocks and counters, nothing else: every engine
-    must still cast exactly the rays of engine LIST.  (Guards the tools: a hoisted expression once pushed the stamped two-phase
-    kernel's register pressure into a miscompile that lost 5 % of the rays -- in that build only.)"""
+    must cast exactly the rays of engine LIST and produce its image, every time.  Round 2's stamped two-phase kernel lost 5 % of
+    its rays, differently in every run: hipcc had placed VGPR spill stores in front of the `s_or_b64 exec` of a join block, so the
+    Phong lanes reloaded stale scratch (tools/check_spill_placement.py lints the ISA for the pattern).  The
+    product library runs the same loop: its kernels are built at their register caps, where such spills would appear first."""
     subprocess.run(["make", "-C", str(ROOT / "amber_amd" / "csrc"), "stamps"], check=True, capture_output=True, timeout=900)
-    env = dict(os.environ, AMBER_AMD_LIB="libamber_hip_stamps.so")
-    r = subprocess.run([sys.executable, "-c", STAMPS_SCRIPT % str(ROOT)], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and "STAMPS OK" in r.stdout, r.stdout + r.stderr
+    for lib in ("libamber_hip_stamps.so", "libamber_hip.so"):
+        env = dict(os.environ, AMBER_AMD_LIB=lib)
+        r = subprocess.run([sys.executable, "-c", STAMPS_SCRIPT % (str(ROOT), lib)], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "SAME PATHS" in r.stdout, lib + ": " + r.stdout + r.stderr

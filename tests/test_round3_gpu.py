@@ -330,3 +330,25 @@ def test_fresh_fuzz_scenes(amber):
         if seed % 8 < 3:                                               # plain, --scaled and --extreme scenes of the small kind
             oimg, cnt = O.Scene.create(**sc).render_xorshift(W, H, seed, 0, spp)
             assert cnt.casts == ref[1] and np.array_equal(bits(oimg), ref[0]), seed
+
+
+def test_traversal_on_its_own_gives_the_same_closest_hits(amber):
+    """bvh_trace_rate_kernel (engine BVH's resumable traversal in a kernel that does nothing else: the measurement of DESIGN.md
+    section 5) against amber_hip_kat_cast, at every occupancy and at three refill thresholds, incl. rays with zero components,
+    NaN rays and misses, on a scene of all four primitive kinds."""
+    k = _mixed_scene(20000, 3)
+    hs = amber.HostScene.create_arrays(**k)
+    pt = amber.PathTracer(hs, amber.Sensor.default(64, 64), engine=amber.ENGINE_BVH)
+    rng = np.random.default_rng(9)
+    n = 50000
+    org = rng.uniform(-1.3, 1.3, (n, 3)).astype(np.float32); org[: n // 4] = [0, 0, 4]
+    d = rng.normal(size=(n, 3)); d[: n // 4] = np.array([0, 0, -1.0]) + rng.normal(0, 0.2, (n // 4, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[-30:-20, 0] = 0.0; d[-20:-10] = [0, 1, 0]; d[-10:-5] = np.nan; org[-5:] = [50, 50, 50]
+    ref_obj, ref_t, _, _ = pt.kat_cast(org, d)
+    hit = ref_obj >= 0
+    assert 0.5 < hit.mean() < 1.0
+    for waves in (4, 5, 6, 8):
+        for refill in (1, 16, 64):
+            obj, t, ms = pt.kat_traversal_rate(org, d, waves=waves, refill_min=refill, repeats=2)
+            assert np.array_equal(obj, ref_obj) and np.array_equal(bits(t[hit]), bits(ref_t[hit])) and ms > 0, (waves, refill)
