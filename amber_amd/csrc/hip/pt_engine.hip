@@ -53,6 +53,7 @@ struct RenderArgs {
   DevScene scene;
   float* partial;            // pt_bvh_megakernel: [n_chunks][n_pixels][3] per-item sums of this launch
   uint32_t* flags;           // path-granular kernels: bit q set = path q of this launch ended with a non-zero measurement ...
+  uint32_t* touched;         // ... and bit (q / n_samples) of this one: the band pixels that have any record (the reduction skips the others)
   uint4* records;            // ... appended as {q, r, g, b}; q = 0xffffffff marks a reserved slot that was never used
   unsigned int* rec_count;   // slots handed out so far (waves reserve AMBER_REC_BLOCK at a time)
   uint32_t rec_capacity;     // slots of `records`; a launch that needs more is repeated by the host with a larger buffer
@@ -104,6 +105,8 @@ __device__ __forceinline__ void EmitRecords(const RenderArgs& a, bool emit, uint
     const uint32_t slot = rank < room ? rec_next + rank : fresh + (rank - room);
     if (slot < a.rec_capacity) a.records[slot] = make_uint4(q, __float_as_uint(meas.x), __float_as_uint(meas.y), __float_as_uint(meas.z));
     atomicOr(a.flags + (q >> 5), 1u << (q & 31u));
+    const uint32_t p = q / a.n_samples;
+    atomicOr(a.touched + (p >> 5), 1u << (p & 31u));
   }
   if (n > room) { rec_next = fresh + (n - room); rec_end = fresh + AMBER_REC_BLOCK; }
   else rec_next += n;
@@ -319,10 +322,13 @@ __device__ __forceinline__ uint32_t PixelBits(const uint32_t* __restrict__ flags
   for (uint32_t wd = w0 + 1u; wd < w1; ++wd) c += static_cast<uint32_t>(__popc(flags[wd]));
   return c;
 }
-__global__ void rec_rank_kernel(const uint32_t* __restrict__ flags, uint32_t n_pixels, uint32_t n_samples, uint32_t* __restrict__ excl, uint32_t* __restrict__ block_sum) {
+__global__ void rec_rank_kernel(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ touched, uint32_t n_pixels, uint32_t n_samples,
+                                uint32_t* __restrict__ excl, uint32_t* __restrict__ block_sum) {
   __shared__ uint32_t part[256];
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-  const uint32_t c = p < n_pixels ? PixelBits(flags, p * n_samples, p * n_samples + n_samples) : 0u;
+  // only a touched pixel's bits are read: on the Cornell box that is 2e-2 of the pixels, and the bitmap is 128 MB per launch
+  const bool any = p < n_pixels && ((touched[p >> 5] >> (p & 31u)) & 1u) != 0u;
+  const uint32_t c = any ? PixelBits(flags, p * n_samples, p * n_samples + n_samples) : 0u;
   part[threadIdx.x] = c;
   __syncthreads();
   for (uint32_t off = 1; off < 256u; off <<= 1) {             // Hillis-Steele inclusive scan
@@ -379,21 +385,14 @@ __global__ void rec_place_kernel(const uint4* __restrict__ records, const unsign
 // added to the framebuffer value in chunk order.  Only paths whose bit is set contribute a term; every other term is +0,
 // and both the chunk sum (starts at +0) and the framebuffer value (cleared to +0) can never be -0, so leaving the +0
 // terms out changes no bit.  One thread per band pixel; its measurements are sorted[base ..] in sample order.
-__global__ void reduce_flagged_kernel(float* __restrict__ fb, const uint32_t* __restrict__ flags, const float* __restrict__ sorted, const uint32_t* __restrict__ excl,
-                                      const uint32_t* __restrict__ block_sum, const unsigned int* __restrict__ rec_count, uint32_t rec_capacity,
-                                      uint32_t n_pixels, uint32_t n_samples) {
+__global__ void reduce_flagged_kernel(float* __restrict__ fb, uint32_t* __restrict__ flags, const uint32_t* __restrict__ touched, const float* __restrict__ sorted,
+                                      const uint32_t* __restrict__ excl, const uint32_t* __restrict__ block_sum, const unsigned int* __restrict__ rec_count,
+                                      uint32_t rec_capacity, uint32_t n_pixels, uint32_t n_samples) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pixels) return;
   if (*rec_count > rec_capacity) return;                       // out of slots: the launch is repeated
-  const uint32_t q0 = p * n_samples, q1 = q0 + n_samples;      // n_pixels * n_samples < 2^32 (RenderPassPaths splits launches)
-  bool any = false;
-  if ((n_samples & 127u) == 0u) {                              // the pixel's bits are whole 16-byte groups: wide loads
-    const uint4* f4 = reinterpret_cast<const uint4*>(flags + (q0 >> 5));
-    for (uint32_t k = 0; k < n_samples / 128u; ++k) { const uint4 f = f4[k]; any |= (f.x | f.y | f.z | f.w) != 0u; }
-  } else {
-    for (uint32_t wd = q0 >> 5; wd <= (q1 - 1u) >> 5; ++wd) any |= flags[wd] != 0u;   // neighbours' bits may share the edge words: harmless
-  }
-  if (!any) return;
+  if (((touched[p >> 5] >> (p & 31u)) & 1u) == 0u) return;     // no path of this pixel carried a measurement
+  const uint32_t q0 = p * n_samples;                           // n_pixels * n_samples < 2^32 (RenderPassPaths splits launches)
   const float* m = sorted + static_cast<size_t>(block_sum[p >> 8] + excl[p]) * 3u;
   float v0 = fb[3u * p], v1 = fb[3u * p + 1u], v2 = fb[3u * p + 2u];
   for (uint32_t c0 = 0; c0 < n_samples; c0 += AMBER_ACCUM_CHUNK) {
@@ -411,6 +410,9 @@ __global__ void reduce_flagged_kernel(float* __restrict__ fb, const uint32_t* __
     if (hit) { v0 = v0 + s0; v1 = v1 + s1; v2 = v2 + s2; }
   }
   fb[3u * p] = v0; fb[3u * p + 1u] = v1; fb[3u * p + 2u] = v2;
+  // The pixel's bits have been consumed: when it owns whole words (n_samples a multiple of 32) it clears them, so that the
+  // bitmap is all zero again for the next launch and the host does not have to clear 128 MB per launch (LaunchPaths).
+  if ((n_samples & 31u) == 0u) for (uint32_t wd = q0 >> 5; wd < (q0 + n_samples) >> 5; ++wd) flags[wd] = 0u;
 }
 
 // Engine BVH worker.  Same work queue, item walk and accumulation order as pt_megakernel, but the closest-hit query
@@ -750,7 +752,8 @@ struct amber_hip_pt {
   size_t partial_floats = 0;
   bool bvh_pool = false;                    // engine BVH renders with pt_bvh_pool_kernel (AMBER_PT_FLAG_BVH_POOL / AMBER_BVH_POOL=1) instead of pt_bvh_megakernel
   // path-granular accumulation (RenderPassPaths): bitmap, records in arrival order, measurements in path order, ranks
-  uint32_t* d_flags = nullptr;  size_t flag_words = 0;
+  uint32_t* d_flags = nullptr;  size_t flag_words = 0;   bool flags_dirty = true;   // dirty: must be cleared before the next launch
+  uint32_t* d_touched = nullptr; size_t touched_words = 0;
   uint4* d_records = nullptr;   float* d_sorted = nullptr;   uint32_t rec_capacity = 0;
   unsigned int* d_rec_count = nullptr;
   unsigned long long* d_rays_launch = nullptr;
@@ -1235,6 +1238,15 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
     hipError_t e = hipMalloc(&h->d_flags, need_words * sizeof(uint32_t));
     if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(path bitmap): ") + hipGetErrorString(e));
     h->flag_words = need_words;
+    h->flags_dirty = true;
+  }
+  const size_t touched_words = static_cast<size_t>(n_pixels) / 32u + 2u;
+  if (touched_words > h->touched_words) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_touched) { HIP_TRY(hipFree(h->d_touched)); h->d_touched = nullptr; h->touched_words = 0; }
+    hipError_t e = hipMalloc(&h->d_touched, touched_words * sizeof(uint32_t));
+    if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(touched pixels): ") + hipGetErrorString(e));
+    h->touched_words = touched_words;
   }
   if (n_pixels > h->rank_pixels) {
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1273,7 +1285,7 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
     }
   }
   RenderArgs a{};
-  a.scene = h->scene; a.flags = h->d_flags; a.records = h->d_records; a.rec_count = h->d_rec_count; a.rec_capacity = h->rec_capacity;
+  a.scene = h->scene; a.flags = h->d_flags; a.touched = h->d_touched; a.records = h->d_records; a.rec_count = h->d_rec_count; a.rec_capacity = h->rec_capacity;
   a.ray_count = h->d_rays_launch; a.next_item = h->d_next; a.stamps = h->d_stamps; a.hashed_seed = h->hashed_seed;
   a.bvh_stack = h->d_bvh_stack; a.carried = h->d_carried; a.sig = sig;
   a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first; a.n_samples = n;
@@ -1281,7 +1293,11 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
   HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
   HIP_TRY(hipMemsetAsync(h->d_rec_count, 0, sizeof(unsigned int), h->stream));
   HIP_TRY(hipMemsetAsync(h->d_rays_launch, 0, sizeof(unsigned long long), h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_flags, 0, need_words * sizeof(uint32_t), h->stream));
+  // The bitmap is cleared by the reduction itself where it can be (whole words per pixel); the host clears all of it only when a
+  // launch left it dirty: the first use, sample counts that are not multiples of 32, signature launches, a launch that ran out of slots.
+  if (h->flags_dirty) HIP_TRY(hipMemsetAsync(h->d_flags, 0, h->flag_words * sizeof(uint32_t), h->stream));
+  h->flags_dirty = sig != nullptr || (n & 31u) != 0u;
+  HIP_TRY(hipMemsetAsync(h->d_touched, 0, touched_words * sizeof(uint32_t), h->stream));
   std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
   { const int rc = AcquireEventPair(h, &evp); if (rc != AMBER_OK) return rc; }
   auto& ev = *evp;
@@ -1299,11 +1315,11 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
   HIP_TRY(hipEventRecord(ev.second, h->stream));
   if (sig) return AMBER_OK;
   const uint32_t n_rank_blocks = (n_pixels + 255u) / 256u;
-  hipLaunchKernelGGL(rec_rank_kernel, dim3(n_rank_blocks), dim3(256), 0, h->stream, h->d_flags, n_pixels, n, h->d_excl, h->d_block_sum);
+  hipLaunchKernelGGL(rec_rank_kernel, dim3(n_rank_blocks), dim3(256), 0, h->stream, h->d_flags, h->d_touched, n_pixels, n, h->d_excl, h->d_block_sum);
   hipLaunchKernelGGL(rec_scan_blocks_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_block_sum, n_rank_blocks, h->d_rec_count, h->rec_capacity, h->d_rays, h->d_rays_launch);
   hipLaunchKernelGGL(rec_place_kernel, dim3(static_cast<uint32_t>(h->n_cus) * 8u), dim3(256), 0, h->stream, h->d_records, h->d_rec_count, h->rec_capacity, h->d_flags,
                      h->d_excl, h->d_block_sum, n, h->d_sorted);
-  hipLaunchKernelGGL(reduce_flagged_kernel, dim3(n_rank_blocks), dim3(256), 0, h->stream, h->d_fb, h->d_flags, h->d_sorted, h->d_excl, h->d_block_sum,
+  hipLaunchKernelGGL(reduce_flagged_kernel, dim3(n_rank_blocks), dim3(256), 0, h->stream, h->d_fb, h->d_flags, h->d_touched, h->d_sorted, h->d_excl, h->d_block_sum,
                      h->d_rec_count, h->rec_capacity, n_pixels, n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(h->h_rec_count, h->d_rec_count, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
@@ -1324,7 +1340,8 @@ int ResolvePending(amber_hip_pt* h) {
     h->rec_density = n_paths ? static_cast<double>(used) / static_cast<double>(n_paths) : 0.0;
     h->density_known = true;
     if (used <= h->rec_capacity) break;
-    // out of slots: nothing of that launch reached the framebuffer or the ray total
+    // out of slots: nothing of that launch reached the framebuffer or the ray total (and its bits are still set)
+    h->flags_dirty = true;
     const int rc = EnsureRecordCapacity(h, used + used / 4u + RecordSlack(h));
     if (rc != AMBER_OK) return rc;
     const int rl = LaunchPaths(h, h->pending_first, h->pending_n, h->local_rows * h->scene.sensor.w, nullptr);
@@ -1624,6 +1641,7 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_splat_count) (void)hipFree(h->d_splat_count);
   if (h->d_partial) (void)hipFree(h->d_partial);
   if (h->d_flags) (void)hipFree(h->d_flags);
+  if (h->d_touched) (void)hipFree(h->d_touched);
   if (h->d_records) (void)hipFree(h->d_records);
   if (h->d_sorted) (void)hipFree(h->d_sorted);
   if (h->d_rec_count) (void)hipFree(h->d_rec_count);
