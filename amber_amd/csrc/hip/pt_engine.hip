@@ -145,9 +145,9 @@ __device__ __forceinline__ void CloseRecords(const RenderArgs& a, uint32_t rec_n
 // queue head the bottleneck -- 190 ms per launch; 1024 paths (16 generation rounds) is 15 atomics per microsecond, and the
 // tail it can leave on one wave is ~35 iterations (80 us).
 #define AMBER_CLAIM_PATHS 1024u
-// Pool slot: three 16-byte chunks {o.xyz d.x} {d.yz w slot} {rng q -} (stride 48 B: ds_read_b128 / ds_write_b128 without bank
-// conflicts); light tracing carries an RGB weight and uses a fourth chunk.
-template <bool kLight> struct PoolLayout { static constexpr int kChunks = kLight ? 4 : 3; };
+// Pool slot: the whole state of a path between two bounces in four 16-byte chunks {o.xyz d.x} {d.yz w.xy} {w.z rng q}
+// {casts | carried-flag, origin slot, signature hashes}.
+template <bool kLight> struct PoolLayout { static constexpr int kChunks = 4; };
 
 template <int kEngine, bool kLight = false, bool kSig = false>
 __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megakernel(const RenderArgs a) {
@@ -193,79 +193,81 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
     AMBER_STAMP(6);
     const bool need = !alive && !retired;
     const unsigned long long mask = __ballot(need);
+    bool primary = false;                                     // wave-uniform: this iteration's rays are 64 fresh paths (a primary round)
     if (mask) {                                               // wave-uniform
       const uint32_t n_need = static_cast<uint32_t>(__popcll(mask));
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
-      uint32_t served = 0;
-#pragma unroll 1
-      for (int round = 0; round < 2; ++round) {
-        if (round == 1) {                                     // the pool ran dry with lanes still waiting: generate 64 paths
-          if (exhausted) break;
-          AMBER_STAMP(0);
-          if (claim_next == claim_end) {                      // claim the next block of paths from the global queue
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(a.next_item, AMBER_CLAIM_PATHS);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= a.n_items) { exhausted = true; break; }
-            claim_next = base;
-            claim_end = a.n_items - base < AMBER_CLAIM_PATHS ? a.n_items : base + AMBER_CLAIM_PATHS;
-          }
+      // (1) the parked rays first
+      const uint32_t take = pool_count < n_need ? pool_count : n_need;
+      if (need && rank < take) {                              // pop
+        const uint32_t sl = pool_count - 1u - rank;
+        const uint4 c0 = pool[sl * kChunks + 0], c1 = pool[sl * kChunks + 1], c2 = pool[sl * kChunks + 2], c3 = pool[sl * kChunks + 3];
+        o = v3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z));
+        d = v3(__uint_as_float(c0.w), __uint_as_float(c1.x), __uint_as_float(c1.y));
+        w = v3(__uint_as_float(c1.z), __uint_as_float(c1.w), __uint_as_float(c2.x));
+        rng = static_cast<uint64_t>(c2.y) | (static_cast<uint64_t>(c2.z) << 32);
+        q = c2.w;
+        casts = c3.x & 0x7fffffffu; carries = (c3.x >> 31) != 0u;
+        origin_slot = static_cast<int>(c3.y);
+        if (kSig) { sig_obj = c3.z; sig_t = c3.w; }
+        alive = true;
+      }
+      __builtin_amdgcn_wave_barrier();                        // (compiler fence: the park below overwrites the slots just read)
+      pool_count -= take;
+      if (take < n_need && !exhausted) {
+        // (2) the pool is empty and lanes still wait: a PRIMARY ROUND.  Every lane that holds a ray parks it in the pool;
+        // all 64 lanes then start the next 64 paths of the queue TOGETHER -- 64 samples of one pixel: one coherent iteration
+        // (first hits, materials) at full width; the parked rays go to whichever lanes lose their path afterwards.
+        AMBER_STAMP(0);
+        if (claim_next == claim_end) {                        // claim the next block of paths from the global queue
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(a.next_item, AMBER_CLAIM_PATHS);
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (base >= a.n_items) exhausted = true;
+          else { claim_next = base; claim_end = a.n_items - base < AMBER_CLAIM_PATHS ? a.n_items : base + AMBER_CLAIM_PATHS; }
+        }
+        if (!exhausted) {
           const uint32_t n_new = claim_end - claim_next < 64u ? claim_end - claim_next : 64u;
           const uint32_t gbase = claim_next;
           claim_next += n_new;
-          if (lane < n_new) {
-            const uint32_t gq = gbase + lane;
-            const uint32_t plocal = gq / a.n_samples, k = gq - plocal * a.n_samples;
-            uint64_t grng; V3 go, gd, gw; int gslot;
+          const unsigned long long m_alive = __ballot(alive);
+          if (alive) {                                        // park (pool_count is 0 here)
+            const uint32_t sl = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_alive >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_alive), 0u));
+            pool[sl * kChunks + 0] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(d.x));
+            pool[sl * kChunks + 1] = make_uint4(__float_as_uint(d.y), __float_as_uint(d.z), __float_as_uint(w.x), __float_as_uint(w.y));
+            pool[sl * kChunks + 2] = make_uint4(__float_as_uint(w.z), static_cast<uint32_t>(rng), static_cast<uint32_t>(rng >> 32), q);
+            pool[sl * kChunks + 3] = make_uint4(casts | (carries ? 0x80000000u : 0u), static_cast<uint32_t>(origin_slot), sig_obj, sig_t);
+          }
+          pool_count = static_cast<uint32_t>(__popcll(m_alive));
+          __builtin_amdgcn_wave_barrier();
+          alive = lane < n_new;
+          if (alive) {
+            q = gbase + lane;
+            const uint32_t plocal = q / a.n_samples, k = q - plocal * a.n_samples;
             if (kLight) {
-              grng = XorShiftSeed(a.hashed_seed, a.path_offset + plocal, a.first_sample + k);
-              GenerateLightRay(sc, grng, go, gd, gw, gslot);
+              rng = XorShiftSeed(a.hashed_seed, a.path_offset + plocal, a.first_sample + k);
+              GenerateLightRay(sc, rng, o, d, w, origin_slot);
             } else {
               const uint32_t lrow = plocal / sc.sensor.w;
               const uint32_t px = plocal - lrow * sc.sensor.w;
               const uint32_t py = a.row_begin + (a.stripe_rows ? (lrow / a.stripe_rows) * a.stripe_period + lrow % a.stripe_rows : lrow);
-              grng = XorShiftSeed(a.hashed_seed, px + py * sc.sensor.w, a.first_sample + k);   // Image index x + y*W (image.h:116-124)
+              rng = XorShiftSeed(a.hashed_seed, px + py * sc.sensor.w, a.first_sample + k);   // Image index x + y*W (image.h:116-124)
               float ew;
-              GenerateEyeRay(sc, px, py, grng, go, gd, ew, gslot);
-              gw = v3(ew, ew, ew);                            // Leading<RGB>(.., Radiant(weight)) lens_basic.h:139-144
+              GenerateEyeRay(sc, px, py, rng, o, d, ew, origin_slot);
+              w = v3(ew, ew, ew);                             // Leading<RGB>(.., Radiant(weight)) lens_basic.h:139-144
             }
-            pool[lane * kChunks + 0] = make_uint4(__float_as_uint(go.x), __float_as_uint(go.y), __float_as_uint(go.z), __float_as_uint(gd.x));
-            pool[lane * kChunks + 1] = make_uint4(__float_as_uint(gd.y), __float_as_uint(gd.z), __float_as_uint(gw.x), static_cast<uint32_t>(gslot));
-            pool[lane * kChunks + 2] = make_uint4(static_cast<uint32_t>(grng), static_cast<uint32_t>(grng >> 32), gq, 0u);
-            if (kLight) pool[lane * kChunks + (kChunks - 1)] = make_uint4(__float_as_uint(gw.y), __float_as_uint(gw.z), 0u, 0u);
+            carries = false;
+            casts = 0;
+            if (kSig) { sig_obj = 2166136261u; sig_t = 2166136261u; }
           }
-          pool_count = n_new;
-          // The pops below read slots that OTHER lanes of this wave have just written.  One wave's LDS instructions execute
-          // in order, so the hardware needs nothing here; the barrier (no instruction: a scheduling fence for the compiler)
-          // pins the order of the stores above and the loads below in the instruction stream.
-          __builtin_amdgcn_wave_barrier();
+          primary = true;
           AMBER_STAMP(1);
         }
-        const uint32_t left = n_need - served;
-        const uint32_t take = pool_count < left ? pool_count : left;
-        if (need && !alive && rank >= served && rank < served + take) {      // pop
-          const uint32_t sl = pool_count - 1u - (rank - served);
-          const uint4 c0 = pool[sl * kChunks + 0], c1 = pool[sl * kChunks + 1], c2 = pool[sl * kChunks + 2];
-          o = v3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z));
-          d = v3(__uint_as_float(c0.w), __uint_as_float(c1.x), __uint_as_float(c1.y));
-          origin_slot = static_cast<int>(c1.w);
-          rng = static_cast<uint64_t>(c2.x) | (static_cast<uint64_t>(c2.y) << 32);
-          q = c2.z;
-          const float wx = __uint_as_float(c1.z);
-          if (kLight) { const uint4 c3 = pool[sl * kChunks + (kChunks - 1)]; w = v3(wx, __uint_as_float(c3.x), __uint_as_float(c3.y)); }
-          else w = v3(wx, wx, wx);
-          carries = false;
-          casts = 0;
-          if (kSig) { sig_obj = 2166136261u; sig_t = 2166136261u; }
-          alive = true;
-        }
-        __builtin_amdgcn_wave_barrier();                     // the next generation round overwrites the slots just read
-        pool_count -= take; served += take;
-        if (served == n_need) break;
       }
-      if (!alive && !retired) retired = true;                 // queue and pool empty: this lane retires
+      if (!alive && !retired && pool_count == 0u && exhausted) retired = true;   // queue and pool empty: this lane retires
       if (__ballot(!retired) == 0ull) break;
     }
+    (void)primary;
 
     rays_wave += static_cast<uint32_t>(__popcll(__ballot(alive)));
     bool emit = false;
