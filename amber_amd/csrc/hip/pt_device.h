@@ -161,6 +161,8 @@ struct DevLens {
   float n_blades_f;
   uint32_t kind;              // 0 thin lens, 1 pinhole
   float inv_scene_area;       // 1 / sensor.SceneArea() (lens_pinhole.cc:101)
+  float edge_tol;             // barycentric distance from a blade's boundary below which an aperture sample may also lie in ANOTHER blade for the exact
+                              // test: 1e-3, or more when the blades are small against the binary32 grid of their world coordinates (>= 0.34: always)
 };
 struct DevSensor {
   uint32_t w, h;
@@ -177,6 +179,7 @@ struct DevScene {
   uint32_t n_planes, n_sphere_filters;
   uint32_t n_simple_planes;    // the first planes of the program, an even number: slabs of two parallel planes with one pair record each
   uint32_t always_mask;        // program slots that are always candidates (disks, cylinders, degenerate triangles)
+  uint32_t blade_mask;         // program slots of the aperture blades (primary rays: decided per ray, not per pixel)
   uint32_t n_prog_tris;        // program slots [0, n_prog_tris) are filtered triangles, then spheres, then the rest
   const DevObject* __restrict__ prog_objects;   // objects in program order, kind |= scene index << 8 (staged to LDS)
   const DevBvhNodeQ* __restrict__ bvh_nodes;    // engine BVH: quantised 2-wide nodes
@@ -615,10 +618,15 @@ __device__ __forceinline__ void ClosestHitList(const DevScene& sc, V3 o, V3 d, H
 //  only, object records gathered from the LDS copy; the (t, index) tie rule makes the visiting order irrelevant.
 //  The result is identical to ClosestHitList (tests: full-image and per-ray equality of both engines).
 #define AMBER_GRAZING 1e-3f
-__device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const DevObject* lds_objects, V3 o_world, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM) {
+__device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const DevObject* lds_objects, V3 o_world, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM,
+                                                   const bool use_premask = false, const uint32_t premask = 0u) {
   best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;
   uint32_t cand = sc.always_mask;
-  {
+  // use_premask (WAVE-UNIFORM): the candidates are already known -- a primary round of pt_megakernel, whose 64 eye rays take them
+  // from their pixel's mask (pixel_mask_kernel: every object some ray of the pixel's beam can hit, computed once per handle) --
+  // so Phase A, a third of the kernel, is skipped for the ray that every path starts with.
+  if (use_premask) cand |= premask;
+  else {
     const V3 o = v3(o_world.x - sc.fp_center[0], o_world.y - sc.fp_center[1], o_world.z - sc.fp_center[2]);   // Phase A runs in centred coordinates (filter_build.h)
     // Pruning by distance.  A triangle that the filter finds hit with a MARGIN -- inside by the same tolerance that
     // otherwise widens it, beyond kEPS by the distance tolerance, not grazing -- is certain to pass the reference's exact
@@ -719,7 +727,7 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
   // The filter's tolerances are derived for rays of the scene: origin within the model box, |d| <= 2 (DESIGN.md section
   // 5).  Anything else -- possible only when a scene hands the reference non-unit normals, whose sphere test then
   // reports "hits" far outside the scene -- skips the filter: every object becomes a candidate for the exact tests.
-  {
+  if (!use_premask) {
     const float ex = Abs(o_world.x - sc.fp_center[0]), ey = Abs(o_world.y - sc.fp_center[1]), ez = Abs(o_world.z - sc.fp_center[2]);
     const bool in_model = __builtin_fmaxf(__builtin_fmaxf(ex, ey), ez) <= sc.fp_reach && (d.x * d.x + d.y * d.y + d.z * d.z) <= 4.0f;   // NaN -> false
     if (!in_model) cand = sc.n_objects >= 32u ? 0xffffffffu : ((1u << sc.n_objects) - 1u);
@@ -1122,8 +1130,9 @@ __device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_s
 enum { ENGINE_LIST = 1, ENGINE_TWO_PHASE = 2, ENGINE_BVH = 3 };
 
 template <int kEngine>
-__device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3 o, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM) {
-  if (kEngine == ENGINE_TWO_PHASE) ClosestHitTwoPhase(sc, lds_objects, o, d, origin_slot, best AMBER_STAMP_ARG);
+__device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3 o, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM,
+                                           const bool use_premask = false, const uint32_t premask = 0u) {
+  if (kEngine == ENGINE_TWO_PHASE) ClosestHitTwoPhase(sc, lds_objects, o, d, origin_slot, best AMBER_STAMP_ARG, use_premask, premask);
   else if (kEngine == ENGINE_BVH) ClosestHitBvh(sc, lds_stack, o, d, best);
   else ClosestHitList(sc, o, d, best);
   AMBER_STAMP(3);
@@ -1382,8 +1391,10 @@ __device__ __forceinline__ bool LensResponse(const DevScene& sc, V3 position, V3
 // eye ray: BasicThin::GenerateRay (lens_thin.cc:70-107) + Sensor::PixelBound::Uniform
 // (sensor.cc:111-120, jitter draw order Y then X -- the g++ order the reference outputs were made with)
 // ---------------------------------------------------------------------------------------------
+// near_edge (optional): the aperture sample lies within DevLens.edge_tol (barycentric) of its blade's boundary -- only then can the exact
+// test of ANOTHER blade accept the ray's own origin (pt_megakernel's primary rounds: which blades are candidates).
 __device__ __forceinline__ void GenerateEyeRay(const DevScene& sc, uint32_t px, uint32_t py, uint64_t& rng,
-                                               V3& origin, V3& dir, float& weight, int& origin_slot) {
+                                               V3& origin, V3& dir, float& weight, int& origin_slot, bool* near_edge = nullptr) {
   const DevLens L = LoadLens(sc);
   if (L.kind == 1u) {                                      // BasicPinhole::GenerateRay lens_pinhole.cc:48-68
     const float jy = Uniform(rng);
@@ -1400,6 +1411,7 @@ __device__ __forceinline__ void GenerateEyeRay(const DevScene& sc, uint32_t px, 
     origin = ld3(L.origin); dir = ray_dir;
     weight = 1.0f / 1.0f / pdf_dir;                        // 1 / PDFArea (= kDiracDelta) / PDFDirection
     origin_slot = -1;
+    if (near_edge) *near_edge = true;                      // (the pinhole's degenerate blade: keep every blade bit)
     return;
   }
   const float fpos = __builtin_floorf(Uniform(rng) * L.n_blades_f);
@@ -1409,6 +1421,7 @@ __device__ __forceinline__ void GenerateEyeRay(const DevScene& sc, uint32_t px, 
   float u = Uniform(rng);
   float v = Uniform(rng);
   if (u + v >= 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+  if (near_edge) *near_edge = !(u >= L.edge_tol && v >= L.edge_tol && u + v <= 1.0f - L.edge_tol);
   const V3 ap_origin = (1.0f - u - v) * ld3(bl->v0) + u * ld3(bl->v1) + v * ld3(bl->v2);   // primitive_triangle.cc:136-150
   const V3 aperture_point = MatMul(L.local_, ap_origin - ld3(L.origin));
   const float jy = Uniform(rng);
@@ -1443,9 +1456,10 @@ __device__ __forceinline__ bool PathShade(const DevScene& sc, const DevObject* l
 
 template <bool kTrace, int kEngine, bool kLight = false>
 __device__ __forceinline__ bool PathStep(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3& o, V3& d, V3& weight, V3& measurement,
-                                         uint64_t& rng, uint32_t& casts, int& origin_slot, Bounce* trace AMBER_STAMP_PARAM, const SplatSink* sink = nullptr) {
+                                         uint64_t& rng, uint32_t& casts, int& origin_slot, Bounce* trace AMBER_STAMP_PARAM, const SplatSink* sink = nullptr,
+                                         const bool use_premask = false, const uint32_t premask = 0u) {
   HitRec h;
-  ClosestHit<kEngine>(sc, lds_objects, lds_stack, o, d, origin_slot, h AMBER_STAMP_ARG);
+  ClosestHit<kEngine>(sc, lds_objects, lds_stack, o, d, origin_slot, h AMBER_STAMP_ARG, use_premask, premask);
   return PathShade<kTrace, kEngine, kLight>(sc, lds_objects, h, o, d, weight, measurement, rng, casts, origin_slot, trace AMBER_STAMP_ARG, sink);
 }
 

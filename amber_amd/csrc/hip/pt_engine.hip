@@ -65,6 +65,7 @@ struct RenderArgs {
   uint32_t splat_capacity;
   int32_t* bvh_stack;        // pt_bvh_pool_kernel: traversal-stack levels beyond the LDS part, [level][thread of the grid]
   float* carried;            // pt_bvh_pool_kernel: measurements of the (degenerate) paths that carry a non-zero one across bounces, [thread of the grid * kRays/64 ...]
+  const uint32_t* pixel_mask; // pt_megakernel, two-phase engine: candidate mask of every band pixel's primary rays (pixel_mask_kernel); null = off
   unsigned long long* sig;   // signature variants: sig[q] = the path's hit-object / hit-distance hashes (amber_hip_pt_signatures)
   uint64_t hashed_seed;      // SplitMix64(global_seed)
   uint32_t row_begin;
@@ -193,7 +194,8 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
     AMBER_STAMP(6);
     const bool need = !alive && !retired;
     const unsigned long long mask = __ballot(need);
-    bool primary = false;                                     // wave-uniform: this iteration's rays are 64 fresh paths (a primary round)
+    bool primary = false;                                     // wave-uniform: this iteration's rays are 64 fresh paths whose candidates are known (premask)
+    uint32_t premask = 0u;
     if (mask) {                                               // wave-uniform
       const uint32_t n_need = static_cast<uint32_t>(__popcll(mask));
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
@@ -253,21 +255,26 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
               const uint32_t py = a.row_begin + (a.stripe_rows ? (lrow / a.stripe_rows) * a.stripe_period + lrow % a.stripe_rows : lrow);
               rng = XorShiftSeed(a.hashed_seed, px + py * sc.sensor.w, a.first_sample + k);   // Image index x + y*W (image.h:116-124)
               float ew;
-              GenerateEyeRay(sc, px, py, rng, o, d, ew, origin_slot);
+              bool near_edge = false;
+              GenerateEyeRay(sc, px, py, rng, o, d, ew, origin_slot, &near_edge);
               w = v3(ew, ew, ew);                             // Leading<RGB>(.., Radiant(weight)) lens_basic.h:139-144
+              if (kTwoPhase && a.pixel_mask) {
+                // the candidates of this pixel's beam, plus the ray's own aperture blade (the self trip decides it exactly), plus
+                // every blade when the aperture sample lies on a blade's boundary (only then can a neighbour's exact test see it)
+                premask = a.pixel_mask[plocal] | (origin_slot >= 0 ? 1u << origin_slot : 0u) | (near_edge ? sc.blade_mask : 0u);
+              }
             }
             carries = false;
             casts = 0;
             if (kSig) { sig_obj = 2166136261u; sig_t = 2166136261u; }
           }
-          primary = true;
+          primary = !kLight && kTwoPhase && a.pixel_mask != nullptr;
           AMBER_STAMP(1);
         }
       }
       if (!alive && !retired && pool_count == 0u && exhausted) retired = true;   // queue and pool empty: this lane retires
       if (__ballot(!retired) == 0ull) break;
     }
-    (void)primary;
 
     rays_wave += static_cast<uint32_t>(__popcll(__ballot(alive)));
     bool emit = false;
@@ -280,12 +287,12 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
         alive = PathStep<false, kEngine, true>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, &sink);
       } else if (kSig) {
         Bounce b;
-        alive = PathStep<true, kEngine>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, &b AMBER_STAMP_ARG);
+        alive = PathStep<true, kEngine>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, &b AMBER_STAMP_ARG, nullptr, primary, premask);
         sig_obj = Fnv32(sig_obj, static_cast<uint32_t>(b.object));
         if (b.object >= 0) sig_t = Fnv32(sig_t, __float_as_uint(b.t));
         if (!alive) a.sig[q] = static_cast<unsigned long long>(sig_obj) | (static_cast<unsigned long long>(sig_t) << 32);
       } else {
-        alive = PathStep<false, kEngine>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG);
+        alive = PathStep<false, kEngine>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, nullptr, primary, premask);
       }
       if (!kLight) {
         const bool nz = (__float_as_uint(meas.x) | __float_as_uint(meas.y) | __float_as_uint(meas.z)) != 0u;   // anything but +0 (RGB)
@@ -415,6 +422,156 @@ __global__ void reduce_flagged_kernel(float* __restrict__ fb, uint32_t* __restri
   // The pixel's bits have been consumed: when it owns whole words (n_samples a multiple of 32) it clears them, so that the
   // bitmap is all zero again for the next launch and the host does not have to clear 128 MB per launch (LaunchPaths).
   if ((n_samples & 31u) == 0u) for (uint32_t wd = q0 >> 5; wd < (q0 + n_samples) >> 5; ++wd) flags[wd] = 0u;
+}
+
+// ---- per-pixel candidate masks of the primary rays (two-phase engine) ---------------------------------------------------------
+// All eye rays of pixel (px, py) lie in one thin BEAM: every ray starts in the aperture (thin lens: lens_thin.cc:70-107; inside the
+// rectangle A that bounds the blades in the lens plane) and passes through the image of its jittered sensor point on the focal plane
+// (inside the rectangle F: the image of the pixel; the direction is Normalize(-fd/sd * sensor_point - aperture_point), which does not
+// depend on where in the aperture the ray starts), or starts at the pinhole (A = one point).  The mask of a pixel has a bit for every
+// object of the filter program that SOME ray of that beam can hit -- the closest hit of every one of the pixel's eye rays, whatever its
+// sample index, is then found among the mask's objects, and a primary round needs no Phase A.  Conservative by construction:
+//  * plane records: the hit points of the beam on a plane form a convex region whenever the plane cuts neither A nor F and no ray is
+//    close to parallel to it (before the focal plane the beam is conv(A u F), behind it F + cone(F - A): both convex, and a plane that
+//    separates or misses A and F meets them only in edges that lie on CORNER rays a_i -> f_j); barycentric coordinates are affine on
+//    the plane, so each one's maximum over the region is attained on one of the 16 corner rays.  A triangle is dropped only if one of
+//    its three coordinates stays below -tolerance on all 16, or if every corner ray meets the plane behind its origin.  Planes that cut
+//    A or F, or that a corner ray grazes, keep all their triangles.
+//  * spheres: kept unless the central ray passes the centre farther away than the radius plus the beam's half width there.
+//  * the same tolerances as Phase A (DevPlane.kt / ktol scaled by the largest 1 / |n.d| of the corner rays) plus a position slack of
+//    1e-5 of the model size for the difference between a binary32 eye ray and the ideal one; A is inflated by 1e-3 of its size, F by
+//    2 % of the pixel.  Aperture blades are NOT part of the mask: a ray's own blade and, on blade boundaries, its neighbours are added
+//    per ray where the path starts.
+// Double precision throughout; one thread per band pixel, once per handle (the mask depends on scene and sensor only).
+struct PixelMaskArgs {
+  float ap[4][3];                 // world corners of the aperture's bounding rectangle in the lens plane (inflated); pinhole: the origin
+  uint32_t row_begin, stripe_rows, stripe_period, n_pixels;
+};
+__global__ void pixel_mask_kernel(const DevScene sc, const PixelMaskArgs pm, uint32_t* __restrict__ out) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= pm.n_pixels) return;
+  const uint32_t lrow = p / sc.sensor.w, px = p - lrow * sc.sensor.w;
+  const uint32_t py = pm.row_begin + (pm.stripe_rows ? (lrow / pm.stripe_rows) * pm.stripe_period + lrow % pm.stripe_rows : lrow);
+  const DevLens& L = *sc.lens;
+  const double cx = sc.fp_center[0], cy = sc.fp_center[1], cz = sc.fp_center[2];
+  const double reach = sc.fp_reach;
+  // Position slack (world units): 1e-5 of the model size, plus the binary32 grid of WORLD coordinates -- an eye ray is defined by the
+  // reference's binary32 arithmetic on world coordinates (blade point, aperture_point = local (point - lens origin), ...), so in a scene
+  // that lies 1e4 of its size from the world origin (the fuzzer's --scaled scenes) the actual ray is a few 1e-4 of the scene away from
+  // the ideal one.  The same amount widens A (host) and F (below).
+  const double world_mag = fmax(fmax(fabs(cx), fmax(fabs(cy), fabs(cz))) + reach, fmax(fabs(double(L.origin[0])), fmax(fabs(double(L.origin[1])), fabs(double(L.origin[2])))));
+  const double slack = 1e-5 * reach + 32.0 * 5.9604644775390625e-08 * world_mag;
+  double A[4][3], F[4][3];
+  for (int i = 0; i < 4; i++) { A[i][0] = pm.ap[i][0] - cx; A[i][1] = pm.ap[i][1] - cy; A[i][2] = pm.ap[i][2] - cz; }
+  for (int j = 0; j < 4; j++) {
+    const double ux = (static_cast<double>(px) + ((j & 1) ? 1.02 : -0.02)) / static_cast<double>(sc.sensor.wf);
+    const double uy = (static_cast<double>(py) + ((j & 2) ? 1.02 : -0.02)) / static_cast<double>(sc.sensor.hf);
+    const double sx = (ux - 0.5) * sc.sensor.sw, sy = (uy - 0.5) * sc.sensor.sh, sz = L.sensor_distance;
+    // thin lens: the point of the focal plane all rays of this sensor point pass through; pinhole: a point far along the ray
+    const double k = L.kind == 1u ? -(8.0 * reach + 1.0) / sz : static_cast<double>(L.focus_distance) / -static_cast<double>(L.sensor_distance);
+    const double fl[3] = {k * sx + ((k * ((j & 1) ? 1.0 : -1.0) >= 0) ? slack : -slack), k * sy + ((k * ((j & 2) ? 1.0 : -1.0) >= 0) ? slack : -slack), k * sz};   // outwards by the slack
+    for (int c = 0; c < 3; c++) F[j][c] = L.origin[c] + L.global_[3 * c] * fl[0] + L.global_[3 * c + 1] * fl[1] + L.global_[3 * c + 2] * fl[2];
+    F[j][0] -= cx; F[j][1] -= cy; F[j][2] -= cz;
+  }
+  double D[16][3];                                                      // corner-ray directions (unit)
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      const double v[3] = {F[j][0] - A[i][0], F[j][1] - A[i][1], F[j][2] - A[i][2]};
+      const double l = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      for (int c = 0; c < 3; c++) D[4 * i + j][c] = v[c] / l;
+    }
+  uint32_t mask = 0u, bit = 1u;
+  const DevPlane* pl = sc.planes;
+  const DevTriFilter* tr = sc.tri_filters;
+  for (uint32_t pi = 0; pi < sc.n_planes; ++pi, ++pl) {
+    const double n[3] = {pl->n[0], pl->n[1], pl->n[2]}, d0 = pl->d0;
+    const uint32_t nt = pl->n_tris & 0x7fffffffu, np = pl->n_pairs;
+    // does the plane cut A or F?  (all corners strictly on one side, with the slack)
+    bool all = false;
+    {
+      double lo = 1e300, hi = -1e300;
+      for (int j = 0; j < 4; j++) { const double sgn = n[0] * F[j][0] + n[1] * F[j][1] + n[2] * F[j][2] - d0; lo = fmin(lo, sgn); hi = fmax(hi, sgn); }
+      if (!(lo > 10.0 * slack || hi < -10.0 * slack)) all = true;
+      lo = 1e300; hi = -1e300;
+      for (int i = 0; i < 4; i++) { const double sgn = n[0] * A[i][0] + n[1] * A[i][1] + n[2] * A[i][2] - d0; lo = fmin(lo, sgn); hi = fmax(hi, sgn); }
+      if (!(lo > 10.0 * slack || hi < -10.0 * slack)) all = true;
+    }
+    double P[16][3], rho_max = 0, t_max = -1e300;
+    int n_pos = 0, n_neg = 0;
+    for (int k = 0; k < 16 && !all; k++) {
+      const double* a_ = A[k >> 2];
+      const double nd = n[0] * D[k][0] + n[1] * D[k][1] + n[2] * D[k][2];
+      if (!(fabs(nd) >= 4.0 * AMBER_GRAZING)) { all = true; break; }    // grazing (or NaN): no convexity argument
+      if (nd > 0) n_pos++; else n_neg++;
+      const double t = (d0 - (n[0] * a_[0] + n[1] * a_[1] + n[2] * a_[2])) / nd;
+      for (int c = 0; c < 3; c++) P[k][c] = a_[c] + t * D[k][c];
+      rho_max = fmax(rho_max, 1.0 / fabs(nd));
+      t_max = fmax(t_max, t);
+    }
+    if (!all && n_pos != 0 && n_neg != 0) all = true;
+    if (all) {
+      for (uint32_t k = 0; k < 2u * np + nt; k++, bit <<= 1) mask |= bit;
+      tr += np + nt;
+      continue;
+    }
+    if (t_max < static_cast<double>(AMBER_KEPS) - static_cast<double>(pl->kt) * rho_max - slack) {   // every ray meets the plane behind its origin
+      bit <<= (2u * np + nt); tr += np + nt;
+      continue;
+    }
+    const double ptol = static_cast<double>(pl->ktol) * rho_max;
+    for (uint32_t r = 0; r < np + nt; ++r, ++tr) {
+      const double g0 = sqrt(double(tr->c[0][0]) * tr->c[0][0] + double(tr->c[1][0]) * tr->c[1][0] + double(tr->c[2][0]) * tr->c[2][0]);
+      const double g1 = sqrt(double(tr->c[0][1]) * tr->c[0][1] + double(tr->c[1][1]) * tr->c[1][1] + double(tr->c[2][1]) * tr->c[2][1]);
+      const double tol = ptol + (g0 + g1) * slack + 1e-6;               // barycentric units
+      double mx[6] = {-1e300, -1e300, -1e300, -1e300, -1e300, -1e300};
+      for (int k = 0; k < 16; k++) {
+        const double u = tr->c[0][0] * P[k][0] + tr->c[1][0] * P[k][1] + tr->c[2][0] * P[k][2] + tr->c[3][0];
+        const double v = tr->c[0][1] * P[k][0] + tr->c[1][1] * P[k][1] + tr->c[2][1] * P[k][2] + tr->c[3][1];
+        // pair record: (u, v) = (beta, alpha) of the first triangle; the second one's coordinates are (-beta, 1 - alpha, beta + alpha)
+        mx[0] = fmax(mx[0], u); mx[1] = fmax(mx[1], v); mx[2] = fmax(mx[2], 1.0 - u - v);
+        mx[3] = fmax(mx[3], -u); mx[4] = fmax(mx[4], 1.0 - v); mx[5] = fmax(mx[5], u + v);
+      }
+      const bool keep1 = !(mx[0] < -tol || mx[1] < -tol || mx[2] < -tol);                  // NaN -> keep
+      mask |= keep1 ? bit : 0u; bit <<= 1;
+      if (r < np) {
+        const bool keep2 = !(mx[3] < -tol || mx[4] < -tol || mx[5] < -tol);
+        mask |= keep2 ? bit : 0u; bit <<= 1;
+      }
+    }
+  }
+  // spheres: the central ray against the sphere inflated by the beam's half width at the sphere's depth
+  {
+    double ac[3] = {0, 0, 0}, fc[3] = {0, 0, 0};
+    for (int i = 0; i < 4; i++) for (int c = 0; c < 3; c++) { ac[c] += 0.25 * A[i][c]; fc[c] += 0.25 * F[i][c]; }
+    double dc[3] = {fc[0] - ac[0], fc[1] - ac[1], fc[2] - ac[2]};
+    const double lc = sqrt(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]);
+    for (int c = 0; c < 3; c++) dc[c] /= lc;
+    auto half_width = [&](double tau) {                                // largest distance of a corner ray from the central one in the plane at depth tau
+      double w2 = 0;
+      for (int k = 0; k < 16; k++) {
+        const double* a_ = A[k >> 2];
+        const double dd = D[k][0] * dc[0] + D[k][1] * dc[1] + D[k][2] * dc[2];
+        const double off = (a_[0] - ac[0]) * dc[0] + (a_[1] - ac[1]) * dc[1] + (a_[2] - ac[2]) * dc[2];
+        const double s_ = (tau - off) / dd;
+        double e2 = 0;
+        for (int c = 0; c < 3; c++) { const double e = a_[c] + s_ * D[k][c] - (ac[c] + tau * dc[c]); e2 += e * e; }
+        w2 = fmax(w2, e2);
+      }
+      return sqrt(w2);
+    };
+    const DevSphereFilter* sp = sc.sphere_filters;
+    for (uint32_t k = 0; k < sc.n_sphere_filters; ++k, ++sp, bit <<= 1) {
+      const double co[3] = {sp->c[0] - ac[0], sp->c[1] - ac[1], sp->c[2] - ac[2]};
+      const double r = sqrt(static_cast<double>(sp->r2)) * 1.001 + slack;
+      const double tau = co[0] * dc[0] + co[1] * dc[1] + co[2] * dc[2];
+      const double d2 = co[0] * co[0] + co[1] * co[1] + co[2] * co[2] - tau * tau;
+      const double hw = fmax(half_width(tau - r), half_width(tau + r));
+      const double lim = (r + hw) * 1.02 + slack;
+      const bool miss = d2 > lim * lim;                                  // NaN -> keep
+      mask |= miss ? 0u : bit;
+    }
+  }
+  out[p] = mask & ~sc.blade_mask;
 }
 
 // Engine BVH worker.  Same work queue, item walk and accumulation order as pt_megakernel, but the closest-hit query
@@ -769,6 +926,8 @@ struct amber_hip_pt {
   int32_t* d_bvh_stack = nullptr;  size_t bvh_stack_ints = 0;     // pt_bvh_pool_kernel: deep traversal-stack levels
   float* d_carried = nullptr;      size_t carried_floats = 0;     // ... and carried measurements
   unsigned long long* d_sig = nullptr;  uint64_t sig_paths = 0;   // amber_hip_pt_signatures
+  uint32_t* d_pixel_mask = nullptr;  bool pixel_mask_ready = false, pixel_mask_on = true;   // two-phase engine: primary-ray candidates per band pixel
+  float aperture_rect[4][3] = {};           // world corners of the blades' bounding rectangle in the lens plane (pixel_mask_kernel)
   int n_cus = 256;
   uint32_t row_begin = 0, row_end = 0, stripe_rows = 0, stripe_period = 0, local_rows = 0;
   uint64_t seed = 0, hashed_seed = 0;
@@ -1054,6 +1213,28 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.fp_tmax = static_cast<float>(std::min(3.0e38, 1.7320508 * 1.5 * 1.01 * static_cast<double>(fp_reach)));
   sc.lights = h->d_lights; sc.n_lights = s->n_lights; sc.total_power = s->n_lights ? s->lights[s->n_lights - 1].cum_power : 0.0f;
   sc.n_prog_tris = fprog.n_prog_tris; sc.always_mask = fprog.always_mask; sc.prog_objects = h->d_prog_objects;
+  sc.blade_mask = 0u;
+  for (const DevBlade& bl : blades) if (bl.slot >= 0 && bl.slot < 32) sc.blade_mask |= 1u << bl.slot;
+  {
+    // bounding rectangle of the aperture in the lens plane (lens-local x, y; the blades lie in z = 0), inflated, as four world points
+    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+    for (const DevBlade& bl : blades)
+      for (const float* v : {bl.v0, bl.v1, bl.v2}) {
+        const double r[3] = {double(v[0]) - L.origin[0], double(v[1]) - L.origin[1], double(v[2]) - L.origin[2]};
+        for (int c = 0; c < 2; c++) {
+          const double x = L.local_[3 * c] * r[0] + L.local_[3 * c + 1] * r[1] + L.local_[3 * c + 2] * r[2];
+          lo[c] = std::min(lo[c], x); hi[c] = std::max(hi[c], x);
+        }
+      }
+    double world_mag = 0;
+    for (int c = 0; c < 3; c++) world_mag = std::max({world_mag, std::fabs(double(fp_center[c])) + fp_reach, std::fabs(double(L.origin[c]))});
+    for (int c = 0; c < 2; c++) { const double m = 1e-3 * (hi[c] - lo[c]) + 1e-6 + 1e-5 * fp_reach + 32.0 * 5.9604644775390625e-08 * world_mag; lo[c] -= m; hi[c] += m; }
+    for (int i = 0; i < 4; i++) {
+      const double x = (i & 1) ? hi[0] : lo[0], y = (i & 2) ? hi[1] : lo[1];
+      for (int c = 0; c < 3; c++) h->aperture_rect[i][c] = static_cast<float>(L.origin[c] + (L.kind == AMBER_LENS_PINHOLE ? 0.0 : L.global_[3 * c] * x + L.global_[3 * c + 1] * y));
+    }
+  }
+  { const char* ev = std::getenv("AMBER_PIXEL_MASK"); h->pixel_mask_on = !(ev && ev[0] == '0'); }
   sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;
   h->n_materials = s->n_materials;
   DevLens lens{};
@@ -1078,6 +1259,22 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.sensor.sw = sensor->scene_width; sc.sensor.sh = sensor->scene_height;
   sc.sensor.size_f = static_cast<float>(static_cast<uint64_t>(sensor->width) * sensor->height);
   { volatile float q = -L.sensor_distance / L.focus_distance; lens.neg_sd_over_fd = q; }
+  {
+    // a ray that starts on blade b is seen by another blade's exact test only if its origin lies within the rounding of WORLD
+    // coordinates of that blade: a few ulp of the lens position, in units of the blade's size
+    double world_mag = 0, min_edge = 1e300;
+    for (int c = 0; c < 3; c++) world_mag = std::max(world_mag, std::fabs(double(L.origin[c])));
+    for (const DevBlade& bl : blades) {
+      const float* v[3] = {bl.v0, bl.v1, bl.v2};
+      for (int k = 0; k < 3; k++) {
+        double e2 = 0;
+        for (int c = 0; c < 3; c++) { const double e = double(v[k][c]) - v[(k + 1) % 3][c]; e2 += e * e; world_mag = std::max(world_mag, std::fabs(double(v[k][c]))); }
+        min_edge = std::min(min_edge, std::sqrt(e2));
+      }
+    }
+    const double tol = min_edge > 0 ? std::max(1e-3, 64.0 * 5.9604644775390625e-08 * world_mag / min_edge) : 1.0;
+    lens.edge_tol = static_cast<float>(std::min(1.0, tol));
+  }
   HIP_TRY_H(hipMalloc(&h->d_lens, sizeof(DevLens)));
   HIP_TRY_H(hipMemcpy(h->d_lens, &lens, sizeof(DevLens), hipMemcpyHostToDevice));
   sc.lens = h->d_lens;
@@ -1286,7 +1483,17 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
       h->bvh_stack_ints = stack_ints;
     }
   }
+  if (h->two_phase && h->pixel_mask_on && !h->pixel_mask_ready) {         // once per handle: the candidates of every band pixel's eye rays
+    HIP_TRY(hipMalloc(&h->d_pixel_mask, static_cast<size_t>(n_pixels) * sizeof(uint32_t)));
+    PixelMaskArgs pm{};
+    std::memcpy(pm.ap, h->aperture_rect, sizeof pm.ap);
+    pm.row_begin = h->row_begin; pm.stripe_rows = h->stripe_rows; pm.stripe_period = h->stripe_period; pm.n_pixels = n_pixels;
+    hipLaunchKernelGGL(pixel_mask_kernel, dim3((n_pixels + 127u) / 128u), dim3(128), 0, h->stream, h->scene, pm, h->d_pixel_mask);
+    HIP_TRY(hipGetLastError());
+    h->pixel_mask_ready = true;
+  }
   RenderArgs a{};
+  a.pixel_mask = h->pixel_mask_ready ? h->d_pixel_mask : nullptr;
   a.scene = h->scene; a.flags = h->d_flags; a.touched = h->d_touched; a.records = h->d_records; a.rec_count = h->d_rec_count; a.rec_capacity = h->rec_capacity;
   a.ray_count = h->d_rays_launch; a.next_item = h->d_next; a.stamps = h->d_stamps; a.hashed_seed = h->hashed_seed;
   a.bvh_stack = h->d_bvh_stack; a.carried = h->d_carried; a.sig = sig;
@@ -1655,6 +1862,7 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_bvh_stack) (void)hipFree(h->d_bvh_stack);
   if (h->d_carried) (void)hipFree(h->d_carried);
   if (h->d_sig) (void)hipFree(h->d_sig);
+  if (h->d_pixel_mask) (void)hipFree(h->d_pixel_mask);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
