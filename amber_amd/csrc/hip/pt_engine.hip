@@ -179,6 +179,11 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
     return a.carried + (static_cast<size_t>(blockIdx.x) * 256u + t) * 3u;
   };
 #define AMBER_CARRIED() carried_slot()
+  // a carried measurement travels with its ray: parked with it (a second block of slots, one per pool slot of the wave) and handed to
+  // the lane that pops the ray -- rays change lanes since the primary rounds
+  auto carried_parked = [&](uint32_t pool_slot) -> float* {
+    return a.carried + (static_cast<size_t>(gridDim.x) * 256u + (static_cast<size_t>(blockIdx.x) * 4u + wave_in_block) * 64u + pool_slot) * 3u;
+  };
   V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), w = v3(0.f, 0.f, 0.f);
   uint64_t rng = 1;
   uint32_t casts = 0;
@@ -210,6 +215,7 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
         rng = static_cast<uint64_t>(c2.y) | (static_cast<uint64_t>(c2.z) << 32);
         q = c2.w;
         casts = c3.x & 0x7fffffffu; carries = (c3.x >> 31) != 0u;
+        if (!kLight && carries) { const float* from = carried_parked(sl); float* to = AMBER_CARRIED(); to[0] = from[0]; to[1] = from[1]; to[2] = from[2]; }
         origin_slot = static_cast<int>(c3.y);
         if (kSig) { sig_obj = c3.z; sig_t = c3.w; }
         alive = true;
@@ -239,6 +245,7 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
             pool[sl * kChunks + 1] = make_uint4(__float_as_uint(d.y), __float_as_uint(d.z), __float_as_uint(w.x), __float_as_uint(w.y));
             pool[sl * kChunks + 2] = make_uint4(__float_as_uint(w.z), static_cast<uint32_t>(rng), static_cast<uint32_t>(rng >> 32), q);
             pool[sl * kChunks + 3] = make_uint4(casts | (carries ? 0x80000000u : 0u), static_cast<uint32_t>(origin_slot), sig_obj, sig_t);
+            if (!kLight && carries) { const float* from = AMBER_CARRIED(); float* to = carried_parked(sl); to[0] = from[0]; to[1] = from[1]; to[2] = from[2]; }
           }
           pool_count = static_cast<uint32_t>(__popcll(m_alive));
           __builtin_amdgcn_wave_barrier();
@@ -1465,7 +1472,7 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
   {
     // measurements carried across bounces (degenerate paths only): pt_megakernel 3 floats per thread of the grid, pt_bvh_pool_kernel per ray of a wave
     const size_t carried = bvh ? static_cast<size_t>(h->n_cus) * AMBER_BVH_POOL_WGS * 4u * AMBER_BVH_POOL_CARRIED_PER_WAVE
-                               : static_cast<size_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth) * 256u * 3u;
+                               : static_cast<size_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth) * 256u * 3u * 2u;   // own slots + parked slots
     if (carried > h->carried_floats) {
       HIP_TRY(hipStreamSynchronize(h->stream));
       if (h->d_carried) { HIP_TRY(hipFree(h->d_carried)); h->d_carried = nullptr; h->carried_floats = 0; }
