@@ -132,7 +132,7 @@ def load_library() -> C.CDLL:
     lib.amber_hip_kat_math.argtypes = [i32, i32, u32, vp, vp]
     lib.amber_hip_kat_signatures.argtypes = [vp, u32, u32, vp]
     if hasattr(lib, "amber_hip_kat_traversal_rate"):
-        lib.amber_hip_kat_traversal_rate.argtypes = [vp, u32, vp, vp, u32, u32, u32, vp, vp, C.POINTER(C.c_double)]
+        lib.amber_hip_kat_traversal_rate.argtypes = [vp, u32, vp, vp, u32, u32, u32, vp, vp, C.POINTER(C.c_double), vp]
     if hasattr(lib, "amber_hip_pt_signatures"):    # absent only in older builds loaded by tools/ab_lib.py
         lib.amber_hip_pt_signatures.argtypes = [vp, u32, u32, vp]
     lib.amber_host_cornell_box.restype = vp
@@ -372,13 +372,14 @@ class PathTracer:
                                                   casts.ctypes.data))
         return rec, casts
 
-    def kat_traversal_rate(self, origins, dirs, waves: int = 5, refill_min: int = 16, repeats: int = 3):
-        """Engine BVH's traversal alone: returns (object index, t, best kernel ms) for the rays."""
+    def kat_traversal_rate(self, origins, dirs, waves: int = 5, refill_min: int = 16, repeats: int = 3, rounds=None):
+        """Engine BVH's traversal alone: returns (object index, t, best kernel ms) for the rays; `rounds` (uint32 array of len(rays),
+        optional) receives the number of wave rounds each ray was in flight for."""
         o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
         n = len(o)
         obj, t, ms = np.empty(n, np.int32), np.empty(n, np.float32), C.c_double()
         _check(load_library().amber_hip_kat_traversal_rate(self._h, n, o.ctypes.data, d.ctypes.data, waves, refill_min, repeats, t.ctypes.data,
-                                                           obj.ctypes.data, C.byref(ms)))
+                                                           obj.ctypes.data, C.byref(ms), rounds.ctypes.data if rounds is not None else None))
         return obj, t, ms.value
 
     def kat_signatures(self, first_sample: int, n_samples: int) -> np.ndarray:

@@ -814,9 +814,9 @@ __device__ __forceinline__ void ClosestHitLeafList(const DevScene& sc, V3 o, V3 
 // node word (min | max << 16) so that the entry plane sits in the low half.
 struct BvhTrav {
   V3 A;                // step / d
-  V3 b_in, b_out;      // entry planes: (gmin - o -+ E) / d - slack;  exit planes: ... + slack
+  V3 b_in, b_out;      // entry planes: (gmin - o -+ E) / d - slack of the axis;  exit planes: ... + slack of the axis
   uint32_t rot[3];     // 16 where d < 0
-  float neg_slack;     // -slack: lower clamp of the entry parameter
+  float neg_slack;     // -(smallest axis slack): lower clamp of the entry parameter
   int32_t cur;         // >= 0 inner node, < 0 leaf reference, AMBER_BVH_DONE finished
   int32_t pend;        // postponed leaf reference (< 0), 0 = none (BvhRound)
   int sp;              // entries on the lane's stack
@@ -852,28 +852,35 @@ __device__ __forceinline__ void BvhOperands(const DevScene& sc, V3 o, V3 d, BvhT
   V3 bmn = v3((sc.bvh_gmin[0] - (o.x + E)) * inv.x, (sc.bvh_gmin[1] - (o.y + E)) * inv.y, (sc.bvh_gmin[2] - (o.z + E)) * inv.z);
   V3 bmx = v3((sc.bvh_gmin[0] - (o.x - E)) * inv.x, (sc.bvh_gmin[1] - (o.y - E)) * inv.y, (sc.bvh_gmin[2] - (o.z - E)) * inv.z);
   // Rounding of q * A + B: A and B carry three roundings each and the fma one more -- at most 2^-22 of
-  // (|gmin - o| + E + scene extent) / |d| on the axis, which also bounds |t| of every plane of the axis; the slack takes
-  // 2^-20 of that (per ray, max over the axes).  2^-16 costs 13 % on config 3: the term scales with |o / d|.
+  // (|gmin - o| + E + scene extent) / |d| ON THE AXIS (`mg`), which also bounds |t| of every plane of the axis; the axis' slack
+  // takes 2^-20 of that.  2^-16 costs 13 % on config 3: the term scales with |o / d|.  The slack is PER AXIS since round 3:
+  // one value for the ray (the maximum over the axes, rounds 1-2) lets an almost axis-parallel ray -- |d.y| = 4e-7 on the
+  // middle rows of a frame: mg.y = 7.5e6, slack 7 in units of t, more than the whole scene -- switch off the culling of the
+  // OTHER two axes and of the closest hit so far: such a ray walked every node its plane y = o.y touches, 39 000 of them
+  // against 60 for its neighbours (tools/traversal_rounds.py: 0.1 % of the eye rays of those rows took 450 .. 7 800 wave rounds,
+  // the median 10).  The error bound never needed it: it is a bound on the axis' own plane parameters.
   V3 mg = v3((Abs(sc.bvh_gmin[0] - o.x) + E + sc.bvh_reach[0]) * Abs(inv.x), (Abs(sc.bvh_gmin[1] - o.y) + E + sc.bvh_reach[1]) * Abs(inv.y),
              (Abs(sc.bvh_gmin[2] - o.z) + E + sc.bvh_reach[2]) * Abs(inv.z));
   // An axis whose operands are not finite (d component 0 or denormal, huge origin) is taken OUT of the slab test by making
   // them NaN: fma(q, NaN, NaN) = NaN, which min/max skip.  Leaving +-inf in would not be conservative (inf - inf), and an
-  // infinite value must not reach the slack either: an infinite slack makes every box "hit", and an axis-parallel ray
+  // infinite value must not reach a slack either: an infinite slack makes every box "hit", and an axis-parallel ray
   // then walks the whole tree -- 2 M nodes, 0.75 s for one lane, found on config 3.
   const float kNaN = __builtin_nanf("");
   if (!(Abs(A.x) < 3.0e38f) || !(Abs(bmn.x) < 3.0e38f) || !(Abs(bmx.x) < 3.0e38f) || !(mg.x < 3.0e38f)) { A.x = kNaN; bmn.x = kNaN; bmx.x = kNaN; mg.x = kNaN; }
   if (!(Abs(A.y) < 3.0e38f) || !(Abs(bmn.y) < 3.0e38f) || !(Abs(bmx.y) < 3.0e38f) || !(mg.y < 3.0e38f)) { A.y = kNaN; bmn.y = kNaN; bmx.y = kNaN; mg.y = kNaN; }
   if (!(Abs(A.z) < 3.0e38f) || !(Abs(bmn.z) < 3.0e38f) || !(Abs(bmx.z) < 3.0e38f) || !(mg.z < 3.0e38f)) { A.z = kNaN; bmn.z = kNaN; bmx.z = kNaN; mg.z = kNaN; }
-  float mag = __builtin_fmaxf(__builtin_fmaxf(mg.x, mg.y), mg.z);                     // fmax skips the NaN axes
-  if (!(mag == mag)) mag = 0.0f;                                                      // no axis takes part
-  const float slack = AMBER_BVH_REL_SLACK * mag + slack_len;
-  // The subtraction / addition of the slack rounds once more, by at most half an ulp of B +- slack <= 2^-24 * 2 mag: inside
-  // the 2^-20 - 2^-22 of mag the slack has to spare.
+  // The subtraction / addition of a slack rounds once more, by at most 2^-24 of |B| + slack <= 2^-24 * (mg + mg * 2^-20 + slack_len):
+  // inside what the axis' slack has to spare (2^-20 - 2^-22 of mg, and half of slack_len, which is twice the bound it stands for).
+  const V3 slack = v3(AMBER_BVH_REL_SLACK * mg.x + slack_len, AMBER_BVH_REL_SLACK * mg.y + slack_len, AMBER_BVH_REL_SLACK * mg.z + slack_len);   // NaN on a NaN axis
   const bool nx = A.x < 0.0f, ny = A.y < 0.0f, nz = A.z < 0.0f;                       // NaN axes: either order, the planes are NaN
-  tr.b_in = v3((nx ? bmx.x : bmn.x) - slack, (ny ? bmx.y : bmn.y) - slack, (nz ? bmx.z : bmn.z) - slack);
-  tr.b_out = v3((nx ? bmn.x : bmx.x) + slack, (ny ? bmn.y : bmx.y) + slack, (nz ? bmn.z : bmx.z) + slack);
+  tr.b_in = v3((nx ? bmx.x : bmn.x) - slack.x, (ny ? bmx.y : bmn.y) - slack.y, (nz ? bmx.z : bmn.z) - slack.z);
+  tr.b_out = v3((nx ? bmn.x : bmx.x) + slack.x, (ny ? bmn.y : bmx.y) + slack.y, (nz ? bmn.z : bmx.z) + slack.z);
   tr.rot[0] = nx ? 16u : 0u; tr.rot[1] = ny ? 16u : 0u; tr.rot[2] = nz ? 16u : 0u;
-  tr.neg_slack = -slack;
+  // Lower clamp of the entry parameter, the widened form of t >= 0.  Any value <= 0 is conservative (the exit parameters are
+  // raised: a box the ray really enters at t >= 0 has every computed exit >= 0); the smallest of the axes' slacks keeps a margin.
+  float smin = __builtin_fminf(__builtin_fminf(slack.x, slack.y), slack.z);           // fmin skips the NaN axes
+  if (!(smin == smin)) smin = slack_len;                                              // no axis takes part
+  tr.neg_slack = -smin;
   tr.A = A;
 }
 

@@ -1981,7 +1981,7 @@ int amber_hip_kat_signatures(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
 // else, `waves` resident waves per SIMD (4, 5, 6 or 8), idle lanes refilled once `refill_min` of a wave's lanes are idle.
 // Returns t (NaN = miss) and the object index per ray, and the kernel time of `repeats` launches (the best one).
 int amber_hip_kat_traversal_rate(amber_hip_pt* h, uint32_t n, const float* origins, const float* dirs, uint32_t waves, uint32_t refill_min, uint32_t repeats,
-                                 float* out_t, int32_t* out_object, double* best_ms) {
+                                 float* out_t, int32_t* out_object, double* best_ms, uint32_t* out_rounds) {
   // one launch walks the ray array `repeats` times (a launch of n * repeats rays); best_ms is the time of that launch
   if (!h || !origins || !dirs || !out_t || !out_object || n == 0) return Fail(AMBER_EINVAL, "bad argument");
   if (h->hit_engine != AMBER_ENGINE_BVH) return Fail(AMBER_EINVAL, "the handle's engine is not BVH");
@@ -1993,7 +1993,8 @@ int amber_hip_kat_traversal_rate(amber_hip_pt* h, uint32_t n, const float* origi
     packed[2ull * i] = make_float4(origins[3ull * i], origins[3ull * i + 1], origins[3ull * i + 2], 0.f);
     packed[2ull * i + 1] = make_float4(dirs[3ull * i], dirs[3ull * i + 1], dirs[3ull * i + 2], 0.f);
   }
-  DevBuf<float4> d_rays; DevBuf<float2> d_out; DevBuf<unsigned int> d_next; DevBuf<int32_t> d_stack;
+  DevBuf<float4> d_rays; DevBuf<float2> d_out; DevBuf<unsigned int> d_next; DevBuf<int32_t> d_stack; DevBuf<uint32_t> d_rounds;
+  if (out_rounds) HIP_TRY(d_rounds.alloc(n));
   HIP_TRY(d_rays.alloc(2ull * n)); HIP_TRY(d_out.alloc(n)); HIP_TRY(d_next.alloc(1));
   const uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * (waves >= 4 && waves <= 8 ? waves : 5u);
   HIP_TRY(d_stack.alloc(static_cast<size_t>(n_blocks) * 256u * AMBER_BVH_STACK));
@@ -2008,10 +2009,10 @@ int amber_hip_kat_traversal_rate(amber_hip_pt* h, uint32_t n, const float* origi
     HIP_TRY(hipMemsetAsync(d_next.p, 0, sizeof(unsigned int), h->stream));
     HIP_TRY(hipEventRecord(e0, h->stream));
     switch (waves) {
-      case 4: hipLaunchKernelGGL((bvh_trace_rate_kernel<4, 24>), dim3(n_blocks), dim3(256), 0, h->stream, h->scene, nv, d_rays.p, d_out.p, d_next.p, d_stack.p, refill_min, n); break;
-      case 6: hipLaunchKernelGGL((bvh_trace_rate_kernel<6, 24>), dim3(n_blocks), dim3(256), 0, h->stream, h->scene, nv, d_rays.p, d_out.p, d_next.p, d_stack.p, refill_min, n); break;
-      case 8: hipLaunchKernelGGL((bvh_trace_rate_kernel<8, 16>), dim3(n_blocks), dim3(256), 0, h->stream, h->scene, nv, d_rays.p, d_out.p, d_next.p, d_stack.p, refill_min, n); break;
-      default: hipLaunchKernelGGL((bvh_trace_rate_kernel<5, 24>), dim3(n_blocks), dim3(256), 0, h->stream, h->scene, nv, d_rays.p, d_out.p, d_next.p, d_stack.p, refill_min, n); break;
+      case 4: hipLaunchKernelGGL((bvh_trace_rate_kernel<4, 24>), dim3(n_blocks), dim3(256), 0, h->stream, h->scene, nv, d_rays.p, d_out.p, d_next.p, d_stack.p, refill_min, n, d_rounds.p); break;
+      case 6: hipLaunchKernelGGL((bvh_trace_rate_kernel<6, 24>), dim3(n_blocks), dim3(256), 0, h->stream, h->scene, nv, d_rays.p, d_out.p, d_next.p, d_stack.p, refill_min, n, d_rounds.p); break;
+      case 8: hipLaunchKernelGGL((bvh_trace_rate_kernel<8, 16>), dim3(n_blocks), dim3(256), 0, h->stream, h->scene, nv, d_rays.p, d_out.p, d_next.p, d_stack.p, refill_min, n, d_rounds.p); break;
+      default: hipLaunchKernelGGL((bvh_trace_rate_kernel<5, 24>), dim3(n_blocks), dim3(256), 0, h->stream, h->scene, nv, d_rays.p, d_out.p, d_next.p, d_stack.p, refill_min, n, d_rounds.p); break;
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, h->stream));
@@ -2022,6 +2023,7 @@ int amber_hip_kat_traversal_rate(amber_hip_pt* h, uint32_t n, const float* origi
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   std::vector<float2> res(n);
   HIP_TRY(hipMemcpy(res.data(), d_out.p, n * sizeof(float2), hipMemcpyDeviceToHost));
+  if (out_rounds) HIP_TRY(hipMemcpy(out_rounds, d_rounds.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   std::vector<uint32_t> prims(h->scene.n_objects);
   HIP_TRY(hipMemcpy(prims.data(), h->d_bvh_prims, prims.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   for (uint32_t i = 0; i < n; i++) {

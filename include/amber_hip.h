@@ -227,9 +227,10 @@ int amber_hip_kat_signatures(amber_hip_pt*, uint32_t first_sample, uint32_t n_sa
 int amber_hip_pt_signatures(amber_hip_pt*, uint32_t first_sample, uint32_t n_samples, uint64_t* out);
 /* Engine BVH's traversal in a kernel of its own (no shading, no path state): closest hits of n rays, `waves` resident waves per SIMD
  * (4, 5, 6 or 8), idle lanes refilled once `refill_min` of a wave's 64 lanes are idle; out_t = NaN for a miss; best_ms = the fastest of
- * `repeats` launches.  A measurement that doubles as a known-answer test of the traversal. */
+ * `repeats` launches; out_rounds (may be NULL): per ray, the number of wave rounds it was in flight for.  A measurement (DESIGN.md
+ * section 5) that doubles as a known-answer test of the traversal. */
 int amber_hip_kat_traversal_rate(amber_hip_pt*, uint32_t n, const float* origins, const float* dirs, uint32_t waves, uint32_t refill_min,
-                                 uint32_t repeats, float* out_t, int32_t* out_object, double* best_ms);
+                                 uint32_t repeats, float* out_t, int32_t* out_object, double* best_ms, uint32_t* out_rounds);
 /* the engine's sin/cos/pow on device: mode 0 = sincos(x[i]) -> out[2i], out[2i+1] ; mode 1 = pow(x[2i], x[2i+1]) -> out[i] ;
  * mode 2 / 3 = x[i]^4 / x[i]^5 in binary64 -> out[2i], out[2i+1] = low, high word of the double */
 int amber_hip_kat_math(int device, int mode, uint32_t n, const float* x, float* out);

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Per-dispatch PMC counters of one kernel of a python script.  Usage: tools/pmc_generic.sh <tag> <kernel substring> <script> [args]   (env passes through)
+set -u
+TAG=$1; KERNEL=$2; shift 2
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/pmcg_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "TA_TA_BUSY_sum TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TA_TOTAL_WAVEFRONTS_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
+  name=$(echo $pass | tr ' ' '_' | cut -c1-40)
+  timeout -k 10 200 rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$name" -- python3 "$@" > "$OUT/pmc_${name}.log" 2>&1 || echo "pmc $pass failed"
+done
+for f in $OUT/pmc_*.log; do tail -n 1 $f; done | sort | uniq -c
+python3 - "$OUT" "$KERNEL" <<'PY'
+import csv, glob, sys, collections
+out, kern = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob(out + "/pmc_*/*/*_counter_collection.csv"):
+    rows = [r for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+    for r in rows:
+        agg[r["Counter_Name"]][ids.index(int(r["Dispatch_Id"]))] += float(r["Counter_Value"])
+n = max(len(v) for v in agg.values())
+for k in sorted(agg): print("%-40s" % k + " ".join("%14.6g" % agg[k].get(i, float("nan")) for i in range(n)))
+PY
