@@ -848,6 +848,22 @@ __device__ __forceinline__ void BvhOperands(const DevScene& sc, V3 o, V3 d, BvhT
     E = 1.001f * __builtin_fminf(dpos * S * S * sc.bvh_inv_rmin, __builtin_amdgcn_sqrtf(dpos) * S);
     slack_len = 2.0f * Abs(delta) * S * __builtin_amdgcn_rsqf(__builtin_fminf(len2, 1.0f));   // t <= S / |d|
   }
+  // An axis the ray is (almost) parallel to: |1 / d| beyond 1e12, or infinite.  Dropping it from the slab test (rounds 1-2) is
+  // conservative but lets the ray walk every box of the sheet it lies in -- 40 000 nodes, 8 000 wave rounds, on the 1M-sphere
+  // scene (tools/traversal_rounds_secondary.py).  It stays in with 1 / d clamped to +-1e12: the plane parameters keep their signs
+  // and only shrink in magnitude, so an entry parameter that was positive is still a lower bound of itself and a negative one stays
+  // non-positive; an exit parameter may now come out too SMALL, and that is repaired by raising the axis' slack by T, a bound on
+  // the t of any hit (no point of the scene is farther than S from the origin).  In distance that slack is 3e-6 of the scene.
+  const float kInvMax = 1.0e12f;
+  const bool flat_x = !(Abs(inv.x) <= kInvMax), flat_y = !(Abs(inv.y) <= kInvMax), flat_z = !(Abs(inv.z) <= kInvMax);   // NaN d: nan_ray in BvhBegin
+  float t_far = 0.0f;
+  if (flat_x || flat_y || flat_z) {
+    const float cx = o.x - sc.bvh_center[0], cy = o.y - sc.bvh_center[1], cz = o.z - sc.bvh_center[2];
+    t_far = 1.001f * (__builtin_amdgcn_sqrtf(cx * cx + cy * cy + cz * cz) + sc.bvh_half_diag) * __builtin_amdgcn_rsqf(__builtin_fminf(len2, 1.0f)) * 1.001f;
+    if (flat_x) inv.x = __builtin_copysignf(kInvMax, d.x);
+    if (flat_y) inv.y = __builtin_copysignf(kInvMax, d.y);
+    if (flat_z) inv.z = __builtin_copysignf(kInvMax, d.z);
+  }
   V3 A = v3(sc.bvh_step[0] * inv.x, sc.bvh_step[1] * inv.y, sc.bvh_step[2] * inv.z);
   V3 bmn = v3((sc.bvh_gmin[0] - (o.x + E)) * inv.x, (sc.bvh_gmin[1] - (o.y + E)) * inv.y, (sc.bvh_gmin[2] - (o.z + E)) * inv.z);
   V3 bmx = v3((sc.bvh_gmin[0] - (o.x - E)) * inv.x, (sc.bvh_gmin[1] - (o.y - E)) * inv.y, (sc.bvh_gmin[2] - (o.z - E)) * inv.z);
@@ -861,7 +877,7 @@ __device__ __forceinline__ void BvhOperands(const DevScene& sc, V3 o, V3 d, BvhT
   // the median 10).  The error bound never needed it: it is a bound on the axis' own plane parameters.
   V3 mg = v3((Abs(sc.bvh_gmin[0] - o.x) + E + sc.bvh_reach[0]) * Abs(inv.x), (Abs(sc.bvh_gmin[1] - o.y) + E + sc.bvh_reach[1]) * Abs(inv.y),
              (Abs(sc.bvh_gmin[2] - o.z) + E + sc.bvh_reach[2]) * Abs(inv.z));
-  // An axis whose operands are not finite (d component 0 or denormal, huge origin) is taken OUT of the slab test by making
+  // An axis whose operands are still not finite (huge origin or scene) is taken OUT of the slab test by making
   // them NaN: fma(q, NaN, NaN) = NaN, which min/max skip.  Leaving +-inf in would not be conservative (inf - inf), and an
   // infinite value must not reach a slack either: an infinite slack makes every box "hit", and an axis-parallel ray
   // then walks the whole tree -- 2 M nodes, 0.75 s for one lane, found on config 3.
@@ -871,7 +887,8 @@ __device__ __forceinline__ void BvhOperands(const DevScene& sc, V3 o, V3 d, BvhT
   if (!(Abs(A.z) < 3.0e38f) || !(Abs(bmn.z) < 3.0e38f) || !(Abs(bmx.z) < 3.0e38f) || !(mg.z < 3.0e38f)) { A.z = kNaN; bmn.z = kNaN; bmx.z = kNaN; mg.z = kNaN; }
   // The subtraction / addition of a slack rounds once more, by at most 2^-24 of |B| + slack <= 2^-24 * (mg + mg * 2^-20 + slack_len):
   // inside what the axis' slack has to spare (2^-20 - 2^-22 of mg, and half of slack_len, which is twice the bound it stands for).
-  const V3 slack = v3(AMBER_BVH_REL_SLACK * mg.x + slack_len, AMBER_BVH_REL_SLACK * mg.y + slack_len, AMBER_BVH_REL_SLACK * mg.z + slack_len);   // NaN on a NaN axis
+  const V3 slack = v3(AMBER_BVH_REL_SLACK * mg.x + slack_len + (flat_x ? t_far : 0.0f), AMBER_BVH_REL_SLACK * mg.y + slack_len + (flat_y ? t_far : 0.0f),
+                      AMBER_BVH_REL_SLACK * mg.z + slack_len + (flat_z ? t_far : 0.0f));   // NaN on a NaN axis
   const bool nx = A.x < 0.0f, ny = A.y < 0.0f, nz = A.z < 0.0f;                       // NaN axes: either order, the planes are NaN
   tr.b_in = v3((nx ? bmx.x : bmn.x) - slack.x, (ny ? bmx.y : bmn.y) - slack.y, (nz ? bmx.z : bmn.z) - slack.z);
   tr.b_out = v3((nx ? bmn.x : bmx.x) + slack.x, (ny ? bmn.y : bmx.y) + slack.y, (nz ? bmn.z : bmx.z) + slack.z);

@@ -352,3 +352,40 @@ def test_traversal_on_its_own_gives_the_same_closest_hits(amber):
         for refill in (1, 16, 64):
             obj, t, ms = pt.kat_traversal_rate(org, d, waves=waves, refill_min=refill, repeats=2)
             assert np.array_equal(obj, ref_obj) and np.array_equal(bits(t[hit]), bits(ref_t[hit])) and ms > 0, (waves, refill)
+
+
+def test_rays_almost_parallel_to_an_axis_stay_cheap_and_exact(amber):
+    """Round 3 found engine BVH's slab slack shared by the three axes: a ray with |d.y| = 4e-7 (the middle rows of a frame) or a zero
+    component switched off the culling of the other axes and walked every box of the sheet it lies in -- 40 000 nodes, 8 000 wave rounds on
+    the 1M-sphere scene against a median of 10.  The slack is per axis now and a parallel axis stays in the test with a clamped 1/d
+    (pt_device.h BvhOperands).  Closest hits must equal the List scan's bit for bit, and no ray may be in flight for more than 100 rounds."""
+    from amber_amd import scenes
+    kw = scenes.random_spheres(200_000, 7)
+    hs = amber.HostScene.create_arrays(**kw)
+    bvh = amber.PathTracer(hs, amber.Sensor.default(1920, 1080), seed=1, engine=amber.ENGINE_BVH)
+    lst = amber.PathTracer(hs, amber.Sensor.default(1920, 1080), seed=1, engine=amber.ENGINE_LIST)
+    rng = np.random.default_rng(21)
+    n = 6000
+    org = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tiny = np.array([0.0, -0.0, 4e-7, -4e-7, 1e-12, -1e-13, 1e-20, 1e-30, 1e-39, -1e-42], np.float64)      # incl. denormals: 1/d overflows
+    ax = rng.integers(0, 3, n)
+    d[np.arange(n), ax] = tiny[rng.integers(0, len(tiny), n)]
+    two = rng.random(n) < 0.2                                                    # a fifth of them parallel to two axes at once
+    d[two, (ax[two] + 1) % 3] = tiny[rng.integers(0, len(tiny), int(two.sum()))]
+    d = d.astype(np.float32)
+    # plus the eye rays of the frame's middle row and column (|d.y| or |d.x| of a pixel pitch and below)
+    px = np.concatenate([540 * 1920 + np.arange(0, 1920, 2), np.arange(0, 1080, 2) * 1920 + 960]).astype(np.uint32)
+    eye = bvh.kat_eye(np.repeat(px, 4), np.tile(np.arange(4, dtype=np.uint32), len(px)))
+    org = np.ascontiguousarray(np.concatenate([org, eye[:, 0:3]]), np.float32); d = np.ascontiguousarray(np.concatenate([d, eye[:, 3:6]]), np.float32)
+    ref_obj, ref_t, _, _ = lst.kat_cast(org, d)
+    obj, t, _, _ = bvh.kat_cast(org, d)
+    hit = ref_obj >= 0
+    assert 0.3 < hit.mean() < 1.0
+    assert np.array_equal(obj, ref_obj) and np.array_equal(bits(t[hit]), bits(ref_t[hit]))
+    rounds = np.zeros(len(org), np.uint32)
+    obj2, t2, _ = bvh.kat_traversal_rate(org, d, waves=5, refill_min=16, repeats=1, rounds=rounds)
+    assert np.array_equal(obj2, ref_obj) and np.array_equal(bits(t2[hit]), bits(ref_t[hit]))
+    assert rounds.max() <= 100, (int(rounds.max()), org[rounds.argmax()], d[rounds.argmax()])
+    assert np.median(rounds) <= 15
