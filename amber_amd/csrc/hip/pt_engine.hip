@@ -138,14 +138,23 @@ __device__ __forceinline__ void CloseRecords(const RenderArgs& a, uint32_t rec_n
 //    nothing is stored at a path's end, Eye hits append splat records instead.
 //  * kSig (tests only, amber_hip_pt_signatures): the same kernel also hashes every cast's hit object and hit distance and
 //    stores the pair at the path's end -- the PRODUCT kernel's paths, compared with the oracle's one by one.
+#define AMBER_WAVE_TIME_SLOTS 8192u          /* diagnostic build: per-wave timestamps behind the 8 section sums of RenderArgs.stamps */
 #ifndef AMBER_MEGAKERNEL_WAVES_PER_SIMD
 #define AMBER_MEGAKERNEL_WAVES_PER_SIMD 6
 #endif
 // Paths a wave claims from the global queue head with one atomicAdd.  One L2 word retires ~88 returning atomics per
 // microsecond (MI355X_MICROARCH.md, "dequeue"): claiming 64 paths at a time (1.7e7 atomics per config-2 launch) made the
 // queue head the bottleneck -- 190 ms per launch; 1024 paths (16 generation rounds) is 15 atomics per microsecond, and the
-// tail it can leave on one wave is ~35 iterations (80 us).
+// tail it can leave on one wave is ~35 iterations (80 us).  Round 3 measured the queue again (tools/launch_fixed_cost.py, kernel time
+// = fixed + slope * spp on config 2's frame): a claim costs the wave 4.4 us (512 / 1024 / 2048 / 4096 paths per claim: slope 51.67 /
+// 50.97 / 50.60 / 50.21 us per spp, i.e. 0.75 ms of a 52.8-ms launch at 1024), the fixed part of a launch is 0.59 / 0.63 / 0.81 / 1.17 ms
+// -- 0.5 ms of it independent of the claim size (9 % of a rank's step when 8 GPUs share config 2) -- and it is NOT the idle -> busy
+// transition (8 launches back to back cost the same each, tools/launch_back_to_back.py).  Tried and dropped: guided claims
+// ((paths left) / (2 waves), 256 .. 1024, from a fresh load of the queue head): +4 ms per launch -- the extra load of the hot word costs
+// more than a claim -- and a static first claim per wave (no start-up burst of 6144 atomics): -0.05 ms, within noise of its cost.
+#ifndef AMBER_CLAIM_PATHS
 #define AMBER_CLAIM_PATHS 1024u
+#endif
 // Pool slot: the whole state of a path between two bounces in four 16-byte chunks {o.xyz d.x} {d.yz w.xy} {w.z rng q}
 // {casts | carried-flag, origin slot, signature hashes}.
 template <bool kLight> struct PoolLayout { static constexpr int kChunks = 4; };
@@ -193,6 +202,8 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
 #ifdef AMBER_STAMPS
   StampCtx stamp_store{}; StampCtx* stamp_ctx = &stamp_store;
   stamp_ctx->last = __builtin_amdgcn_s_memtime();
+  unsigned long long* wave_times = a.stamps ? a.stamps + 8 + 4ull * ((blockIdx.x * 4u + wave_in_block) % AMBER_WAVE_TIME_SLOTS) : nullptr;
+  if (wave_times && lane == 0) { wave_times[0] = wall_clock64(); wave_times[1] = 0; wave_times[2] = 0; }
 #endif
 
   for (;;) {
@@ -233,6 +244,9 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
           base = __builtin_amdgcn_readfirstlane(base);
           if (base >= a.n_items) exhausted = true;
           else { claim_next = base; claim_end = a.n_items - base < AMBER_CLAIM_PATHS ? a.n_items : base + AMBER_CLAIM_PATHS; }
+#ifdef AMBER_STAMPS
+          if (wave_times && lane == 0) { if (exhausted) wave_times[2] = wall_clock64(); else if (wave_times[1] == 0) wave_times[1] = wall_clock64(); }
+#endif
         }
         if (!exhausted) {
           const uint32_t n_new = claim_end - claim_next < 64u ? claim_end - claim_next : 64u;
@@ -314,6 +328,7 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
   if (!kLight) CloseRecords(a, rec_next, rec_end);
 #ifdef AMBER_STAMPS
   if (lane == 0 && a.stamps) for (int k = 0; k < 8; k++) atomicAdd(a.stamps + k, stamp_ctx->acc[k]);
+  if (wave_times && lane == 0) wave_times[3] = wall_clock64();
 #endif
   // one atomic per wave for the ray counter
   if (lane == 0 && rays_wave) atomicAdd(a.ray_count, static_cast<unsigned long long>(rays_wave));
@@ -411,6 +426,28 @@ __global__ void reduce_flagged_kernel(float* __restrict__ fb, uint32_t* __restri
   const uint32_t q0 = p * n_samples;                           // n_pixels * n_samples < 2^32 (RenderPassPaths splits launches)
   const float* m = sorted + static_cast<size_t>(block_sum[p >> 8] + excl[p]) * 3u;
   float v0 = fb[3u * p], v1 = fb[3u * p + 1u], v2 = fb[3u * p + 2u];
+  if ((n_samples & 31u) == 0u && (32u % AMBER_ACCUM_CHUNK) == 0u) {
+    // The pixel owns whole words: walk the SET bits only (a touched pixel of the Cornell box has one or two among 1024) -- the same
+    // sums in the same order: samples of a chunk in order from +0, chunk sums onto the pixel in chunk order.  The bit-by-bit loop
+    // below took 0.135 ms per launch of a rank's share of config 2 on 8 GPUs, 2 % of its step.  Consumed words are cleared on the
+    // way, so that the bitmap is all zero again for the next launch and the host does not have to clear 128 MB per launch.
+    const uint32_t w0 = q0 >> 5, nw = n_samples >> 5;
+    constexpr uint32_t kChunkMask = AMBER_ACCUM_CHUNK >= 32u ? 0xffffffffu : ((1u << (AMBER_ACCUM_CHUNK & 31u)) - 1u);
+    for (uint32_t wd = 0; wd < nw; ++wd) {
+      uint32_t bits = flags[w0 + wd];
+      if (bits == 0u) continue;
+      flags[w0 + wd] = 0u;
+      for (uint32_t sh = 0; sh < 32u; sh += AMBER_ACCUM_CHUNK) {
+        uint32_t b = (bits >> sh) & kChunkMask;
+        if (b == 0u) continue;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        while (b) { b &= b - 1u; s0 = s0 + m[0]; s1 = s1 + m[1]; s2 = s2 + m[2]; m += 3; }
+        v0 = v0 + s0; v1 = v1 + s1; v2 = v2 + s2;
+      }
+    }
+    fb[3u * p] = v0; fb[3u * p + 1u] = v1; fb[3u * p + 2u] = v2;
+    return;
+  }
   for (uint32_t c0 = 0; c0 < n_samples; c0 += AMBER_ACCUM_CHUNK) {
     const uint32_t c1 = c0 + AMBER_ACCUM_CHUNK < n_samples ? c0 + AMBER_ACCUM_CHUNK : n_samples;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -426,9 +463,7 @@ __global__ void reduce_flagged_kernel(float* __restrict__ fb, uint32_t* __restri
     if (hit) { v0 = v0 + s0; v1 = v1 + s1; v2 = v2 + s2; }
   }
   fb[3u * p] = v0; fb[3u * p + 1u] = v1; fb[3u * p + 2u] = v2;
-  // The pixel's bits have been consumed: when it owns whole words (n_samples a multiple of 32) it clears them, so that the
-  // bitmap is all zero again for the next launch and the host does not have to clear 128 MB per launch (LaunchPaths).
-  if ((n_samples & 31u) == 0u) for (uint32_t wd = q0 >> 5; wd < (q0 + n_samples) >> 5; ++wd) flags[wd] = 0u;
+  // (a pixel that does not own whole words leaves its bits: the host clears the bitmap before the next launch, LaunchPaths)
 }
 
 // ---- per-pixel candidate masks of the primary rays (two-phase engine) ---------------------------------------------------------
@@ -921,6 +956,7 @@ struct amber_hip_pt {
   uint32_t* d_flags = nullptr;  size_t flag_words = 0;   bool flags_dirty = true;   // dirty: must be cleared before the next launch
   uint32_t* d_touched = nullptr; size_t touched_words = 0;
   uint4* d_records = nullptr;   float* d_sorted = nullptr;   uint32_t rec_capacity = 0;
+  unsigned int* d_launch_ctl = nullptr;      // [0] queue head of the path kernels, [1] = *d_rec_count, [2..3] = *d_rays_launch
   unsigned int* d_rec_count = nullptr;
   unsigned long long* d_rays_launch = nullptr;
   uint32_t* d_excl = nullptr;   uint32_t* d_block_sum = nullptr;   uint32_t rank_pixels = 0;
@@ -1190,8 +1226,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMalloc(&h->d_rays, sizeof(unsigned long long)));
   HIP_TRY_H(hipMalloc(&h->d_next, sizeof(unsigned int)));
 #ifdef AMBER_STAMPS
-  HIP_TRY_H(hipMalloc(&h->d_stamps, 8 * sizeof(unsigned long long)));
-  HIP_TRY_H(hipMemset(h->d_stamps, 0, 8 * sizeof(unsigned long long)));
+  HIP_TRY_H(hipMalloc(&h->d_stamps, (8 + 4 * AMBER_WAVE_TIME_SLOTS) * sizeof(unsigned long long)));     // 8 section sums, then per wave: start, first claim done, queue empty, end
+  HIP_TRY_H(hipMemset(h->d_stamps, 0, (8 + 4 * AMBER_WAVE_TIME_SLOTS) * sizeof(unsigned long long)));
 #endif
   { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, params->device) == hipSuccess && v > 0) h->n_cus = v; }
   HIP_TRY_H(hipMemsetAsync(h->d_fb, 0, fb_floats * sizeof(float), h->stream));
@@ -1464,8 +1500,11 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
     if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(pixel ranks): ") + hipGetErrorString(e));
     h->rank_pixels = n_pixels;
   }
-  if (!h->d_rec_count) HIP_TRY(hipMalloc(&h->d_rec_count, sizeof(unsigned int)));
-  if (!h->d_rays_launch) HIP_TRY(hipMalloc(&h->d_rays_launch, sizeof(unsigned long long)));
+  if (!h->d_launch_ctl) {                                                   // queue head | record count | rays of the launch: one block, one memset per launch
+    HIP_TRY(hipMalloc(&h->d_launch_ctl, 4 * sizeof(unsigned int)));
+    h->d_rec_count = h->d_launch_ctl + 1;
+    h->d_rays_launch = reinterpret_cast<unsigned long long*>(h->d_launch_ctl + 2);
+  }
   if (!h->h_rec_count) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_rec_count), sizeof(unsigned int), hipHostMallocDefault));
   if (!h->pending_event) HIP_TRY(hipEventCreateWithFlags(&h->pending_event, hipEventDisableTiming));
   const uint32_t n_blocks = PathBlocks(h, n_paths);
@@ -1502,13 +1541,11 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
   RenderArgs a{};
   a.pixel_mask = h->pixel_mask_ready ? h->d_pixel_mask : nullptr;
   a.scene = h->scene; a.flags = h->d_flags; a.touched = h->d_touched; a.records = h->d_records; a.rec_count = h->d_rec_count; a.rec_capacity = h->rec_capacity;
-  a.ray_count = h->d_rays_launch; a.next_item = h->d_next; a.stamps = h->d_stamps; a.hashed_seed = h->hashed_seed;
+  a.ray_count = h->d_rays_launch; a.next_item = h->d_launch_ctl; a.stamps = h->d_stamps; a.hashed_seed = h->hashed_seed;
   a.bvh_stack = h->d_bvh_stack; a.carried = h->d_carried; a.sig = sig;
   a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first; a.n_samples = n;
   a.n_chunks = (n + AMBER_ACCUM_CHUNK - 1) / AMBER_ACCUM_CHUNK; a.n_items = static_cast<uint32_t>(n_paths);
-  HIP_TRY(hipMemsetAsync(h->d_next, 0, sizeof(unsigned int), h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_rec_count, 0, sizeof(unsigned int), h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_rays_launch, 0, sizeof(unsigned long long), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_launch_ctl, 0, 4 * sizeof(unsigned int), h->stream));
   // The bitmap is cleared by the reduction itself where it can be (whole words per pixel); the host clears all of it only when a
   // launch left it dirty: the first use, sample counts that are not multiples of 32, signature launches, a launch that ran out of slots.
   if (h->flags_dirty) HIP_TRY(hipMemsetAsync(h->d_flags, 0, h->flag_words * sizeof(uint32_t), h->stream));
@@ -1822,6 +1859,13 @@ int amber_hip_pt_kernel_time(amber_hip_pt* h, uint32_t* n_launches, double* tota
 }
 
 #ifdef AMBER_STAMPS
+// diagnostic build only: per wave of the last pt_megakernel launch, wall-clock ticks (100 MHz) at start, after the first claim,
+// when it found the queue empty, at its end (tools/wave_times.py)
+extern "C" int amber_hip_pt_read_wave_times(amber_hip_pt* h, unsigned long long* out, unsigned int n_waves) {
+  if (!h || !h->d_stamps || n_waves > AMBER_WAVE_TIME_SLOTS) return AMBER_EINVAL;
+  (void)hipStreamSynchronize(h->stream);
+  return hipMemcpy(out, h->d_stamps + 8, 4ull * n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? AMBER_OK : AMBER_EHIP;
+}
 extern "C" int amber_hip_pt_read_stamps(amber_hip_pt* h, unsigned long long out[8]) {
   if (!h || !h->d_stamps) return AMBER_EINVAL;
   (void)hipStreamSynchronize(h->stream);
@@ -1860,8 +1904,7 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_touched) (void)hipFree(h->d_touched);
   if (h->d_records) (void)hipFree(h->d_records);
   if (h->d_sorted) (void)hipFree(h->d_sorted);
-  if (h->d_rec_count) (void)hipFree(h->d_rec_count);
-  if (h->d_rays_launch) (void)hipFree(h->d_rays_launch);
+  if (h->d_launch_ctl) (void)hipFree(h->d_launch_ctl);                     // d_rec_count and d_rays_launch point into it
   if (h->d_excl) (void)hipFree(h->d_excl);
   if (h->d_block_sum) (void)hipFree(h->d_block_sum);
   if (h->h_rec_count) (void)hipHostFree(h->h_rec_count);

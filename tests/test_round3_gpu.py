@@ -374,7 +374,8 @@ def test_rays_almost_parallel_to_an_axis_stay_cheap_and_exact(amber):
     d[np.arange(n), ax] = tiny[rng.integers(0, len(tiny), n)]
     two = rng.random(n) < 0.2                                                    # a fifth of them parallel to two axes at once
     d[two, (ax[two] + 1) % 3] = tiny[rng.integers(0, len(tiny), int(two.sum()))]
-    d = d.astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)                               # unit length again (a direction far from unit length widens
+    d = d.astype(np.float32)                                                    #  every box on purpose: BvhOperands' slack_len)
     # plus the eye rays of the frame's middle row and column (|d.y| or |d.x| of a pixel pitch and below)
     px = np.concatenate([540 * 1920 + np.arange(0, 1920, 2), np.arange(0, 1080, 2) * 1920 + 960]).astype(np.uint32)
     eye = bvh.kat_eye(np.repeat(px, 4), np.tile(np.arange(4, dtype=np.uint32), len(px)))
