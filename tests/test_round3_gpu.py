@@ -390,3 +390,40 @@ def test_rays_almost_parallel_to_an_axis_stay_cheap_and_exact(amber):
     assert np.array_equal(obj2, ref_obj) and np.array_equal(bits(t2[hit]), bits(ref_t[hit]))
     assert rounds.max() <= 100, (int(rounds.max()), org[rounds.argmax()], d[rounds.argmax()])
     assert np.median(rounds) <= 15
+
+
+def test_candidate_masks_of_the_primary_rays_change_nothing(amber, cornell):
+    """pt_megakernel's per-pixel candidate masks (round 3: a primary round skips the candidate filter and tests the pixel's own
+    candidates) against the same kernel without them (AMBER_PIXEL_MASK=0 at create): images, ray counts and the product kernel's
+    path signatures, on the Cornell box (thin lens; striped rows; sample counts that make generation rounds straddle pixels; a
+    second launch at an offset), on a pinhole camera and on the all-primitive test scene."""
+    import os
+    from test_host_model import SCENE
+
+    def pair(make):
+        os.environ["AMBER_PIXEL_MASK"] = "0"
+        try:
+            off = make()
+        finally:
+            os.environ["AMBER_PIXEL_MASK"] = "1"
+        try:
+            return off, make()
+        finally:
+            del os.environ["AMBER_PIXEL_MASK"]
+
+    hs, _ = cornell
+    cases = [
+        ("cornell 96x80, 24 + 40 spp", lambda: amber.PathTracer(hs, amber.Sensor.default(96, 80), seed=3, engine=amber.ENGINE_TWO_PHASE), ((0, 24), (24, 40))),
+        ("cornell 256x256 stripes 1 of 3, 64 spp", lambda: amber.PathTracer(hs, amber.Sensor.default(256, 256), seed=5, rows=(8, 256), stripe=(8, 24), engine=amber.ENGINE_TWO_PHASE), ((7, 64),)),
+        ("pinhole 56x40, 48 spp", lambda: amber.PathTracer(amber.HostScene.create(**dict(SCENE, n_blades=0, focal_length=0.045)), amber.Sensor.default(56, 40), seed=6, engine=amber.ENGINE_TWO_PHASE), ((0, 48),)),
+        ("all primitive kinds 64x48, 33 spp", lambda: amber.PathTracer(amber.HostScene.create(**SCENE), amber.Sensor.default(64, 48), seed=9, engine=amber.ENGINE_TWO_PHASE), ((2, 33),)),
+    ]
+    for name, make, launches in cases:
+        off, on = pair(make)
+        for first, n in launches:
+            off.render_pass(first, n); on.render_pass(first, n)
+        a, ra = off.download(); b, rb = on.download()
+        assert ra == rb and np.array_equal(bits(a), bits(b)) and (a > 0).any(), name
+        first, n = launches[0]
+        assert np.array_equal(off.render_signatures(first, n), on.render_signatures(first, n)), name
+        off.close(); on.close()
