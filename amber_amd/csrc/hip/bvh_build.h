@@ -226,9 +226,69 @@ struct FlatBvh {
 // in binary64), leaf references re-encoded as first*8 + all_spheres*4 + count.
 struct QuantizedBvh {
   std::vector<DevBvhNodeQ> nodes;
-  float gmin[3] = {0, 0, 0}, step[3] = {1, 1, 1}, reach[3] = {0, 0, 0};
+  float gmin[3] = {0, 0, 0}, step[3] = {1, 1, 1}, reach[3] = {0, 0, 0};   // plane = gmin + value * step ; reach >= |value * step| for every stored value
   int32_t root_ref = -1;
 };
+// AMBER_BVH_F16 (default): the 16 bits of a plane are a binary16 NUMBER u in [-1, 1], plane = centre + u * half extent -- so that the
+// device's slab parameter u * A + B is ONE v_fma_mix_f32 (it converts a binary16 operand on the way in) instead of a
+// v_cvt_f32_u32 and an fma: 12 of a node visit's 46 vector instructions less.  The price is resolution: 11 significant bits
+// (2^-11 of the coordinate, i.e. 5e-4 of the half extent in the outer half of the scene, finer towards the centre) against the
+// uniform 1.5e-5 of the integer grid -- leaf boxes of the 1M-sphere scene grow by about 1 % per axis.  Denormal binary16 values are
+// never stored (what a v_fma_mix does with them depends on the wave's denormal mode): a plane inside +-2^-14 goes to 0 or +-2^-14.
+#ifndef AMBER_BVH_F16
+#define AMBER_BVH_F16 1
+#endif
+inline double F16Value(uint16_t h) {                          // exact
+  const int e = (h >> 10) & 31, m = h & 1023;
+  const double v = e == 0 ? std::ldexp(double(m), -24) : std::ldexp(double(1024 + m), e - 25);
+  return (h & 0x8000u) ? -v : v;
+}
+inline uint16_t F16Step(uint16_t h, bool up) {                // the next NORMAL (or zero) binary16 value above / below h; h is normal or zero, finite
+  const bool neg = (h & 0x8000u) != 0;
+  const uint16_t mag = h & 0x7fffu;
+  if (mag == 0) return up ? 0x0400u : 0x8400u;               // 0 -> +-2^-14
+  if (neg == up) return mag == 0x0400u ? 0u : static_cast<uint16_t>((neg ? 0x8000u : 0u) | (mag - 1u));   // towards zero
+  return mag >= 0x7bffu ? h : static_cast<uint16_t>((neg ? 0x8000u : 0u) | (mag + 1u));                    // away from zero (stops at 65504)
+}
+inline uint16_t F16Nearest(double u) {                        // some normal-or-zero binary16 value near u (the caller walks to the side it needs)
+  if (!(u == u)) return 0u;
+  const bool neg = u < 0; double a = std::fabs(u);
+  if (a < std::ldexp(1.0, -14)) return 0u;
+  if (a >= 65504.0) return static_cast<uint16_t>((neg ? 0x8000u : 0u) | 0x7bffu);
+  int e; const double f = std::frexp(a, &e);                  // a = f * 2^e, f in [0.5, 1)
+  int m = static_cast<int>(std::floor(f * 2048.0)) - 1024;    // 11 significant bits, truncated
+  if (m < 0) m = 0; if (m > 1023) m = 1023;
+  return static_cast<uint16_t>((neg ? 0x8000u : 0u) | (uint32_t(e + 14) << 10) | uint32_t(m));
+}
+// The word of one axis of a box: value(min) | value(max) << 16 with  gmin + value(min) * step <= mn  and  gmin + value(max) * step >= mx,
+// checked in extended precision with a guard of 2^-50 of the operands' magnitude (one representable value further out when in doubt).
+inline uint32_t PlaneWord(float mn, float mx, float gmin, float step) {
+#if AMBER_BVH_F16
+  const long double g = gmin, st = step;
+  const long double guard = (std::fabs((long double)gmin) + std::fabs((long double)step) * 2.0L) * 0x1p-50L;
+  auto plane = [&](uint16_t h) { return g + (long double)F16Value(h) * st; };
+  uint16_t a = F16Nearest((double(mn) - double(gmin)) / double(step)), b = F16Nearest((double(mx) - double(gmin)) / double(step));
+  while (plane(a) > (long double)mn - guard) { const uint16_t n = F16Step(a, false); if (n == a) break; a = n; }
+  for (;;) { const uint16_t n = F16Step(a, true); if (n == a || plane(n) > (long double)mn - guard) break; a = n; }        // the tightest such value
+  while (plane(b) < (long double)mx + guard) { const uint16_t n = F16Step(b, true); if (n == b) break; b = n; }
+  for (;;) { const uint16_t n = F16Step(b, false); if (n == b || plane(n) < (long double)mx + guard) break; b = n; }
+  return uint32_t(a) | (uint32_t(b) << 16);
+#else
+  const double g = gmin, st = step;
+  double a = std::floor((double(mn) - g) / st), b = std::ceil((double(mx) - g) / st);
+  a = std::min(65535.0, std::max(0.0, a)); b = std::min(65535.0, std::max(0.0, b));
+  while (a > 0 && g + a * st > mn) a -= 1;                                                   // exact: conservative in every case
+  while (b < 65535 && g + b * st < mx) b += 1;
+  return uint32_t(a) | (uint32_t(b) << 16);
+#endif
+}
+inline uint32_t EmptyPlaneWord() {                            // min above max: no ray enters
+#if AMBER_BVH_F16
+  return 0x3c00u | (0xbc00u << 16);                           // min +1, max -1
+#else
+  return 0x0000ffffu;                                         // min 65535, max 0
+#endif
+}
 template <typename IsSphere>
 inline int32_t QuantizedLeafRef(int32_t ref, IsSphere is_sphere_slot) {
   if (ref >= 0) return ref;
@@ -255,6 +315,14 @@ inline QuantizedBvh QuantizeBvh(const std::vector<DevBvhNode>& bin, int32_t root
       for (int c = 0; c < 3; c++) { lo[c] = std::min<double>(lo[c], mn[c]); hi[c] = std::max<double>(hi[c], mx[c]); }
     }
   for (int c = 0; c < 3; c++) {
+#if AMBER_BVH_F16
+    const float mid = static_cast<float>(0.5 * (lo[c] + hi[c]));
+    float half = static_cast<float>(std::max(hi[c] - double(mid), double(mid) - lo[c]) * 1.000001);
+    while (!(double(mid) + double(half) >= hi[c] && double(mid) - double(half) <= lo[c])) half = std::nextafter(half, 3.0e38f);
+    if (!(half > 0.0f)) half = 1e-30f;
+    out.gmin[c] = mid; out.step[c] = half;
+    out.reach[c] = static_cast<float>(double(half) * 1.002);                                // |value| <= 1 + one binary16 step
+#else
     out.gmin[c] = std::nextafter(static_cast<float>(lo[c]), -3.0e38f);                    // <= lo
     double st = (hi[c] - double(out.gmin[c])) / 65535.0;
     float stf = static_cast<float>(st);
@@ -262,25 +330,16 @@ inline QuantizedBvh QuantizeBvh(const std::vector<DevBvhNode>& bin, int32_t root
     if (!(stf > 0.0f)) stf = 1e-30f;
     out.step[c] = stf;
     out.reach[c] = static_cast<float>(65535.0 * double(stf) * 1.0001);
+#endif
   }
   out.nodes.resize(bin.size());
   for (size_t i = 0; i < bin.size(); i++) {
     const DevBvhNode& nd = bin[i];
-    uint16_t ql[2][3], qh[2][3];
+    DevBvhNodeQ& q = out.nodes[i];
     for (int side = 0; side < 2; side++) {
       float mn[3], mx[3]; child_box(nd, side, mn, mx);
-      for (int c = 0; c < 3; c++) {
-        const double g = out.gmin[c], st = out.step[c];
-        double a = std::floor((double(mn[c]) - g) / st), b = std::ceil((double(mx[c]) - g) / st);
-        a = std::min(65535.0, std::max(0.0, a)); b = std::min(65535.0, std::max(0.0, b));
-        while (a > 0 && g + a * st > mn[c]) a -= 1;                                        // exact: conservative in every case
-        while (b < 65535 && g + b * st < mx[c]) b += 1;
-        ql[side][c] = static_cast<uint16_t>(a); qh[side][c] = static_cast<uint16_t>(b);
-      }
+      for (int c = 0; c < 3; c++) q.w[3 * side + c] = PlaneWord(mn[c], mx[c], out.gmin[c], out.step[c]);   // one word per axis: min | max << 16
     }
-    DevBvhNodeQ& q = out.nodes[i];
-    for (int side = 0; side < 2; side++)
-      for (int c = 0; c < 3; c++) q.w[3 * side + c] = uint32_t(ql[side][c]) | (uint32_t(qh[side][c]) << 16);   // one word per axis: min | max << 16
     q.left = QuantizedLeafRef(nd.left, is_sphere_slot);
     q.right = QuantizedLeafRef(nd.right, is_sphere_slot);
   }
@@ -330,15 +389,8 @@ inline QuantizedBvh4 CollapseBvh4(const std::vector<DevBvhNode>& bin, int32_t ro
     }
     amber_dev::DevBvhNodeQ4 q;
     for (int i = 0; i < 4; i++) {
-      if (i >= n) { for (int c = 0; c < 3; c++) q.w[3 * i + c] = 0x0000ffffu; q.child[i] = -1; continue; }    // min 65535, max 0
-      for (int c = 0; c < 3; c++) {
-        const double g = grid.gmin[c], st = grid.step[c];
-        double a = std::floor((double(kid[i].mn[c]) - g) / st), b = std::ceil((double(kid[i].mx[c]) - g) / st);
-        a = std::min(65535.0, std::max(0.0, a)); b = std::min(65535.0, std::max(0.0, b));
-        while (a > 0 && g + a * st > kid[i].mn[c]) a -= 1;
-        while (b < 65535 && g + b * st < kid[i].mx[c]) b += 1;
-        q.w[3 * i + c] = uint32_t(a) | (uint32_t(b) << 16);
-      }
+      if (i >= n) { for (int c = 0; c < 3; c++) q.w[3 * i + c] = EmptyPlaneWord(); q.child[i] = -1; continue; }
+      for (int c = 0; c < 3; c++) q.w[3 * i + c] = PlaneWord(kid[i].mn[c], kid[i].mx[c], grid.gmin[c], grid.step[c]);
       if (kid[i].ref >= 0) {
         const uint32_t idx = static_cast<uint32_t>(out.nodes.size());
         out.nodes.emplace_back();

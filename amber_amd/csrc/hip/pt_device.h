@@ -118,12 +118,13 @@ struct alignas(16) DevBvhNode {   // 64 B
   float z[4];                     // left min.z, left max.z, right min.z, right max.z
   int32_t left, right, pad0, pad1;
 };
-// The node the DEVICE traverses: the same 2-wide tree with both children's boxes quantised to 16 bits per plane on one
-// grid over the scene bounds (plane = bvh_gmin + q * bvh_step, min planes rounded down, max planes up), 32 bytes = two
+// The node the DEVICE traverses: the same 2-wide tree with both children's boxes quantised to 16 bits per plane
+// (plane = bvh_gmin + value * bvh_step, min planes rounded down, max planes up; since round 3 `value` is a binary16 number in
+// [-1, 1] around the scene centre -- bvh_build.h, AMBER_BVH_F16 -- before that an integer of a uniform grid), 32 bytes = two
 // 16-byte loads per visit instead of four.  The traversal of the 1M-sphere scene is bound by the per-CU rate at which the
 // vector L1 looks up the distinct lines a wave's lanes ask for (rocprofv3: TCP busy 92 %, TA busy 70 %, VALU issue 41 %:
 // profiles/r02_config3_memory_counters.txt), so bytes -- i.e. load instructions -- per visit are what counts.
-// The grid step is 1 / 65535 of the scene extent: 3e-5 of it, 0.3 % of the smallest sphere of config 3.
+// (Uniform grid: step 1 / 65535 of the scene extent, 0.3 % of the smallest sphere of config 3; binary16: 2^-11 of the coordinate.)
 struct alignas(16) DevBvhNodeQ {  // 32 B
   uint32_t w[6];                  // 16-bit planes, one word per axis: L.min.x|L.max.x<<16, L.y, L.z, R.x, R.y, R.z (a rotation by 16 swaps entry and exit)
   int32_t left, right;            // >= 0 inner node index; < 0 leaf: -(ref+1) = first*8 + all_spheres*4 + count (count <= 3)
@@ -184,7 +185,7 @@ struct DevScene {
   const DevObject* __restrict__ prog_objects;   // objects in program order, kind |= scene index << 8 (staged to LDS)
   const DevBvhNodeQ* __restrict__ bvh_nodes;    // engine BVH: quantised 2-wide nodes
   const DevBvhNodeQ4* __restrict__ bvh_nodes4;  // AMBER_BVH_WIDE builds: the collapsed 4-wide nodes (else null)
-  float bvh_gmin[3], bvh_step[3];               // quantisation grid: plane = bvh_gmin + q * bvh_step
+  float bvh_gmin[3], bvh_step[3];               // plane = bvh_gmin + value * bvh_step (binary16 planes: scene centre, half extent)
   float bvh_reach[3];                           // max(|bounds_min - x|, |bounds_max - x|) over x in the bounds, per axis = extent (slab rounding slack)
   const float4* __restrict__ bvh_spheres;       // (centre, radius) of every object in leaf order (zeros for non-spheres): leaves of spheres only test from here
   const uint32_t* __restrict__ bvh_prims;       // leaf order -> object index
@@ -1013,6 +1014,16 @@ struct BvhStackHybrid {
     return glob[static_cast<uint32_t>(sp - lds_levels) * glob_stride + LaneId()];
   }
 };
+// The value of a plane's 16 bits (bvh_build.h): a binary16 number in [-1, 1] -- the conversion folds into the fma that consumes it
+// (v_fma_mix_f32 with op_sel on the half of the word) -- or, in -DAMBER_BVH_F16=0 builds, an integer of the 16-bit grid.
+#ifndef AMBER_BVH_F16
+#define AMBER_BVH_F16 1
+#endif
+#if AMBER_BVH_F16
+#define AMBER_PLANE_VALUE(bits16) static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(bits16)))
+#else
+#define AMBER_PLANE_VALUE(bits16) static_cast<float>(bits16)
+#endif
 template <class Stack>
 __device__ __forceinline__ void BvhDescend(const DevScene& sc, const Stack& stack, BvhTrav& tr, const float t_best AMBER_STAMP_PARAM_OPT) {
   int32_t cur = tr.cur, pend = tr.pend;
@@ -1028,8 +1039,8 @@ __device__ __forceinline__ void BvhDescend(const DevScene& sc, const Stack& stac
     const uint4* nd = reinterpret_cast<const uint4*>(sc.bvh_nodes4 + cur);
     const uint4 p0 = nd[0], p1 = nd[1], p2 = nd[2], cr = nd[3];
 #define AMBER_ROT(wd, c) __builtin_amdgcn_alignbit((wd), (wd), tr.rot[c])
-#define AMBER_QLO(wd) static_cast<float>((wd) & 0xffffu)
-#define AMBER_QHI(wd) static_cast<float>((wd) >> 16)
+#define AMBER_QLO(wd) AMBER_PLANE_VALUE((wd) & 0xffffu)
+#define AMBER_QHI(wd) AMBER_PLANE_VALUE((wd) >> 16)
 #define AMBER_CHILD(wx_, wy_, wz_, hit_, key_) { \
       const uint32_t wx = AMBER_ROT(wx_, 0), wy = AMBER_ROT(wy_, 1), wz = AMBER_ROT(wz_, 2); \
       const float nx = __builtin_fmaf(AMBER_QLO(wx), tr.A.x, tr.b_in.x), ny = __builtin_fmaf(AMBER_QLO(wy), tr.A.y, tr.b_in.y), nz = __builtin_fmaf(AMBER_QLO(wz), tr.A.z, tr.b_in.z); \
@@ -1066,8 +1077,8 @@ __device__ __forceinline__ void BvhDescend(const DevScene& sc, const Stack& stac
     const int32_t left = static_cast<int32_t>(q.z), right = static_cast<int32_t>(q.w);
     // rotate each axis word so that the entry plane is the low half, convert (v_cvt_f32_u32 with a half-word select), one fma
 #define AMBER_ROT(wd, c) __builtin_amdgcn_alignbit((wd), (wd), tr.rot[c])
-#define AMBER_QLO(wd) static_cast<float>((wd) & 0xffffu)
-#define AMBER_QHI(wd) static_cast<float>((wd) >> 16)
+#define AMBER_QLO(wd) AMBER_PLANE_VALUE((wd) & 0xffffu)
+#define AMBER_QHI(wd) AMBER_PLANE_VALUE((wd) >> 16)
     const uint32_t wlx = AMBER_ROT(p.x, 0), wly = AMBER_ROT(p.y, 1), wlz = AMBER_ROT(p.z, 2), wrx = AMBER_ROT(p.w, 0), wry = AMBER_ROT(q.x, 1), wrz = AMBER_ROT(q.y, 2);
     const float lnx = __builtin_fmaf(AMBER_QLO(wlx), tr.A.x, tr.b_in.x), lny = __builtin_fmaf(AMBER_QLO(wly), tr.A.y, tr.b_in.y), lnz = __builtin_fmaf(AMBER_QLO(wlz), tr.A.z, tr.b_in.z);
     const float lfx = __builtin_fmaf(AMBER_QHI(wlx), tr.A.x, tr.b_out.x), lfy = __builtin_fmaf(AMBER_QHI(wly), tr.A.y, tr.b_out.y), lfz = __builtin_fmaf(AMBER_QHI(wlz), tr.A.z, tr.b_out.z);
