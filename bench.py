@@ -281,6 +281,9 @@ def main():
         if args.rehearse_on_one_gpu and world > 1:
             tracer.sync()
             return gather(fb.cpu())                                # gloo: host tensors
+        if collective:
+            tracer.sync()                                          # a launch that ran out of record slots is repeated HERE: the
+                                                                   # gather below must not ship a framebuffer that still misses it
         with torch.cuda.stream(render_stream):
             if timed and collective:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
