@@ -632,8 +632,10 @@ __global__ void pixel_mask_kernel(const DevScene sc, const PixelMaskArgs pm, uin
 #ifndef AMBER_BVH_WGS
 #define AMBER_BVH_WGS 5
 #endif
-template <bool kLight, int kStack>
-__global__ void __launch_bounds__(256, kStack <= 24 ? AMBER_BVH_WGS : 4) pt_bvh_megakernel(const RenderArgs a) {
+// kSig (tests only, amber_hip_pt_signatures): the same kernel also hashes every cast's hit object and hit distance and stores the pair
+// at the path's end -- config 3's PRODUCT kernel compared with the oracle path by path, like pt_megakernel's signature instantiation.
+template <bool kLight, int kStack, bool kSig = false>
+__global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4) pt_bvh_megakernel(const RenderArgs a) {
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
   __shared__ int32_t lds_stack[kStack * 256];
@@ -648,6 +650,7 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? AMBER_BVH_WGS : 4) pt_bvh_
   uint32_t casts = 0;
   uint32_t rays_wave = 0;                                   // wave-uniform (SGPR): rays shaded by this wave
   int origin_slot = -1;
+  uint32_t sig_obj = 2166136261u, sig_t = 2166136261u;      // kSig only
   BvhTrav tr; tr.A = v3(0.f, 0.f, 0.f); tr.b_in = v3(0.f, 0.f, 0.f); tr.b_out = v3(0.f, 0.f, 0.f); tr.neg_slack = 0.f; tr.rot[0] = tr.rot[1] = tr.rot[2] = 0u;
   tr.cur = AMBER_BVH_DONE; tr.pend = 0; tr.sp = 0; tr.overflow = false;
   HitRec hit; hit.t = 0.f; hit.u = 0.f; hit.v = 0.f; hit.idx = -1; hit.slot = -1;
@@ -721,6 +724,7 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? AMBER_BVH_WGS : 4) pt_bvh_
       casts = 0;
       alive = true;
       ++s;
+      if (kSig) { sig_obj = 2166136261u; sig_t = 2166136261u; }
       BvhBegin(sc, o, d, tr, hit);
       traversing = true;
     }
@@ -743,6 +747,16 @@ __global__ void __launch_bounds__(256, kStack <= 24 ? AMBER_BVH_WGS : 4) pt_bvh_
       if (kLight) {
         const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, pixel, s - 1u, sc.sensor.size_f};
         alive = PathShade<false, ENGINE_BVH, true>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_SHADE_STAMP_ARG, &sink);
+      } else if (kSig) {
+        BvhResolveIndex(sc, hit);                             // only the signature variant reports object indices
+        Bounce b;
+        alive = PathShade<true, ENGINE_BVH, false>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, &b AMBER_SHADE_STAMP_ARG, nullptr);
+        sig_obj = Fnv32(sig_obj, static_cast<uint32_t>(b.object));
+        if (b.object >= 0) sig_t = Fnv32(sig_t, __float_as_uint(b.t));
+        if (!alive) {                                         // path (band pixel, sample s - 1) of this launch
+          const uint32_t plocal = slot % a.n_pixels;
+          a.sig[static_cast<size_t>(plocal) * a.n_samples + (s - 1u - a.first_sample)] = static_cast<unsigned long long>(sig_obj) | (static_cast<unsigned long long>(sig_t) << 32);
+        }
       } else {
         alive = PathShade<false, ENGINE_BVH, false>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_SHADE_STAMP_ARG, nullptr);
       }
@@ -1470,6 +1484,15 @@ int EnsureRecordCapacity(amber_hip_pt* h, uint64_t slots) {
 
 // Enqueues one launch over samples [first, first + n) of the band.  `sig` != nullptr: the signature variant of the same
 // kernel; nothing is reduced (amber_hip_pt_signatures).
+int EnsureLaunchCtl(amber_hip_pt* h) {                                       // queue head | record count | rays of the launch: one block, one memset per launch
+  if (!h->d_launch_ctl) {
+    HIP_TRY(hipMalloc(&h->d_launch_ctl, 4 * sizeof(unsigned int)));
+    h->d_rec_count = h->d_launch_ctl + 1;
+    h->d_rays_launch = reinterpret_cast<unsigned long long*>(h->d_launch_ctl + 2);
+  }
+  return AMBER_OK;
+}
+
 int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, unsigned long long* sig) {
   const uint64_t n_paths = static_cast<uint64_t>(n_pixels) * n;
   const bool bvh = h->hit_engine == AMBER_ENGINE_BVH;
@@ -1500,11 +1523,7 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
     if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(pixel ranks): ") + hipGetErrorString(e));
     h->rank_pixels = n_pixels;
   }
-  if (!h->d_launch_ctl) {                                                   // queue head | record count | rays of the launch: one block, one memset per launch
-    HIP_TRY(hipMalloc(&h->d_launch_ctl, 4 * sizeof(unsigned int)));
-    h->d_rec_count = h->d_launch_ctl + 1;
-    h->d_rays_launch = reinterpret_cast<unsigned long long*>(h->d_launch_ctl + 2);
-  }
+  { const int rc = EnsureLaunchCtl(h); if (rc != AMBER_OK) return rc; }
   if (!h->h_rec_count) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_rec_count), sizeof(unsigned int), hipHostMallocDefault));
   if (!h->pending_event) HIP_TRY(hipEventCreateWithFlags(&h->pending_event, hipEventDisableTiming));
   const uint32_t n_blocks = PathBlocks(h, n_paths);
@@ -1647,7 +1666,9 @@ int RenderPassPaths(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, 
 }
 }  // namespace
 
-extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples) {
+extern "C" int RenderPassBvhItems(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint32_t n_pixels, unsigned long long* sig);
+
+int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples) {
   if (!h) return Fail(AMBER_EINVAL, "null handle");
   if (n_samples == 0) return AMBER_OK;
   if (static_cast<uint64_t>(first_sample) + n_samples > 0xffffffffull) return Fail(AMBER_EINVAL, "sample index overflow");
@@ -1656,6 +1677,11 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
   if (n_pixels == 0) return AMBER_OK;                    // empty band
   if (h->engine == AMBER_ENGINE_WAVEFRONT) return RenderPassWavefront(h, first_sample, n_samples);
   if (h->hit_engine != AMBER_ENGINE_BVH || h->bvh_pool) return RenderPassPaths(h, first_sample, n_samples, n_pixels);
+  return RenderPassBvhItems(h, first_sample, n_samples, n_pixels, nullptr);
+}
+
+// sig != null (amber_hip_pt_signatures): one launch of the signature instantiation; nothing reaches the framebuffer or the ray total
+int RenderPassBvhItems(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint32_t n_pixels, unsigned long long* sig) {
   // engine BVH, default scheduler (pt_bvh_megakernel: lanes own (pixel, chunk) items).  A launch covers at most kMaxPartialFloats
   // of per-item sums and < 2^31 items; longer passes are split on chunk boundaries, which leaves the summation order unchanged
   const uint64_t kMaxPartialFloats = 768ull << 20;    // 3 GiB
@@ -1677,10 +1703,12 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
       if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(partial sums): ") + hipGetErrorString(e));
       h->partial_floats = need;
     }
+    if (sig && n != n_samples) return Fail(AMBER_EINVAL, "too many paths for one signature launch");
+    if (sig) { const int rc = EnsureLaunchCtl(h); if (rc != AMBER_OK) return rc; }
     RenderArgs a{};
-    a.scene = h->scene; a.partial = h->d_partial; a.ray_count = h->d_rays; a.next_item = h->d_next; a.stamps = h->d_stamps; a.hashed_seed = h->hashed_seed;
+    a.scene = h->scene; a.partial = h->d_partial; a.ray_count = sig ? h->d_rays_launch : h->d_rays; a.next_item = h->d_next; a.stamps = h->d_stamps; a.hashed_seed = h->hashed_seed;
     a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first_sample + done; a.n_samples = n;
-    a.n_chunks = n_chunks; a.n_items = n_pixels * n_chunks;
+    a.n_chunks = n_chunks; a.n_items = n_pixels * n_chunks; a.sig = sig;
     // persistent workers: one workgroup of 4 waves per CU and resident wave slot, fewer if the queue is short
     uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth);
     const uint32_t by_work = (a.n_items + 255u) / 256u;
@@ -1690,6 +1718,13 @@ extern "C" int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, 
     { const int rc = AcquireEventPair(h, &evp); if (rc != AMBER_OK) return rc; }
     auto& ev = *evp;
     HIP_TRY(hipEventRecord(ev.first, h->stream));
+    if (sig) {
+      if (h->bvh_depth <= 24) hipLaunchKernelGGL((pt_bvh_megakernel<false, 24, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+      else hipLaunchKernelGGL((pt_bvh_megakernel<false, AMBER_BVH_STACK, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(ev.second, h->stream));
+      return AMBER_OK;
+    }
     if (h->bvh_depth <= 24) hipLaunchKernelGGL((pt_bvh_megakernel<false, 24>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL((pt_bvh_megakernel<false, AMBER_BVH_STACK>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
@@ -2081,7 +2116,8 @@ int amber_hip_kat_traversal_rate(amber_hip_pt* h, uint32_t n, const float* origi
 int amber_hip_pt_signatures(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint64_t* out) {
   if (!h || !out || n_samples == 0) return Fail(AMBER_EINVAL, "bad argument");
   if (static_cast<uint64_t>(first_sample) + n_samples > 0xffffffffull) return Fail(AMBER_EINVAL, "sample index overflow");
-  if (h->engine == AMBER_ENGINE_WAVEFRONT || (h->hit_engine == AMBER_ENGINE_BVH && !h->bvh_pool)) return Fail(AMBER_EINVAL, "signatures come from the path-granular kernels (engines list / two_phase, or bvh with AMBER_PT_FLAG_BVH_POOL)");
+  if (h->engine == AMBER_ENGINE_WAVEFRONT) return Fail(AMBER_EINVAL, "signatures come from the work-queue kernels (engines list, two_phase, bvh)");
+  const bool bvh_items = h->hit_engine == AMBER_ENGINE_BVH && !h->bvh_pool;        // pt_bvh_megakernel's signature instantiation
   const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
   const uint64_t n = static_cast<uint64_t>(n_pixels) * n_samples;
   if (n == 0) return AMBER_OK;
@@ -2095,9 +2131,13 @@ int amber_hip_pt_signatures(amber_hip_pt* h, uint32_t first_sample, uint32_t n_s
     if (e != hipSuccess) return Fail(AMBER_ENOMEM, std::string("hipMalloc(signatures): ") + hipGetErrorString(e));
     h->sig_paths = n;
   }
-  { const int rc = EnsureRecordCapacity(h, RecordSlack(h)); if (rc != AMBER_OK) return rc; }   // records of this launch are discarded
   HIP_TRY(hipMemsetAsync(h->d_sig, 0, n * sizeof(unsigned long long), h->stream));
-  { const int rc = LaunchPaths(h, first_sample, n_samples, n_pixels, h->d_sig); if (rc != AMBER_OK) return rc; }
+  if (bvh_items) {
+    const int rc = RenderPassBvhItems(h, first_sample, n_samples, n_pixels, h->d_sig); if (rc != AMBER_OK) return rc;
+  } else {
+    { const int rc = EnsureRecordCapacity(h, RecordSlack(h)); if (rc != AMBER_OK) return rc; }   // records of this launch are discarded
+    const int rc = LaunchPaths(h, first_sample, n_samples, n_pixels, h->d_sig); if (rc != AMBER_OK) return rc;
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out, h->d_sig, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return AMBER_OK;

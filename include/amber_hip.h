@@ -220,7 +220,7 @@ int amber_hip_kat_trace(amber_hip_pt*, uint32_t n, const uint32_t* pixel, const 
  * DIVERGED iff these differ -- and FNV-1a-32 over the bits of every hit distance in the high word.  out: host pointer,
  * local_rows * width * n_samples entries. */
 int amber_hip_kat_signatures(amber_hip_pt*, uint32_t first_sample, uint32_t n_samples, uint64_t* out);
-/* The same signatures from the PRODUCT render kernel (pt_megakernel / pt_bvh_pool_kernel instantiated with the hashing
+/* The same signatures from the PRODUCT render kernel (pt_megakernel / pt_bvh_megakernel / pt_bvh_pool_kernel instantiated with the hashing
  * switched on: identical scheduling, work queue, ray pool and device functions), so that the kernel that renders -- not
  * only the per-thread known-answer kernel above -- is compared with the oracle path by path
  * (algorithm_pt.cc:125-160).  Same layout as amber_hip_kat_signatures.  Leaves the framebuffer and the ray count untouched. */

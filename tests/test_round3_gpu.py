@@ -33,14 +33,14 @@ def _split(sig):
 
 
 def test_product_kernel_signatures_against_the_oracle(amber, cornell):
-    """algorithm_pt.cc:125-160, path by path, from the kernels that RENDER: pt_megakernel (two-phase and list) and
-    pt_bvh_pool_kernel instantiated with the hashing on -- same work queue, ray pool and device functions as the product
+    """algorithm_pt.cc:125-160, path by path, from the kernels that RENDER: pt_megakernel (two-phase and list), pt_bvh_megakernel
+    and pt_bvh_pool_kernel instantiated with the hashing on -- same work queue, ray pool and device functions as the product
     instantiation.  Object sequence and hit distances of every path == oracle (List), == the per-thread KAT kernel."""
     hs, osc = cornell
     W = H = 256
     rows, spp, seed = (100, 108), 64, 12345
     so = osc.path_signatures(W, H, seed, 0, spp, rows, threads=16)
-    for engine, flags in ((amber.ENGINE_TWO_PHASE, 0), (amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_POOL)):
+    for engine, flags in ((amber.ENGINE_TWO_PHASE, 0), (amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_POOL)):
         pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=seed, rows=rows, engine=engine, flags=flags)
         pt.render_pass(0, 8)                                           # state left by a render must not matter
         img0, rays0 = pt.download()
@@ -56,8 +56,23 @@ def test_product_kernel_signatures_against_the_oracle(amber, cornell):
     from amber_amd import scenes
     k = _mixed_scene(3000, 11)
     hm, om = amber.HostScene.create_arrays(**k), O.Scene.create(**scenes.as_tuples(k), accel=O.ACCEL_LIST)
-    pt = amber.PathTracer(hm, amber.Sensor.default(40, 40), seed=21, flags=amber.api.PT_FLAG_BVH_POOL)
-    assert np.array_equal(pt.render_signatures(0, 24), om.path_signatures(40, 40, 21, 0, 24, (0, 40), threads=16))
+    sm = om.path_signatures(40, 40, 21, 0, 24, (0, 40), threads=16)
+    for flags in (amber.api.PT_FLAG_BVH_POOL, 0):                      # ... and through engine BVH's default kernel (pt_bvh_megakernel)
+        pt = amber.PathTracer(hm, amber.Sensor.default(40, 40), seed=21, flags=flags)
+        assert np.array_equal(pt.render_signatures(0, 24), sm), flags
+        pt.close()
+    # BASELINE config 3's own scene: the kernel that renders it (pt_bvh_megakernel) against the per-thread known-answer kernel on every
+    # path of a band of the real frame, and against the oracle's reference BVH on the paths without an exact distance tie
+    hb = amber.HostScene.create_arrays(**scenes.random_spheres(1_000_000, 7))
+    ob = O.Scene.create_arrays(**scenes.random_spheres(1_000_000, 7), accel=O.ACCEL_BVH) if hasattr(O.Scene, "create_arrays") else None
+    pt = amber.PathTracer(hb, amber.Sensor.default(1920, 1080), seed=1, rows=(536, 540))
+    sg = pt.render_signatures(0, 16)
+    assert np.array_equal(sg, pt.kat_signatures(0, 16))
+    assert len(np.unique(sg & np.uint64(0xffffffff))) > 1000           # thousands of different hit sequences
+    if ob is not None:
+        so3 = ob.path_signatures(1920, 1080, 1, 0, 16, (536, 540), threads=16)
+        assert (sg != so3).mean() < 1e-4                               # (random spheres: an exact tie between two objects is all but impossible)
+    pt.close()
 
 
 def test_config2_whole_frame_at_64spp_against_the_oracle(amber, cornell):
