@@ -444,3 +444,19 @@ def test_candidate_masks_of_the_primary_rays_change_nothing(amber, cornell):
         first, n = launches[0]
         assert np.array_equal(off.render_signatures(first, n), on.render_signatures(first, n)), name
         off.close(); on.close()
+
+
+def test_config2_at_full_size_against_the_oracle(amber, cornell):
+    """BASELINE config 2 as the bench renders it -- Cornell 1024x1024 @ 1024 spp, one launch, 2.25e9 rays -- against oracle(XorShift, List,
+    live libm) on EVERY pixel and EVERY sample: image bits and the ray count (half a minute of oracle time on the box's 16 host threads;
+    profiles/r03_full_frame_parity.txt also has the oracle's reference-BVH run: 0 pixels differ, 163 rays of exact-tie paths)."""
+    hs, _ = cornell
+    osc = O.Scene.cornell(O.ACCEL_LIST)
+    W = H = 1024
+    pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=12345)
+    pt.render_pass(0, 1024)
+    img, rays = pt.download()
+    ref, cnt = osc.render_xorshift(W, H, 12345, 0, 1024, math=O.MATH_LIBM, threads=16)
+    assert rays == cnt.casts == 2248938869
+    assert np.array_equal(bits(img), bits(ref)) and 8000 < (ref > 0).any(axis=2).sum() < 9000
+    pt.close()
