@@ -3,7 +3,10 @@ import sys, os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)));
 import numpy as np
 import amber_amd as A
 from amber_amd import scenes
-flags = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+flags = next((int(a) for a in sys.argv[1:] if a.isdigit()), 0)
+import amber_amd.api as api
+for a in sys.argv[1:]:
+    if a.endswith(".so"): api._LIB_PATH = api._ROOT / "lib" / a
 hs = A.HostScene.create_arrays(**scenes.random_spheres(1_000_000, 7))
 pt = A.PathTracer(hs, A.Sensor.default(1920, 1080), seed=1, flags=flags)
 pt.render_pass(0, 8); pt.sync(); pt.clear()
