@@ -1,19 +1,25 @@
 // pt_engine.hip -- kernels and C ABI (include/amber_hip.h) of the gfx950 path-tracing engine.
 //
-// Persistent work-queue kernels.  The work unit is ONE PATH, numbered q = (band pixel) * n_samples + (sample offset)
-// within a launch; a wave claims blocks of consecutive paths with one atomicAdd on the global queue head.
-//   pt_megakernel       (<= 32 objects: engines LIST / TWO_PHASE; also light tracing) -- lanes are decoupled from pixels:
-//                       eye rays are generated 64 at a time into a per-wave pool in LDS, a lane whose path ended pops the
-//                       next ray (ballot + mbcnt rank); ray / throughput / sampler state lives in VGPRs; scene records
-//                       arrive through scalar loads (wave-uniform indices).
-//   pt_bvh_pool_kernel  (engine BVH, bvh_pool.inc) -- 64 rays in flight on the lanes plus a pool of waiting rays per wave
-//                       in LDS: a lane whose traversal finished swaps its ray for a waiting one at once, finished rays
-//                       are shaded in batches; resumable traversal with a short per-lane stack in LDS.
-//   pt_bvh_megakernel   (engine BVH, light tracing only) -- round 2's form: lanes own (pixel, chunk) items.
-// Accumulation without owners: a path that ends with a non-zero measurement appends a record {q, rgb} (slots reserved
-// per wave, 64 at a time) and sets bit q of a bitmap; rec_rank_kernel / rec_place_kernel move the records into path order
-// and reduce_flagged_kernel forms, per pixel, exactly the sums of the numerical contract.
-// wavefront.inc holds the streaming (SoA queues in HBM, one launch per bounce) formulation, kept for measurement.
+// Persistent work-queue kernels.
+//   pt_megakernel       (<= 32 objects: engines LIST / TWO_PHASE; also light tracing) -- the work unit is ONE PATH, numbered
+//                       q = (band pixel) * n_samples + (sample offset) within a launch; a wave claims 1024 consecutive paths with
+//                       one atomicAdd.  Lanes are decoupled from pixels: when the wave's pool (LDS) cannot serve a lane, every
+//                       lane parks its ray there and all 64 lanes start the next 64 paths together (a PRIMARY ROUND: 64 samples
+//                       of one pixel, whose candidate objects come from a per-pixel mask, pixel_mask_kernel); a lane whose path
+//                       ended pops a parked ray (ballot + mbcnt rank).  Ray / throughput / sampler state lives in VGPRs; scene
+//                       records arrive through scalar loads (wave-uniform indices).
+//   pt_bvh_megakernel   (engine BVH, the default for larger scenes; also light tracing) -- lanes own (pixel, chunk of 8 samples)
+//                       items; the closest hit is a RESUMABLE per-lane traversal of the 2-wide binary16-plane tree (stack in LDS),
+//                       advanced in wave rounds until 52 lanes have finished theirs; those are shaded and restarted.
+//   pt_bvh_pool_kernel  (engine BVH, opt-in: AMBER_PT_FLAG_BVH_POOL; bvh_pool.inc) -- path-granular; 64 rays in flight on the
+//                       lanes plus a pool of waiting rays per wave in LDS: a lane whose traversal finished swaps its ray for a
+//                       waiting one at once, finished rays are shaded in batches.  Bit-identical, measured slower.
+// Accumulation without owners (the path-granular kernels): a path that ends with a non-zero measurement appends a record {q, rgb}
+// (slots reserved per wave, 64 at a time) and sets bit q of a bitmap; rec_rank_kernel / rec_place_kernel move the records into
+// path order and reduce_flagged_kernel forms, per pixel, exactly the sums of the numerical contract;
+// pt_bvh_megakernel writes one sum per item and reduce_partials_kernel adds them in chunk order -- the same sums.
+// wavefront.inc holds the streaming (SoA queues in HBM, one launch per bounce) formulation, bvh_stream.inc the traversal on
+// its own; both kept for measurement.
 //
 // Replaces: PathTracing<RGB>::Thread::operator() / Render
 //           (/root/reference/src/amber/rendering/algorithm_pt.cc:112-160).
