@@ -38,7 +38,10 @@ using amber_dev::DevObject;
 constexpr int kLeafSize = AMBER_BVH_LEAF_SIZE;   // <= 3 (quantised leaf references: 2-bit count + the spheres-only flag)
 static_assert(kLeafSize >= 1 && kLeafSize <= 3, "DevBvhNodeQ leaf references hold a 2-bit count");
 constexpr int kMaxDepth = 30;     // device stack holds 32 entries
-constexpr int kBins = 16;
+#ifndef AMBER_BVH_BINS
+#define AMBER_BVH_BINS 16   // config 3 at 128 spp (round 3): 8 bins 102.4 ms, 16 -> 101.9, 32 -> 104.5
+#endif
+constexpr int kBins = AMBER_BVH_BINS;
 
 struct Box {
   float mn[3], mx[3];
