@@ -33,7 +33,7 @@ using amber_dev::DevBvhNodeQ4;
 using amber_dev::DevObject;
 
 #ifndef AMBER_BVH_LEAF_SIZE
-#define AMBER_BVH_LEAF_SIZE 3   // config 3 at 128 spp: 2 -> 151.5 ms, 3 -> 151.1, 4 -> 157.9, 6 -> 173.6
+#define AMBER_BVH_LEAF_SIZE 3   // config 3 at 128 spp: 2 -> 151.5 ms, 3 -> 151.1, 4 -> 157.9, 6 -> 173.6 (round 1); 1 -> 120.2, 2 -> 106.3, 3 -> 101.6 (round 3: two-stage sphere leaves, binary16 planes)
 #endif
 constexpr int kLeafSize = AMBER_BVH_LEAF_SIZE;   // <= 3 (quantised leaf references: 2-bit count + the spheres-only flag)
 static_assert(kLeafSize >= 1 && kLeafSize <= 3, "DevBvhNodeQ leaf references hold a 2-bit count");
