@@ -16,11 +16,15 @@
  */
 #include "amber_oracle.h"
 
+#include <immintrin.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <future>
 #include <limits>
 #include <memory>
 #include <mutex>
@@ -566,18 +570,27 @@ void FinishObject(Object& o) {
 // ------------------------------------------------------------------------------------------
 // BVH (include/amber/raytracer/acceleration_bvh.h:134-403) and List (acceleration_list.h:51-68)
 // ------------------------------------------------------------------------------------------
+// Conservative culling (ORACLE_ACCEL_BVH_CONS): a ray prepared for the widened slab test (ConsRay, below the BVH).
+struct ConsRay {
+  double o[3], d[3];
+  bool flat[3];          // d == 0 on the axis: the ray stays at o there
+  double E;              // extra half width of every box for THIS ray (direction-length drift of the sphere test)
+  double slack_t;        // absolute slack of every comparison between a box parameter and a reference hit distance
+};
+
 struct BVH {
   using It = std::vector<Object>::iterator;
   struct Node {
     std::unique_ptr<Node> left, right;
     It first, last;
-    AABB bb;
+    AABB bb;             // the reference's box: union of Primitive::BoundingBox
+    AABB cb;             // ORACLE_ACCEL_BVH_CONS only: union of ConservativeBox over the subtree
   };
   struct Split { float cost = FLT_MAX; It middle; AABB bl = EmptyBox(), br = EmptyBox(); };
 
   std::vector<Object> objects;
   std::unique_ptr<Node> root;
-  uint32_t n_nodes = 0, n_leaves = 0, max_depth = 0;
+  std::atomic<uint32_t> n_nodes{0}, n_leaves{0}, max_depth{0};
 
   static AABB Box(It first, It last) {                                  // :182-194
     AABB bb = EmptyBox();
@@ -587,15 +600,19 @@ struct BVH {
   static float SAH(const AABB& p, const AABB& l, const AABB& r, std::size_t nl, std::size_t nr) {  // :298-312
     return 2 * 2.0f + (nl * SurfaceArea(l) + nr * SurfaceArea(r)) / SurfaceArea(p) * 1.0f;
   }
-  static Split FindSplitAxis(It first, It last, const AABB& bb, std::function<float(V3)> axis) {   // :243-296
-    std::sort(first, last, [&](const Object& a, const Object& b) { return axis(Center(a)) < axis(Center(b)); });
+  // The reference passes the axis as a std::function<real_type(const Vector3&)> (:243-246); a template parameter calls the same
+  // comparisons in the same order (std::sort / std::lower_bound are deterministic functions of the comparator's answers), 3x faster.
+  template <int kAxis> static float Axis(V3 v) { return kAxis == 0 ? v.x : (kAxis == 1 ? v.y : v.z); }
+  template <int kAxis>
+  static Split FindSplitAxis(It first, It last, const AABB& bb) {       // :243-296
+    std::sort(first, last, [](const Object& a, const Object& b) { return Axis<kAxis>(Center(a)) < Axis<kAxis>(Center(b)); });
     const std::size_t n_splits =
         std::min<std::size_t>(15.0f, std::log2(std::distance(first, last)));
     Split split;
     for (std::size_t i = 0; i < n_splits; i++) {
-      const float split_point = axis(bb.mn) + (axis(bb.mx) - axis(bb.mn)) * (i + 1) / (n_splits + 1);
+      const float split_point = Axis<kAxis>(bb.mn) + (Axis<kAxis>(bb.mx) - Axis<kAxis>(bb.mn)) * (i + 1) / (n_splits + 1);
       const It middle = std::lower_bound(first, last, split_point,
-          [&](const Object& object, const float sp) { return axis(Center(object)) < sp; });
+          [](const Object& object, const float sp) { return Axis<kAxis>(Center(object)) < sp; });
       const AABB bl = Box(first, middle), br = Box(middle, last);
       const std::size_t nl = std::distance(first, middle), nr = std::distance(middle, last);
       const float cost = SAH(bb, bl, br, nl, nr);
@@ -604,9 +621,9 @@ struct BVH {
     return split;
   }
   static Split FindSplit(It first, It last, const AABB& bb) {           // :197-241
-    const Split sx = FindSplitAxis(first, last, bb, [](V3 v) { return v.x; });
-    const Split sy = FindSplitAxis(first, last, bb, [](V3 v) { return v.y; });
-    const Split sz = FindSplitAxis(first, last, bb, [](V3 v) { return v.z; });
+    const Split sx = FindSplitAxis<0>(first, last, bb);
+    const Split sy = FindSplitAxis<1>(first, last, bb);
+    const Split sz = FindSplitAxis<2>(first, last, bb);
     if (sx.cost < sy.cost && sx.cost < sz.cost) {
       std::sort(first, last, [](const Object& a, const Object& b) { return Center(a).x < Center(b).x; });
       return sx;
@@ -618,18 +635,28 @@ struct BVH {
       return sz;
     }
   }
+  // Subtrees work on disjoint ranges of `objects`, so the two recursive calls of a large node may run on two threads: the tree
+  // (topology, boxes, object order) is the one the single-threaded reference recursion builds.  1M spheres: 19 s -> 4 s on 8 cores.
   std::unique_ptr<Node> Create(It first, It last, const AABB& bb, uint32_t depth) {   // :158-180
-    n_nodes++; max_depth = std::max(max_depth, depth);
+    n_nodes++;
+    for (uint32_t seen = max_depth.load(); depth > seen && !max_depth.compare_exchange_weak(seen, depth);) {}
     const Split split = FindSplit(first, last, bb);
     auto node = std::make_unique<Node>();
     node->bb = bb;
+    node->cb = EmptyBox();
     if (split.cost > std::distance(first, last) * 1.0f) {
       n_leaves++;
       node->first = first; node->last = last;
     } else {
       node->first = node->last = It();
-      node->left = Create(first, split.middle, split.bl, depth + 1);
-      node->right = Create(split.middle, last, split.br, depth + 1);
+      if (depth < 4 && std::distance(first, last) > 20000) {
+        auto left = std::async(std::launch::async, [&] { return Create(first, split.middle, split.bl, depth + 1); });
+        node->right = Create(split.middle, last, split.br, depth + 1);
+        node->left = left.get();
+      } else {
+        node->left = Create(first, split.middle, split.bl, depth + 1);
+        node->right = Create(split.middle, last, split.br, depth + 1);
+      }
     }
     return node;
   }
@@ -660,6 +687,160 @@ struct BVH {
     Hit fh; const Object* fo = nullptr;
     CastNode(far_, ray, nh.t, fh, fo);
     if (!fh) { out_hit = nh; out_obj = no; } else { out_hit = fh; out_obj = fo; }
+  }
+
+  // ---- ORACLE_ACCEL_BVH_CONS: the same tree, culled so that the answer is the List scan's --------------------------------
+  // The reference's BVH culls with the GEOMETRIC boxes of its primitives (Primitive::BoundingBox) while its primitive tests are
+  // binary32 arithmetic that accepts rays slightly OUTSIDE the geometry (below), returns the first-visited object on a distance
+  // tie, and stops at the near child when its hit lies in front of the far child's box (:386-391).  So Cast through the
+  // reference's BVH and through its List (acceleration_list.h:51-68) are two different functions of the ray; on the 1M-sphere
+  // scene they differ on 2e-7 of the rays.  The engine under test implements List.  List over 1M objects costs a millisecond per
+  // ray, so this mode computes the List answer at BVH speed: every object whose reference test can possibly accept the ray is
+  // tested with the reference's arithmetic (Intersect), and the winner is chosen by List's rule -- the smallest distance, the
+  // lower insertion index on a tie.  It is a restatement of nothing in the reference: it is the checker's way to evaluate
+  // acceleration_list.h:51-68 on large scenes, and tests/test_oracle_conservative_bvh.py proves it equal to the plain scan.
+  //
+  // "Can possibly accept": ConservativeBox(o) contains every point o + t d (exact arithmetic) at which the reference's test of
+  // object o returns a hit for a ray of unit direction; a ray with |d|^2 = 1 + delta may miss it by ConsRay.E.  The margins are
+  // those DESIGN.md section 5 derives for engine BVH, each taken FOUR TIMES as large (so that a GPU == oracle comparison also
+  // tests whether the engine's own margins suffice):
+  //  * sphere (primitive_sphere.cc:75-107, algebra.h:31-52): the discriminant b*b - 4*c is binary32 arithmetic on b ~ 2D,
+  //    c ~ D^2 (D = distance origin -> centre), absolute error ~ 12 eps D^2: accepted impact parameters p^2 <= r^2 + ~12 eps D^2,
+  //    and the float roots move by up to sqrt of that along the ray.  Box radius r' = sqrt(r^2 + 64 eps Dmax^2), Dmax = scene diagonal.
+  //  * triangle (primitive_triangle.cc:97-128): u and v carry an absolute error ~ 6 eps |T||E|/|det| each; along a needle
+  //    (e_max / e_min >> 1) the test accepts points ~ 36 eps |T| e_max / e_min beyond the short edge: boxes widened by 4x that.
+  //  * disk (primitive_disk.cc:94-114): geometric for any normal length; cylinder (primitive_cylinder.cc:100-142) with an axis
+  //    of length nu: radial distance <= r and axial distance <= height / nu from the base centre: sphere of radius hypot(r, height / nu).
+  //  * every box padded by 2^-14 of (scene extent + coordinate magnitude): roundings of the accepted point itself.
+  struct ConsScene {
+    V3 center{0, 0, 0}; double half_diag = 0, inv_rmin = 0, extent = 0;
+  } cons;
+  bool has_cons = false;
+
+  static AABB ConservativeBox(const Object& o, double sphere_slack2, double tri_reach, double extent) {
+    double mn[3], mx[3];
+    auto grow = [&](V3 p) { const double q[3] = {p.x, p.y, p.z}; for (int c = 0; c < 3; c++) { mn[c] = std::min(mn[c], q[c]); mx[c] = std::max(mx[c], q[c]); } };
+    for (int c = 0; c < 3; c++) { mn[c] = 1e300; mx[c] = -1e300; }
+    auto ball = [&](V3 ctr, double r) { const double q[3] = {ctr.x, ctr.y, ctr.z}; for (int c = 0; c < 3; c++) { mn[c] = q[c] - r; mx[c] = q[c] + r; } };
+    switch (o.kind) {
+      case ORACLE_PRIM_TRIANGLE: {
+        grow(o.a); grow(o.b); grow(o.c);
+        const V3 e1 = o.b - o.a, e2 = o.c - o.a, e3 = o.c - o.b;
+        const double l1 = double(e1.x) * e1.x + double(e1.y) * e1.y + double(e1.z) * e1.z, l2 = double(e2.x) * e2.x + double(e2.y) * e2.y + double(e2.z) * e2.z,
+                     l3 = double(e3.x) * e3.x + double(e3.y) * e3.y + double(e3.z) * e3.z;
+        const double emax = std::sqrt(std::max({l1, l2, l3})), emin = std::sqrt(std::min({l1, l2, l3}));
+        double m = tri_reach;                                             // degenerate triangle: the whole reach
+        if (emin > 0.0 && std::isfinite(emax)) m = std::min(tri_reach, 4.0 * 36.0 * 5.9604644775390625e-08 * tri_reach * emax / emin);
+        for (int c = 0; c < 3; c++) { mn[c] -= m; mx[c] += m; }
+        break;
+      }
+      case ORACLE_PRIM_SPHERE: ball(o.a, std::sqrt(double(o.radius) * o.radius + sphere_slack2) * 1.00001); break;
+      case ORACLE_PRIM_DISK: ball(o.a, std::fabs(double(o.radius)) * 1.00001); break;
+      default: {
+        const double nu = std::sqrt(double(o.b.x) * o.b.x + double(o.b.y) * o.b.y + double(o.b.z) * o.b.z);
+        const double axial = nu > 1e-30 ? std::fabs(double(o.height)) / nu : 1e30;
+        ball(o.a, std::min(1e30, std::hypot(double(o.radius), axial) * 1.00001));
+      }
+    }
+    AABB bb;
+    float* lo[3] = {&bb.mn.x, &bb.mn.y, &bb.mn.z}; float* hi[3] = {&bb.mx.x, &bb.mx.y, &bb.mx.z};
+    for (int c = 0; c < 3; c++) {
+      const double pad = 6.103515625e-05 * (extent + std::max(std::fabs(mn[c]), std::fabs(mx[c]))) + 1e-30;   // 2^-14
+      *lo[c] = std::nextafter(static_cast<float>(mn[c] - pad), -FLT_MAX);   // the conversion may round inward: one more step out
+      *hi[c] = std::nextafter(static_cast<float>(mx[c] + pad), FLT_MAX);
+      if (!(mn[c] == mn[c]) || !(mx[c] == mx[c])) { *lo[c] = -FLT_MAX; *hi[c] = FLT_MAX; }                    // NaN geometry: never culled
+    }
+    return bb;
+  }
+  AABB FillCons(Node* n, double sphere_slack2, double tri_reach, double extent) {
+    if (n->first != n->last) {
+      n->cb = EmptyBox();
+      for (It i = n->first; i != n->last; ++i) n->cb = Union(n->cb, ConservativeBox(*i, sphere_slack2, tri_reach, extent));
+    } else {
+      n->cb = EmptyBox();
+      if (n->left) n->cb = Union(n->cb, FillCons(n->left.get(), sphere_slack2, tri_reach, extent));
+      if (n->right) n->cb = Union(n->cb, FillCons(n->right.get(), sphere_slack2, tri_reach, extent));
+    }
+    return n->cb;
+  }
+  void BuildConservative() {
+    const AABB all = root->bb;                                           // geometric bounds of the scene
+    const double dx = double(all.mx.x) - all.mn.x, dy = double(all.mx.y) - all.mn.y, dz = double(all.mx.z) - all.mn.z;
+    const double diag = std::sqrt(dx * dx + dy * dy + dz * dz);
+    const double sphere_slack2 = 64.0 * 5.9604644775390625e-08 * diag * diag;
+    cons.extent = std::max({dx, dy, dz});
+    const AABB cb = FillCons(root.get(), sphere_slack2, diag, cons.extent);
+    cons.center = v3(0.5f * (cb.mn.x + cb.mx.x), 0.5f * (cb.mn.y + cb.mx.y), 0.5f * (cb.mn.z + cb.mx.z));
+    const double ex = double(cb.mx.x) - cb.mn.x, ey = double(cb.mx.y) - cb.mn.y, ez = double(cb.mx.z) - cb.mn.z;
+    cons.half_diag = 0.5 * std::sqrt(ex * ex + ey * ey + ez * ez) * 1.001;
+    double rmin = 1e300; bool spheres = false;
+    for (const Object& o : objects) if (o.kind == ORACLE_PRIM_SPHERE) { spheres = true; rmin = std::min(rmin, std::fabs(double(o.radius))); }
+    cons.inv_rmin = spheres ? (rmin > 0 ? 1.0 / rmin : 1e300) : 0.0;
+    has_cons = true;
+  }
+  // Direction length: the reference never renormalises sampled directions (vector3.h:236-239) and its sphere test assumes
+  // |d| = 1 (a = 1, primitive_sphere.cc:80-83).  With |d|^2 = 1 + delta, s the distance of the closest approach along the ray
+  // and p the impact parameter, its discriminant is 4 (r^2 - p^2 + delta s^2): it accepts p^2 <= r^2 + delta s^2, i.e. misses the
+  // sphere's box by up to sqrt(r^2 + delta s^2) - r <= min(delta S^2 / r_min, sqrt(delta) S) with S >= s (S = |o - centre| + half
+  // the scene diagonal); and its distance |d| s -+ sqrt(..) differs from the parameter of the geometric crossing, (s -+ h) / |d|,
+  // by about |delta| s / |d|.  Both four times the engine's: E = 4 min(..), slack_t = 8 |delta| S / min(|d|, 1).
+  ConsRay Prepare(const Ray& ray) const {
+    ConsRay r;
+    const double o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
+    for (int c = 0; c < 3; c++) { r.o[c] = o[c]; r.d[c] = d[c]; r.flat[c] = d[c] == 0.0; }
+    const double len2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], delta = len2 - 1.0;
+    const double cx = o[0] - cons.center.x, cy = o[1] - cons.center.y, cz = o[2] - cons.center.z;
+    const double S = 1.001 * (std::sqrt(cx * cx + cy * cy + cz * cz) + cons.half_diag);
+    const double dpos = delta > 0 ? delta : 0.0;
+    r.E = cons.inv_rmin > 0 ? 4.0 * std::min(dpos * S * S * cons.inv_rmin, std::sqrt(dpos) * S) : 0.0;
+    const double len = std::sqrt(std::min(len2, 1.0));
+    r.slack_t = 8.0 * std::fabs(delta) * S / (len > 0 ? len : 1e-300) + 1e-9 * S;
+    if (!(r.E == r.E)) r.E = 1e300;                                      // NaN ray: nothing is culled (every exact test then fails on its own)
+    if (!(r.slack_t == r.slack_t)) r.slack_t = 1e300;
+    return r;
+  }
+  // The ray's parameter interval inside cb widened by E, in binary64 (the box planes and the ray are binary32 values, so lo - o is
+  // exact or rounds once; the quotient rounds once: each plane parameter is within 2^-51 of its exact value, covered by the
+  // relative 1e-9).  Written so that a NaN anywhere means "visit".
+  static bool SlabCons(const AABB& cb, const ConsRay& r, double t_best, double& t_in) {
+    const double mn[3] = {cb.mn.x, cb.mn.y, cb.mn.z}, mx[3] = {cb.mx.x, cb.mx.y, cb.mx.z};
+    double tn = -1e300, tf = 1e300;
+    for (int c = 0; c < 3; c++) {
+      const double lo = mn[c] - r.E, hi = mx[c] + r.E;
+      if (r.flat[c]) { if (r.o[c] < lo || r.o[c] > hi) return false; continue; }
+      double t0 = (lo - r.o[c]) / r.d[c], t1 = (hi - r.o[c]) / r.d[c];
+      if (t1 < t0) std::swap(t0, t1);
+      t0 -= 1e-9 * std::fabs(t0); t1 += 1e-9 * std::fabs(t1);
+      if (t0 > tn) tn = t0;
+      if (t1 < tf) tf = t1;
+    }
+    t_in = tn;
+    if (tn > tf) return false;                                           // the ray misses the widened box
+    if (tf + r.slack_t < 0.0) return false;                              // the box lies behind the origin (accepted hits have t > kEPS)
+    if (tn - r.slack_t > t_best * (1.0 + 1e-6)) return false;            // the box begins behind the closest hit so far (ties are visited)
+    return true;
+  }
+  static void CastCons(const Node* n, const Ray& ray, const ConsRay& cr, float& distance, Hit& best, const Object*& best_obj) {
+    if (n->first != n->last) {
+      for (It i = n->first; i != n->last; ++i) {
+        const Hit hit = Intersect(*i, ray);
+        // acceleration_list.h:58-64 scans in insertion order with a strict <: the smallest distance, then the lowest index
+        if (hit && (hit.t < distance || (best_obj && hit.t == distance && i->index < best_obj->index))) { distance = hit.t; best = hit; best_obj = &*i; }
+      }
+      return;
+    }
+    bool lh = false, rh = false; double lin = 0, rin = 0;
+    if (n->left) lh = SlabCons(n->left->cb, cr, distance, lin);
+    if (n->right) rh = SlabCons(n->right->cb, cr, distance, rin);
+    const Node* first = n->left.get(); const Node* second = n->right.get();
+    if (lh && rh && rin < lin) std::swap(first, second);
+    if (!lh) { first = rh ? n->right.get() : nullptr; second = nullptr; }
+    else if (!rh) second = nullptr;
+    if (first) CastCons(first, ray, cr, distance, best, best_obj);
+    if (second) {
+      double tin;
+      if (SlabCons(second->cb, cr, distance, tin)) CastCons(second, ray, cr, distance, best, best_obj);   // re-tested against the closer hit found meanwhile
+    }
   }
 };
 
@@ -966,7 +1147,8 @@ struct oracle_scene {
   void Finish() {
     for (uint32_t i = 0; i < objects.size(); i++) objects[i].index = i;
     BuildLightSet();
-    if (accel == ORACLE_ACCEL_BVH) bvh = std::make_unique<BVH>(std::vector<Object>(objects));
+    if (accel == ORACLE_ACCEL_BVH || accel == ORACLE_ACCEL_BVH_CONS) bvh = std::make_unique<BVH>(std::vector<Object>(objects));
+    if (accel == ORACLE_ACCEL_BVH_CONS) bvh->BuildConservative();
   }
   // Scene::Create collects the SurfaceType::Light objects (scene/scene.h:177-182); LightSet sorts them by power and
   // accumulates (light_set.h:61-82).  Power = Sum(SurfaceArea * Irradiance) (scene/object.h:99-103), Irradiance = radiance * pi.
@@ -985,9 +1167,14 @@ struct oracle_scene {
     for (const Item& it : items) { power += it.power; light_set.lights.push_back(Light{it.index, power, it.irradiance()}); }
   }
   // Scene::Cast scene/scene.h:236-244 -> Acceleration::Cast(ray, FLT_MAX) acceleration.h:46-51
-  bool Cast(const Ray& ray, Hit& hit, const Object*& obj) const {
-    if (accel == ORACLE_ACCEL_BVH) {
+  bool Cast(const Ray& ray, Hit& hit, const Object*& obj) const { return CastWith(accel, ray, hit, obj); }
+  bool CastWith(int how, const Ray& ray, Hit& hit, const Object*& obj) const {
+    if (how == ORACLE_ACCEL_BVH) {
       BVH::CastNode(bvh->root.get(), ray, FLT_MAX, hit, obj);
+    } else if (how == ORACLE_ACCEL_BVH_CONS) {                          // acceleration_list.h:51-68 evaluated through the tree (BVH::CastCons)
+      float distance = FLT_MAX; hit = Hit(); obj = nullptr;
+      const ConsRay cr = bvh->Prepare(ray);
+      BVH::CastCons(bvh->root.get(), ray, cr, distance, hit, obj);
     } else {                                                            // acceleration_list.h:51-68
       float distance = FLT_MAX; hit = Hit(); obj = nullptr;
       for (const Object& o : objects) {
@@ -1012,10 +1199,13 @@ inline uint32_t Fnv32(uint32_t h, uint32_t v) { for (int k = 0; k < 4; k++) { h 
 struct DirStats { uint64_t rays = 0, above[6] = {0, 0, 0, 0, 0, 0}; double max_dev = 0; };
 DirStats* g_dir_stats = nullptr;
 
+// Sees every Scene::Cast of a traced path (oracle_collect_rays, oracle_classify_path); returning false abandons the path.
+struct CastObserver { virtual bool operator()(const Ray& ray, const Hit& hit, const Object* obj, uint32_t cast_number) = 0; virtual ~CastObserver() {} };
+
 // PathTracing::Thread::Render algorithm_pt.cc:125-160.  max_depth == 0 means RR-only (reference).
 PathResult TracePath(const oracle_scene& sc, const Sensor& S, uint64_t px, uint64_t py, Sampler& smp,
                      const Math& M, uint32_t max_depth, oracle_bounce* trace, uint32_t max_trace,
-                     float* eye_out) {
+                     float* eye_out, CastObserver* observer = nullptr) {
   const EyeRay eye = GenerateEyeRay(sc.lens, S, px, py, smp, M);
   if (eye_out) {
     eye_out[0] = eye.origin.x; eye_out[1] = eye.origin.y; eye_out[2] = eye.origin.z;
@@ -1036,6 +1226,7 @@ PathResult TracePath(const oracle_scene& sc, const Sensor& S, uint64_t px, uint6
     Hit hit; const Object* obj = nullptr;
     sc.Cast(ray, hit, obj);
     r.casts++;
+    if (observer && !(*observer)(ray, hit, obj, r.casts)) break;
     r.sig_obj = Fnv32(r.sig_obj, hit ? static_cast<uint32_t>(obj->index) : 0xffffffffu);
     if (hit) r.sig_t = Fnv32(r.sig_t, f2u(hit.t));
     if (!hit) {
@@ -1250,7 +1441,7 @@ void oracle_scene_get_lens(const oracle_scene* s, float origin[3], float global_
   *focus_distance = s->lens.focus_distance; *sensor_distance = s->lens.sensor_distance; *p_area = s->lens.p_area;
 }
 void oracle_scene_bvh_stats(const oracle_scene* s, uint32_t* n_nodes, uint32_t* n_leaves, uint32_t* max_depth) {
-  *n_nodes = s->bvh ? s->bvh->n_nodes : 0; *n_leaves = s->bvh ? s->bvh->n_leaves : 0; *max_depth = s->bvh ? s->bvh->max_depth : 0;
+  *n_nodes = s->bvh ? s->bvh->n_nodes.load() : 0u; *n_leaves = s->bvh ? s->bvh->n_leaves.load() : 0u; *max_depth = s->bvh ? s->bvh->max_depth.load() : 0u;
 }
 
 // PathTracing::Render (algorithm_pt.cc:82-95) through ParallelMean (rendering/parallel.h:57-68) with
@@ -1375,6 +1566,145 @@ int32_t oracle_cast(const oracle_scene* sc, const float origin[3], const float d
   sc->Cast(ray, hit, obj);
   *t = hit.t; pos[0] = hit.pos.x; pos[1] = hit.pos.y; pos[2] = hit.pos.z; normal[0] = hit.n.x; normal[1] = hit.n.y; normal[2] = hit.n.z;
   return hit ? static_cast<int32_t>(obj->index) : -1;
+}
+
+int oracle_scene_set_accel(oracle_scene* sc, int accel) {
+  if (accel == ORACLE_ACCEL_LIST) { sc->accel = accel; return 0; }
+  if (accel == ORACLE_ACCEL_BVH && sc->bvh) { sc->accel = accel; return 0; }
+  if (accel == ORACLE_ACCEL_BVH_CONS && sc->bvh && sc->bvh->has_cons) { sc->accel = accel; return 0; }
+  return -1;
+}
+
+namespace {
+// Eight spheres against one ray: bit k set unless the discriminant of sphere k is negative -- b, c and b*b - 4*a*c exactly as
+// IntersectSphere / SolveQuadratic form them (a = 1: 4*a*c is 4*c), one binary32 rounding per operation, no contraction.
+inline int SphereDiscriminantNotNegative8(const float* cx, const float* cy, const float* cz, const float* rad, __m256 ox, __m256 oy, __m256 oz,
+                                          __m256 dx, __m256 dy, __m256 dz) {
+  const __m256 x = _mm256_sub_ps(_mm256_loadu_ps(cx), ox), y = _mm256_sub_ps(_mm256_loadu_ps(cy), oy), z = _mm256_sub_ps(_mm256_loadu_ps(cz), oz);
+  const __m256 dot = _mm256_add_ps(_mm256_add_ps(_mm256_mul_ps(x, dx), _mm256_mul_ps(y, dy)), _mm256_mul_ps(z, dz));
+  const __m256 b = _mm256_mul_ps(_mm256_set1_ps(-2.0f), dot);
+  const __m256 sq = _mm256_add_ps(_mm256_add_ps(_mm256_mul_ps(x, x), _mm256_mul_ps(y, y)), _mm256_mul_ps(z, z));
+  const __m256 r = _mm256_loadu_ps(rad);
+  const __m256 c = _mm256_sub_ps(sq, _mm256_mul_ps(r, r));
+  const __m256 disc = _mm256_sub_ps(_mm256_mul_ps(b, b), _mm256_mul_ps(_mm256_set1_ps(4.0f), c));
+  return _mm256_movemask_ps(_mm256_cmp_ps(disc, _mm256_setzero_ps(), _CMP_NLT_UQ));   // !(disc < 0): NaN goes on, like "if (d < 0) return false"
+}
+}  // namespace
+
+void oracle_cast_many(const oracle_scene* sc, int accel, uint64_t n, const float* origins, const float* dirs, uint32_t n_threads,
+                      int32_t* object_out, float* t_out) {
+  if (n_threads == 0) n_threads = 1;
+  auto ray_of = [&](uint64_t i) { return Ray{v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2])}; };
+  const bool blocked = accel == ORACLE_ACCEL_LIST && sc->objects.size() >= 4096;
+  if (!blocked) {
+    auto work = [&](uint32_t tid) {
+      for (uint64_t i = tid; i < n; i += n_threads) {
+        Hit hit; const Object* obj = nullptr;
+        sc->CastWith(accel, ray_of(i), hit, obj);
+        object_out[i] = hit ? static_cast<int32_t>(obj->index) : -1; t_out[i] = hit.t;
+      }
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t t = 1; t < n_threads; t++) threads.emplace_back(work, t);
+    work(0);
+    for (auto& t : threads) t.join();
+    return;
+  }
+  // acceleration_list.h:51-68 over a large scene: blocks of objects (outer) against a thread's rays (inner).  Objects are met in
+  // insertion order by every ray, so "hit.t < distance" keeps the lowest index of a tie exactly as the scan does.
+  const std::vector<Object>& objs = sc->objects;
+  constexpr std::size_t kBlock = 2048;
+  auto work = [&](uint32_t tid) {
+    const uint64_t i0 = n * tid / n_threads, i1 = n * (tid + 1) / n_threads;
+    std::vector<float> dist(i1 - i0, FLT_MAX);
+    for (uint64_t i = i0; i < i1; i++) { object_out[i] = -1; t_out[i] = Hit().t; }
+    std::vector<float> cx(kBlock + 8), cy(kBlock + 8), cz(kBlock + 8), rad(kBlock + 8);
+    std::vector<uint32_t> sphere_at(kBlock + 8), other;
+    for (std::size_t b0 = 0; b0 < objs.size(); b0 += kBlock) {
+      const std::size_t b1 = std::min(objs.size(), b0 + kBlock);
+      std::size_t ns = 0; other.clear();
+      for (std::size_t k = b0; k < b1; k++) {
+        if (objs[k].kind == ORACLE_PRIM_SPHERE) { cx[ns] = objs[k].a.x; cy[ns] = objs[k].a.y; cz[ns] = objs[k].a.z; rad[ns] = objs[k].radius; sphere_at[ns++] = static_cast<uint32_t>(k); }
+        else other.push_back(static_cast<uint32_t>(k));
+      }
+      const std::size_t ns8 = (ns + 7) / 8 * 8;
+      for (std::size_t k = ns; k < ns8; k++) { cx[k] = cy[k] = cz[k] = 0; rad[k] = 0; sphere_at[k] = 0xffffffffu; }
+      std::vector<uint32_t> cand;
+      for (uint64_t i = i0; i < i1; i++) {
+        const Ray ray = ray_of(i);
+        cand = other;
+        const __m256 ox = _mm256_set1_ps(ray.o.x), oy = _mm256_set1_ps(ray.o.y), oz = _mm256_set1_ps(ray.o.z);
+        const __m256 dx = _mm256_set1_ps(ray.d.x), dy = _mm256_set1_ps(ray.d.y), dz = _mm256_set1_ps(ray.d.z);
+        for (std::size_t k = 0; k < ns8; k += 8) {
+          int m = SphereDiscriminantNotNegative8(&cx[k], &cy[k], &cz[k], &rad[k], ox, oy, oz, dx, dy, dz);
+          while (m) { const int j = __builtin_ctz(m); m &= m - 1; if (sphere_at[k + j] != 0xffffffffu) cand.push_back(sphere_at[k + j]); }
+        }
+        std::sort(cand.begin(), cand.end());                              // insertion order
+        float& distance = dist[i - i0];
+        for (uint32_t k : cand) {
+          const Hit h = Intersect(objs[k], ray);
+          if (h && h.t < distance) { distance = h.t; object_out[i] = static_cast<int32_t>(objs[k].index); t_out[i] = h.t; }
+        }
+      }
+    }
+  };
+  std::vector<std::thread> threads;
+  for (uint32_t t = 1; t < n_threads; t++) threads.emplace_back(work, t);
+  work(0);
+  for (auto& t : threads) t.join();
+}
+
+uint64_t oracle_collect_rays(const oracle_scene* sc, const oracle_sensor* sensor, uint64_t global_seed, uint32_t first_sample, uint32_t n_samples,
+                             uint32_t y0, uint32_t y1, int math, uint32_t max_depth, uint64_t max_rays, float* origins, float* dirs) {
+  const Sensor S{sensor->width, sensor->height, sensor->scene_width, sensor->scene_height};
+  const Math M{math};
+  struct Collect : CastObserver {
+    uint64_t n = 0, cap = 0; float* o = nullptr; float* d = nullptr;
+    bool operator()(const Ray& ray, const Hit&, const Object*, uint32_t) override {
+      if (n < cap) { o[3 * n] = ray.o.x; o[3 * n + 1] = ray.o.y; o[3 * n + 2] = ray.o.z; d[3 * n] = ray.d.x; d[3 * n + 1] = ray.d.y; d[3 * n + 2] = ray.d.z; }
+      n++; return true;
+    }
+  } collect;
+  collect.cap = max_rays; collect.o = origins; collect.d = dirs;
+  for (uint64_t y = y0; y < y1; y++)
+    for (uint64_t x = 0; x < S.w; x++)
+      for (uint32_t k = 0; k < n_samples; k++) {
+        XorShiftSampler smp(XorShiftSeed(global_seed, static_cast<uint32_t>(x + y * S.w), first_sample + k));
+        TracePath(*sc, S, x, y, smp, M, max_depth, nullptr, 0, nullptr, &collect);
+      }
+  return collect.n;
+}
+
+int oracle_classify_path(const oracle_scene* sc, const oracle_sensor* sensor, uint64_t global_seed, uint32_t px, uint32_t py, uint32_t sample,
+                         int math, uint32_t max_depth, int accel_a, int accel_b, uint32_t out[10]) {
+  const Sensor S{sensor->width, sensor->height, sensor->scene_width, sensor->scene_height};
+  const Math M{math};
+  struct Classify : CastObserver {
+    const oracle_scene* sc = nullptr; int b = 0; uint32_t* out = nullptr; bool found = false;
+    bool operator()(const Ray& ray, const Hit& ha, const Object* oa, uint32_t cast_number) override {
+      Hit hb; const Object* ob = nullptr;
+      sc->CastWith(b, ray, hb, ob);
+      const uint32_t ia = ha ? oa->index : 0xffffffffu, ib = hb ? ob->index : 0xffffffffu;
+      if (ia == ib && (!ha || f2u(ha.t) == f2u(hb.t))) return true;
+      Hit hl; const Object* ol = nullptr;
+      sc->CastWith(ORACLE_ACCEL_LIST, ray, hl, ol);
+      out[0] = cast_number; out[1] = ia; out[2] = ib; out[3] = hl ? ol->index : 0xffffffffu;
+      out[4] = f2u(ha.t); out[5] = f2u(hb.t); out[6] = f2u(hl.t);
+      float tin, tout;
+      out[7] = hl && SlabTest(BoundingBox(*ol), ray, FLT_MAX, tin, tout) ? 1u : 0u;
+      out[8] = (ha && hb && f2u(ha.t) == f2u(hb.t)) ? 1u : 0u;
+      out[9] = hl && SlabTest(BoundingBox(*ol), ray, hl.t, tin, tout) ? 1u : 0u;
+      found = true;
+      return false;
+    }
+  } classify;
+  classify.sc = sc; classify.b = accel_b; classify.out = out;
+  // TracePath casts through sc->accel: switched for the duration of this call (single-threaded tool, see the header)
+  XorShiftSampler smp(XorShiftSeed(global_seed, static_cast<uint32_t>(px + py * S.w), sample));
+  struct AccelGuard { oracle_scene* s; int old; ~AccelGuard() { s->accel = old; } } guard{const_cast<oracle_scene*>(sc), sc->accel};
+  const_cast<oracle_scene*>(sc)->accel = accel_a;
+  TracePath(*sc, S, px, py, smp, M, max_depth, nullptr, 0, nullptr, &classify);
+  return classify.found ? 1 : 0;
 }
 
 int oracle_intersect(const oracle_object* obj, const float origin[3], const float dir[3], float* t, float pos[3], float normal[3]) {

@@ -60,7 +60,14 @@ typedef struct {
 } oracle_sensor;
 
 /* modes */
-enum { ORACLE_ACCEL_BVH = 0, ORACLE_ACCEL_LIST = 1 };
+enum { ORACLE_ACCEL_BVH = 0, ORACLE_ACCEL_LIST = 1,
+       /* The List scan's answer (acceleration_list.h:51-68: the closest hit over ALL objects, the lower insertion index on a distance tie)
+        * computed through the reference's tree with conservative culling: boxes that contain every point at which the reference's
+        * binary32 primitive tests can accept a ray, and no order-dependent early exit (amber_oracle.cc, BVH::CastCons).  It exists because
+        * the reference's own two accelerations disagree on large scenes (its BVH loses grazing hits its List keeps) and the plain scan
+        * is O(n) per ray; tests/test_oracle_conservative_bvh.py proves it equal to the plain scan.  A scene created with this mode
+        * can be switched between all three (oracle_scene_set_accel). */
+       ORACLE_ACCEL_BVH_CONS = 2 };
 /* Phong rejection sampling (material_phong.cc:81-106) gives up re-sampling at this attempt; same constant on the device */
 #define ORACLE_PHONG_MAX_TRIES 1024
 /* OR into `accel` of oracle_scene_create: append the aperture blades AFTER the objects, the order cli::ImportScene
@@ -82,6 +89,9 @@ oracle_scene* oracle_scene_create(const oracle_object* objects, uint32_t n_objec
                                   const oracle_material* materials, uint32_t n_materials,
                                   const oracle_thin_lens* lens, int accel);
 void          oracle_scene_destroy(oracle_scene*);
+/* Switches the acceleration Scene::Cast uses: LIST always; BVH needs a scene created with BVH or BVH_CONS; BVH_CONS one created with
+ * BVH_CONS.  Returns 0, or -1 when the scene lacks what the mode needs.  Not thread-safe against running renders. */
+int           oracle_scene_set_accel(oracle_scene*, int accel);
 
 /* introspection (for cross-checking the product's own flattening) */
 uint32_t oracle_scene_object_count(const oracle_scene*);
@@ -145,6 +155,30 @@ uint32_t oracle_trace_path(const oracle_scene*, const oracle_sensor*, uint64_t g
 /* closest hit of one ray against the scene; returns object index or -1 */
 int32_t oracle_cast(const oracle_scene*, const float origin[3], const float dir[3],
                     float* t, float pos[3], float normal[3]);
+/* Closest hits of n rays (origins / dirs: 3 floats each) through acceleration `accel` of the scene (see oracle_scene_set_accel for
+ * what a scene can serve), on n_threads threads: object index (-1 = miss) and distance (NaN = miss).  ORACLE_ACCEL_LIST is the plain
+ * scan of acceleration_list.h:51-68 over every object; for scenes of many spheres it runs blocked (objects outer, rays inner) with
+ * the sign of the discriminant -- SolveQuadratic's first exit, algebra.h:33-34, same binary32 operations -- evaluated eight spheres
+ * at a time, and Intersect() called for the survivors: the same function of the ray, 1e11 pairs in seconds. */
+void oracle_cast_many(const oracle_scene*, int accel, uint64_t n, const float* origins, const float* dirs, uint32_t n_threads,
+                      int32_t* object_out, float* t_out);
+/* The rays Scene::Cast is called with while rows [y0, y1), samples [first_sample, first_sample + n_samples) are rendered in XorShift
+ * mode (every bounce of every path, in path order): at most max_rays are stored; returns the number cast. */
+uint64_t oracle_collect_rays(const oracle_scene*, const oracle_sensor*, uint64_t global_seed, uint32_t first_sample, uint32_t n_samples,
+                             uint32_t y0, uint32_t y1, int math, uint32_t max_depth, uint64_t max_rays, float* origins, float* dirs);
+/* Why two accelerations of one scene disagree on a path (scene created with ORACLE_ACCEL_BVH_CONS).  Traces path (px, py, sample)
+ * with acceleration accel_a; at every cast also asks accel_b.  At the FIRST cast on which the two differ (object or distance bits)
+ * it fills `out` and stops:
+ *   out[0] cast number (1-based), out[1] object of a, out[2] object of b, out[3] object of the plain List scan over all objects,
+ *   out[4] bits of a's distance, out[5] bits of b's distance, out[6] bits of List's distance,
+ *   out[7] 1 if the ray passes the reference's slab test (aabb.cc:28-62, t_max = FLT_MAX) on the GEOMETRIC box (Primitive::BoundingBox) of List's object, else 0,
+ *   out[8] 1 if a's and b's distances are equal bit for bit (an exact tie between two objects), else 0,
+ *   out[9] the same slab test limited to List's hit distance (t_max = that distance): 0 means the accepted hit lies IN FRONT OF the point
+ *          where the ray enters the object's geometric box -- a BVH that searches a far child only up to the nearer hit, or returns the
+ *          near child's hit when it lies before the far child's box (acceleration_bvh.h:386-391), cannot find it.
+ * Returns 1 if a difference was found, 0 if the whole path agrees. */
+int oracle_classify_path(const oracle_scene*, const oracle_sensor*, uint64_t global_seed, uint32_t px, uint32_t py, uint32_t sample,
+                         int math, uint32_t max_depth, int accel_a, int accel_b, uint32_t out[10]);
 /* single-primitive intersection (Primitive::Intersect); returns 1 on finite hit */
 int oracle_intersect(const oracle_object* obj, const float origin[3], const float dir[3],
                      float* t, float pos[3], float normal[3]);

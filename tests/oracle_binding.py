@@ -13,7 +13,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 LIB = ROOT / "oracle" / "liboracle.so"
 
-ACCEL_BVH, ACCEL_LIST = 0, 1
+ACCEL_BVH, ACCEL_LIST, ACCEL_BVH_CONS = 0, 1, 2   # BVH_CONS: List's answer through the reference's tree (amber_oracle.h)
 BLADES_LAST = 0x100          # ORACLE_BLADES_LAST: aperture blades after the objects (cli::ImportScene order)
 ACCUM_CHUNK = 8    # include/amber_hip.h AMBER_ACCUM_CHUNK
 MATH_LIBM, MATH_PORTABLE, MATH_GLIBC = 0, 1, 2
@@ -74,6 +74,11 @@ def load():
     L.oracle_scene_create.restype = vp
     L.oracle_scene_create.argtypes = [C.POINTER(OObject), u32, C.POINTER(OMaterial), u32, C.POINTER(OThinLens), C.c_int]
     L.oracle_scene_destroy.argtypes = [vp]
+    L.oracle_scene_set_accel.argtypes = [vp, C.c_int]
+    L.oracle_cast_many.argtypes = [vp, C.c_int, u64, vp, vp, u32, vp, vp]
+    L.oracle_collect_rays.restype = u64
+    L.oracle_collect_rays.argtypes = [vp, C.POINTER(OSensor), u64, u32, u32, u32, u32, C.c_int, u32, u64, vp, vp]
+    L.oracle_classify_path.argtypes = [vp, C.POINTER(OSensor), u64, u32, u32, u32, C.c_int, u32, C.c_int, C.c_int, C.POINTER(u32)]
     L.oracle_scene_object_count.argtypes = [vp]
     L.oracle_scene_object_count.restype = u32
     L.oracle_scene_material_count.argtypes = [vp]
@@ -215,6 +220,39 @@ class Scene:
         eye = (C.c_float * 7)()
         n = self.L.oracle_trace_path(self.h, C.byref(s), seed, px, py, sample, _m(math), max_depth, rec, max_bounces, eye)
         return n, rec, np.array(eye[:], np.float32)
+
+    def set_accel(self, accel):
+        """Switch the acceleration Scene::Cast uses (oracle_scene_set_accel); raises when the scene was not created for it."""
+        if self.L.oracle_scene_set_accel(self.h, accel) != 0:
+            raise ValueError(f"this oracle scene cannot serve acceleration {accel}")
+        return self
+
+    def cast_many(self, origins, dirs, accel, threads=8):
+        """Closest hits of n rays through `accel`: (object index int32, -1 = miss; distance float32, NaN = miss)."""
+        o, d = np.ascontiguousarray(origins, np.float32), np.ascontiguousarray(dirs, np.float32)
+        n = len(o)
+        idx, t = np.empty(n, np.int32), np.empty(n, np.float32)
+        self.L.oracle_cast_many(self.h, accel, n, o.ctypes.data, d.ctypes.data, threads, idx.ctypes.data, t.ctypes.data)
+        return idx, t
+
+    def collect_rays(self, w, h, seed, first, n, rows, max_rays, math=None, max_depth=0):
+        """The rays cast while rows x samples are rendered (every bounce, path order): (origins, dirs), at most max_rays."""
+        s = sensor(w, h)
+        o, d = np.zeros((max_rays, 3), np.float32), np.zeros((max_rays, 3), np.float32)
+        k = self.L.oracle_collect_rays(self.h, C.byref(s), seed, first, n, rows[0], rows[1], _m(math), max_depth, max_rays, o.ctypes.data, d.ctypes.data)
+        k = min(int(k), max_rays)
+        return o[:k], d[:k]
+
+    def classify_path(self, w, h, seed, px, py, sample, accel_a, accel_b, math=None, max_depth=0):
+        """oracle_classify_path: None if the two accelerations agree on the whole path, else a dict describing the first cast they differ on."""
+        s = sensor(w, h)
+        out = (C.c_uint32 * 10)()
+        if not self.L.oracle_classify_path(self.h, C.byref(s), seed, px, py, sample, _m(math), max_depth, accel_a, accel_b, out):
+            return None
+        f = lambda b: float(np.array([b], np.uint32).view(np.float32)[0])
+        i = lambda v: -1 if v == 0xffffffff else int(v)
+        return dict(cast=int(out[0]), object_a=i(out[1]), object_b=i(out[2]), object_list=i(out[3]), t_a=f(out[4]), t_b=f(out[5]), t_list=f(out[6]),
+                    t_bits=(int(out[4]), int(out[5]), int(out[6])), list_object_box_hit=bool(out[7]), exact_tie=bool(out[8]), list_hit_inside_box=bool(out[9]))
 
     def cast(self, o, d):
         t = C.c_float()

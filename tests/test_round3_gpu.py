@@ -61,20 +61,7 @@ def test_product_kernel_signatures_against_the_oracle(amber, cornell):
         pt = amber.PathTracer(hm, amber.Sensor.default(40, 40), seed=21, flags=flags)
         assert np.array_equal(pt.render_signatures(0, 24), sm), flags
         pt.close()
-    # BASELINE config 3's own scene: the kernel that renders it (pt_bvh_megakernel) against the per-thread known-answer kernel on every
-    # path of a band of the real frame, and against the oracle's reference BVH on the paths without an exact distance tie
-    hb = amber.HostScene.create_arrays(**scenes.random_spheres(1_000_000, 7))
-    ob = O.Scene.create_arrays(**scenes.random_spheres(1_000_000, 7), accel=O.ACCEL_BVH) if hasattr(O.Scene, "create_arrays") else None
-    pt = amber.PathTracer(hb, amber.Sensor.default(1920, 1080), seed=1, rows=(536, 540))
-    sg = pt.render_signatures(0, 16)
-    assert np.array_equal(sg, pt.kat_signatures(0, 16))
-    assert len(np.unique(sg & np.uint64(0xffffffff))) > 1000           # thousands of different hit sequences
-    if ob is not None:
-        so3 = ob.path_signatures(1920, 1080, 1, 0, 16, (536, 540), threads=16)
-        # 8 of the 122 880 paths differ: the reference's binary32 sphere test accepts rays that miss the sphere's GEOMETRIC box; its BVH
-        # loses those hits, its List -- the semantics the engine implements -- keeps them
-        assert (sg != so3).sum() <= 16
-    pt.close()
+    # BASELINE config 3's own scene and kernel: tests/test_config3_parity_gpu.py (against an oracle with List semantics at BVH speed)
 
 
 def test_config2_whole_frame_at_64spp_against_the_oracle(amber, cornell):

@@ -1,7 +1,10 @@
-"""BASELINE config 3 at FULL size (1M spheres, 1920x1080 @ 256 spp, 1.37e9 rays) against the oracle's restatement of the REFERENCE BVH
-(the List scan the engine's semantics follow is O(n) per ray: not possible at this size).  Expected: identical except on the paths where
-the reference's binary32 sphere test accepts a ray that misses the sphere's geometric box -- hits its BVH loses and its List keeps
-(DESIGN.md section 5).   python tools/config3_full_parity.py [spp]"""
+"""BASELINE config 3 at FULL size (1M spheres, 1920x1080 @ 256 spp, 1.37e9 rays): the three steps of tests/test_config3_parity_gpu.py on
+the whole frame.
+  (i)   GPU == oracle(List semantics through the conservative BVH, live libm): image bits and ray count;
+  (ii)  the pixels on which the GPU differs from oracle(REFERENCE BVH) == the pixels on which the oracle's two accelerations differ;
+  (iii) every such pixel attributed to a path whose first differing cast is either a hit the reference's BVH loses because the ray misses
+        the sphere's geometric box (its List, like the engine, keeps it) or an exact distance tie.
+python tools/config3_full_parity.py [spp]     (about two minutes of oracle time on 16 host threads)"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
@@ -10,15 +13,39 @@ import oracle_binding as O
 from amber_amd import scenes
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 W, H, seed = 1920, 1080, 1
+threads = min(16, os.cpu_count() or 1)
 kw = scenes.random_spheres(1_000_000, 7)
 pt = A.PathTracer(A.HostScene.create_arrays(**kw), A.Sensor.default(W, H), seed=seed)
 pt.render_pass(0, spp); img, rays = pt.download()
 print("GPU (engine BVH, List semantics): %d rays" % rays, flush=True)
-t = time.time(); osc = O.Scene.create_arrays(**kw, accel=O.ACCEL_BVH); tb = time.time() - t
-t = time.time(); ref, cnt = osc.render_xorshift(W, H, seed, 0, spp, math=O.MATH_LIBM, threads=min(16, os.cpu_count() or 1)); dt = time.time() - t
-diff = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=2)
-err = np.sqrt(((img.astype(np.float64) - ref) ** 2).sum(axis=2)); mag = np.sqrt((ref.astype(np.float64) ** 2).sum(axis=2))
-rel = np.where(mag > 0, err / np.where(mag > 0, mag, 1), 0)
-print("oracle(XorShift, reference BVH, live libm): build %.1f s, %d rays in %.1f s (%.1f Mrays/s)" % (tb, cnt.casts, dt, cnt.casts / dt / 1e6))
-print("pixels differing %d of %d (%.2e); over the 1e-4 relative-L2 tolerance %d; ray count delta %d (%.1e of the rays); lit pixels %d"
-      % (int(diff.sum()), W * H, diff.mean(), int((rel > 1e-4).sum()), int(rays) - int(cnt.casts), abs(int(rays) - int(cnt.casts)) / rays, int((ref > 0).any(axis=2).sum())))
+t = time.time(); osc = O.Scene.create_arrays(**kw, accel=O.ACCEL_BVH_CONS); tb = time.time() - t
+bits = lambda a: a.view(np.uint32)
+res = {}
+for name, accel in (("List via the conservative BVH", O.ACCEL_BVH_CONS), ("reference BVH", O.ACCEL_BVH)):
+    t = time.time(); ref, cnt = osc.set_accel(accel).render_xorshift(W, H, seed, 0, spp, math=O.MATH_LIBM, threads=threads); dt = time.time() - t
+    res[accel] = (ref, cnt.casts)
+    diff = (bits(img) != bits(ref)).any(axis=2)
+    err = np.sqrt(((img.astype(np.float64) - ref) ** 2).sum(axis=2)); mag = np.sqrt((ref.astype(np.float64) ** 2).sum(axis=2))
+    rel = np.where(mag > 0, err / np.where(mag > 0, mag, 1), 0)
+    print("oracle(XorShift, %s, live libm): tree %.1f s, %d rays in %.1f s (%.1f Mrays/s)" % (name, tb, cnt.casts, dt, cnt.casts / dt / 1e6))
+    print("  GPU vs this: pixels differing %d of %d (%.2e); over the 1e-4 relative-L2 tolerance %d; ray count delta %+d; lit pixels %d"
+          % (int(diff.sum()), W * H, diff.mean(), int((rel > 1e-4).sum()), int(rays) - int(cnt.casts), int((ref > 0).any(axis=2).sum())), flush=True)
+cons, refb = res[O.ACCEL_BVH_CONS][0], res[O.ACCEL_BVH][0]
+gpu_vs_ref = (bits(img) != bits(refb)).any(axis=2); cons_vs_ref = (bits(cons) != bits(refb)).any(axis=2)
+print("(ii) set of pixels GPU != reference BVH equals set of pixels List != reference BVH:", bool(np.array_equal(gpu_vs_ref, cons_vs_ref)))
+from test_config3_parity_gpu import classify_pixels
+pixels = list(zip(*np.nonzero(gpu_vs_ref)))
+t = time.time(); causes = classify_pixels(osc, pixels, spp=spp, seed=seed); dt = time.time() - t
+tally = {}
+unattributed = 0
+for px, found in causes.items():
+    if not found: unattributed += 1
+    for c in found: tally[c["cause"]] = tally.get(c["cause"], 0) + 1
+print("(iii) %d differing pixels classified in %.1f s: %d without a differing path; first differing casts by cause:" % (len(pixels), dt, unattributed))
+for k, v in sorted(tally.items()): print("      %5d  %s" % (v, k))
+for px, found in list(causes.items())[:12]:
+    for c in found:
+        print("      pixel (y %4d, x %4d) sample %3d cast %d: List object %7d t %.9g | reference BVH object %7d t %.9g | %s"
+              % (px[0], px[1], c["sample"], c["cast"], c["object_list"], c["t_list"], c["object_b"], c["t_b"], c["cause"]))
+ok = int((bits(img) != bits(cons)).any(axis=2).sum()) == 0 and rays == res[O.ACCEL_BVH_CONS][1] and np.array_equal(gpu_vs_ref, cons_vs_ref) and unattributed == 0 and "unexplained" not in tally
+print("RESULT:", "every difference from the reference's BVH is the reference's own List/BVH disagreement" if ok else "NOT fully attributed")
