@@ -78,7 +78,7 @@ ABI_SYMBOLS = [
     "amber_hip_pt_create", "amber_hip_pt_render_pass", "amber_hip_pt_clear", "amber_hip_pt_sync",
     "amber_hip_pt_download", "amber_hip_pt_device_framebuffer", "amber_hip_pt_stream", "amber_hip_pt_local_rows", "amber_hip_pt_kernel_time", "amber_hip_pt_destroy",
     "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_math_mode", "amber_hip_device_count", "amber_hip_lt_trace", "amber_hip_lt_trace_range",
-    "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math", "amber_hip_kat_signatures", "amber_hip_pt_signatures", "amber_hip_kat_traversal_rate",
+    "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math", "amber_hip_kat_signatures", "amber_hip_pt_signatures", "amber_hip_kat_traversal_rate", "amber_hip_kat_pixel_masks",
     "amber_host_cornell_box", "amber_host_scene_import", "amber_host_scene_create", "amber_host_scene_destroy", "amber_host_scene_flatten",
     "amber_host_pt_create", "amber_host_render", "amber_host_render_devices", "amber_host_last_error", "amber_host_tonemap", "amber_host_export",
 ]
@@ -131,6 +131,7 @@ def load_library() -> C.CDLL:
     lib.amber_hip_kat_trace.argtypes = [vp, u32, vp, vp, u32, vp, vp]
     lib.amber_hip_kat_math.argtypes = [i32, i32, u32, vp, vp]
     lib.amber_hip_kat_signatures.argtypes = [vp, u32, u32, vp]
+    lib.amber_hip_kat_pixel_masks.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     if hasattr(lib, "amber_hip_kat_traversal_rate"):
         lib.amber_hip_kat_traversal_rate.argtypes = [vp, u32, vp, vp, u32, u32, u32, vp, vp, C.POINTER(C.c_double), vp]
     if hasattr(lib, "amber_hip_pt_signatures"):    # absent only in older builds loaded by tools/ab_lib.py
@@ -388,6 +389,22 @@ class PathTracer:
         out = np.zeros((rows, width, n_samples), np.uint64)
         _check(load_library().amber_hip_kat_signatures(self._h, first_sample, n_samples, out.ctypes.data))
         return out
+
+    def pixel_masks(self):
+        """(masks (rows, width) uint32, slot of every scene object (n_objects,) uint32, ms of the mask kernel or -1 if it had run before)."""
+        rows, width, _ = self.band_shape
+        masks = np.zeros((rows, width), np.uint32)
+        ms = C.c_double()
+        _check(load_library().amber_hip_kat_pixel_masks(self._h, masks.ctypes.data, None, None, C.byref(ms)))
+        return masks, ms.value
+
+    def object_slots(self, n_objects: int) -> np.ndarray:
+        """Filter-program slot (mask bit) of every scene object; 0xffffffff = none."""
+        slots = np.zeros(n_objects, np.uint32)
+        always = C.c_uint32()
+        _check(load_library().amber_hip_kat_pixel_masks(self._h, None, slots.ctypes.data, C.byref(always), None))
+        self.always_mask = always.value          # slots that are candidates of every ray (no filter record; aperture blades)
+        return slots
 
     def render_signatures(self, first_sample: int, n_samples: int) -> np.ndarray:
         """kat_signatures' layout and meaning, produced by the PRODUCT render kernel (its signature instantiation)."""

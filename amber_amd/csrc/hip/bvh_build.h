@@ -263,6 +263,17 @@ inline uint16_t F16Nearest(double u) {                        // some normal-or-
   if (m < 0) m = 0; if (m > 1023) m = 1023;
   return static_cast<uint16_t>((neg ? 0x8000u : 0u) | (uint32_t(e + 14) << 10) | uint32_t(m));
 }
+// Centre and half extent of the binary16 grid of one axis whose node boxes span [lo, hi]: |plane - mid| <= half for every plane.
+// A scene with NO extent on the axis (a planar mesh in x = 1234.5) gets half = 2^-20 |mid|, not a denormal-sized step: with a step
+// far below the rounding of mid, PlaneWord's search for a representable value beyond its guard walked all 30 000 binary16
+// values per plane (a millisecond per node) and ended at +-65504, outside the |value| <= 1 + one step that `reach` promises.
+inline void F16AxisGrid(double lo, double hi, float& mid, float& half) {
+  mid = static_cast<float>(0.5 * (lo + hi));
+  half = static_cast<float>(std::max(hi - double(mid), double(mid) - lo) * 1.000001);
+  const float floor_half = std::max(1e-30f, std::fabs(mid) * 9.5367431640625e-07f);        // 2^-20 |mid|: 16 binary32 ulps of the coordinate
+  if (!(half > floor_half)) half = floor_half;
+  while (!(double(mid) + double(half) >= hi && double(mid) - double(half) <= lo)) half = std::nextafter(half, 3.0e38f);
+}
 // The word of one axis of a box: value(min) | value(max) << 16 with  gmin + value(min) * step <= mn  and  gmin + value(max) * step >= mx,
 // checked in extended precision with a guard of 2^-50 of the operands' magnitude (one representable value further out when in doubt).
 inline uint32_t PlaneWord(float mn, float mx, float gmin, float step) {
@@ -319,10 +330,8 @@ inline QuantizedBvh QuantizeBvh(const std::vector<DevBvhNode>& bin, int32_t root
     }
   for (int c = 0; c < 3; c++) {
 #if AMBER_BVH_F16
-    const float mid = static_cast<float>(0.5 * (lo[c] + hi[c]));
-    float half = static_cast<float>(std::max(hi[c] - double(mid), double(mid) - lo[c]) * 1.000001);
-    while (!(double(mid) + double(half) >= hi[c] && double(mid) - double(half) <= lo[c])) half = std::nextafter(half, 3.0e38f);
-    if (!(half > 0.0f)) half = 1e-30f;
+    float mid, half;
+    F16AxisGrid(lo[c], hi[c], mid, half);
     out.gmin[c] = mid; out.step[c] = half;
     out.reach[c] = static_cast<float>(double(half) * 1.002);                                // |value| <= 1 + one binary16 step
 #else

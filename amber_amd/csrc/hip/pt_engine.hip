@@ -80,6 +80,7 @@ struct RenderArgs {
   uint32_t first_sample, n_samples;
   uint32_t n_chunks, n_items;   // pt_bvh_megakernel: items = (pixel, chunk); path-granular kernels: n_items = paths of the launch
   uint32_t path_offset;      // light tracing: index of the first light path of this launch's range (amber_hip_lt_trace_range)
+  uint32_t claim_shift;      // pt_megakernel: log2 of the grid's wave count rounded up to a power of two (tapered claims)
 };
 
 // FNV-1a-32 step over the four bytes of v (path signatures: amber_hip_kat_signatures, amber_hip_pt_signatures)
@@ -161,6 +162,21 @@ __device__ __forceinline__ void CloseRecords(const RenderArgs& a, uint32_t rec_n
 #ifndef AMBER_CLAIM_PATHS
 #define AMBER_CLAIM_PATHS 1024u
 #endif
+// Tapered claims (round 4).  The last claims of a launch decide when it ends: a wave that takes 1024 paths just before the queue runs dry
+// works on them for ~0.3 ms while the waves that found it empty drain and leave (tools/launch_tail_floor.py: even with paths capped at
+// TWO bounces a launch has 0.26 ms of fixed time).  A wave therefore sizes its claim from what was left when it LAST looked -- the value
+// its previous atomicAdd returned, no extra access to the hot word --: left / (waves of the grid, rounded up to a power of two), in
+// whole primary rounds, between AMBER_CLAIM_MIN and AMBER_CLAIM_PATHS.  Claims shrink over the last ~2 % of a config-2 launch (the
+// last ~9 % of one rank's share on 8 GPUs); a launch too small to feed every wave (the one-chunk probe, tests) starts with small claims.
+#ifndef AMBER_CLAIM_MIN
+#define AMBER_CLAIM_MIN 128u
+#endif
+// MEASURED NEUTRAL, hence off (profiles/r04_launch_tail.txt: fixed part of a launch 0.614 ms without, 0.600 ms with; 1024 spp 52.64 / 52.83 ms):
+// what a launch waits for at its end is not the last claim but the LONGEST PATH still in flight (total-internal-reflection chains of
+// 100+ bounces), whose bounces are sequential.  Kept as a build option next to its measurement.
+#ifndef AMBER_CLAIM_TAPER
+#define AMBER_CLAIM_TAPER 0
+#endif
 // Pool slot: the whole state of a path between two bounces in four 16-byte chunks {o.xyz d.x} {d.yz w.xy} {w.z rng q}
 // {casts | carried-flag, origin slot, signature hashes}.
 template <bool kLight> struct PoolLayout { static constexpr int kChunks = 4; };
@@ -178,6 +194,7 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
   uint4* pool = lds_pool[wave_in_block];
 
   uint32_t claim_next = 0, claim_end = 0;    // wave-uniform: paths claimed from the global queue, not yet generated
+  uint32_t claim_seen = 0;                   // wave-uniform: queue head after this wave's previous claim (a stale lower bound of the head)
   uint32_t pool_count = 0;                   // wave-uniform: rays in the pool (slots [0, pool_count))
   uint32_t rec_next = 0, rec_end = 0;        // wave-uniform: the wave's open block of record slots
   bool exhausted = false;                    // wave-uniform: the global queue is empty
@@ -245,11 +262,22 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
         // (first hits, materials) at full width; the parked rays go to whichever lanes lose their path afterwards.
         AMBER_STAMP(0);
         if (claim_next == claim_end) {                        // claim the next block of paths from the global queue
+          uint32_t size = AMBER_CLAIM_PATHS;
+#if AMBER_CLAIM_TAPER
+          {
+            const uint32_t left = a.n_items > claim_seen ? a.n_items - claim_seen : 0u;
+            uint32_t want = (left >> a.claim_shift) & ~63u;                // per wave of the grid, whole primary rounds
+            if (want < AMBER_CLAIM_MIN) want = AMBER_CLAIM_MIN;
+            if (want < size) size = want;
+          }
+#endif
           uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(a.next_item, AMBER_CLAIM_PATHS);
+          if (lane == 0) base = atomicAdd(a.next_item, size);
           base = __builtin_amdgcn_readfirstlane(base);
+          claim_seen = base + size;                                        // (wraps only past 2^32 paths: launches are capped at 2^30)
+          (void)claim_seen;
           if (base >= a.n_items) exhausted = true;
-          else { claim_next = base; claim_end = a.n_items - base < AMBER_CLAIM_PATHS ? a.n_items : base + AMBER_CLAIM_PATHS; }
+          else { claim_next = base; claim_end = a.n_items - base < size ? a.n_items : base + size; }
 #ifdef AMBER_STAMPS
           if (wave_times && lane == 0) { if (exhausted) wave_times[2] = wall_clock64(); else if (wave_times[1] == 0) wave_times[1] = wall_clock64(); }
 #endif
@@ -504,12 +532,30 @@ __global__ void reduce_flagged_kernel(float* __restrict__ fb, uint32_t* __restri
 //    per ray where the path starts.
 // Double precision throughout; one thread per band pixel, once per handle (the mask depends on scene and sensor only).
 struct PixelMaskArgs {
-  float ap[4][3];                 // world corners of the aperture's bounding rectangle in the lens plane (inflated); pinhole: the origin
+  double ap[4][3];                // corners of the aperture's bounding rectangle in the lens plane (inflated), RELATIVE TO THE FILTER CENTRE; pinhole: the origin
+  double inv_w, inv_h;            // 1 / sensor width, height (pixels)
+  double focal_scale;             // thin lens: -focus_distance / sensor_distance; pinhole: -(8 reach + 1) / sensor_distance (a point far along the ray)
   uint32_t row_begin, stripe_rows, stripe_period, n_pixels;
 };
-__global__ void pixel_mask_kernel(const DevScene sc, const PixelMaskArgs pm, uint32_t* __restrict__ out) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= pm.n_pixels) return;
+// SIXTEEN LANES PER PIXEL, lane k = corner ray a_(k >> 2) -> f_(k & 3) (round 4).  Round 3's kernel ran one thread per pixel with the 16
+// directions and the 16 plane points in per-thread arrays: 128 VGPRs, 1 728 B of scratch, 3.7 ms per config-2 handle -- more than the first
+// 64 samples per pixel of the render it prepares.  Here a lane keeps ITS ray (3 + 3 doubles); "on all 16 corner rays" is a vote
+// (__ballot, masked to the pixel's 16 lanes), the maxima a plane needs are butterfly reductions over the 16 lanes, the aperture
+// corners are wave-uniform kernel arguments (SGPRs), and a lane forms only its own corner of F.  Same tests as before with two
+// differences, both towards keeping a candidate: a NaN coordinate keeps its triangle (fmax used to skip it), and the gradient norms
+// of a record's affine rows are bounded by their 1-norms (no square roots).
+__device__ __forceinline__ double Max16(double x) {               // maximum over the 16 lanes of a pixel (lanes 16 g .. 16 g + 15)
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) x = fmax(x, __shfl_xor(x, m, 16));
+  return x;
+}
+__global__ void __launch_bounds__(256) pixel_mask_kernel(const DevScene sc, const PixelMaskArgs pm, uint32_t* __restrict__ out) {
+  const uint32_t p_raw = blockIdx.x * 16u + (threadIdx.x >> 4), k = threadIdx.x & 15u;     // 16 pixels per workgroup of 256
+  const bool live = p_raw < pm.n_pixels;
+  const uint32_t p = live ? p_raw : pm.n_pixels - 1u;              // whole groups of 16 lanes stay active (votes, shuffles); only `live` groups store
+  const uint32_t shift = threadIdx.x & 48u;                        // position of the pixel's 16 lanes in the wave's 64-bit votes
+  auto all16 = [&](bool c) { return ((__ballot(c) >> shift) & 0xffffull) == 0xffffull; };
+  auto any16 = [&](bool c) { return ((__ballot(c) >> shift) & 0xffffull) != 0ull; };
   const uint32_t lrow = p / sc.sensor.w, px = p - lrow * sc.sensor.w;
   const uint32_t py = pm.row_begin + (pm.stripe_rows ? (lrow / pm.stripe_rows) * pm.stripe_period + lrow % pm.stripe_rows : lrow);
   const DevLens& L = *sc.lens;
@@ -521,106 +567,92 @@ __global__ void pixel_mask_kernel(const DevScene sc, const PixelMaskArgs pm, uin
   // the ideal one.  The same amount widens A (host) and F (below).
   const double world_mag = fmax(fmax(fabs(cx), fmax(fabs(cy), fabs(cz))) + reach, fmax(fabs(double(L.origin[0])), fmax(fabs(double(L.origin[1])), fabs(double(L.origin[2])))));
   const double slack = 1e-5 * reach + 32.0 * 5.9604644775390625e-08 * world_mag;
-  double A[4][3], F[4][3];
-  for (int i = 0; i < 4; i++) { A[i][0] = pm.ap[i][0] - cx; A[i][1] = pm.ap[i][1] - cy; A[i][2] = pm.ap[i][2] - cz; }
-  for (int j = 0; j < 4; j++) {
-    const double ux = (static_cast<double>(px) + ((j & 1) ? 1.02 : -0.02)) / static_cast<double>(sc.sensor.wf);
-    const double uy = (static_cast<double>(py) + ((j & 2) ? 1.02 : -0.02)) / static_cast<double>(sc.sensor.hf);
+  // this lane's corner ray: from a_ = A[k >> 2] towards fk = F[k & 3], the corner (k & 1, k & 2) of the pixel's image on the focal plane
+  const uint32_t ki = k >> 2, kj = k & 3u;
+  double a_[3], fk[3];
+  for (int c = 0; c < 3; c++) a_[c] = ki == 0u ? pm.ap[0][c] : (ki == 1u ? pm.ap[1][c] : (ki == 2u ? pm.ap[2][c] : pm.ap[3][c]));
+  {
+    // (an IEEE binary64 division is 64 SIMD cycles on gfx950: the wave-uniform quotients are kernel arguments)
+    const double ux = (static_cast<double>(px) + ((kj & 1u) ? 1.02 : -0.02)) * pm.inv_w;
+    const double uy = (static_cast<double>(py) + ((kj & 2u) ? 1.02 : -0.02)) * pm.inv_h;
     const double sx = (ux - 0.5) * sc.sensor.sw, sy = (uy - 0.5) * sc.sensor.sh, sz = L.sensor_distance;
     // thin lens: the point of the focal plane all rays of this sensor point pass through; pinhole: a point far along the ray
-    const double k = L.kind == 1u ? -(8.0 * reach + 1.0) / sz : static_cast<double>(L.focus_distance) / -static_cast<double>(L.sensor_distance);
-    const double fl[3] = {k * sx + ((k * ((j & 1) ? 1.0 : -1.0) >= 0) ? slack : -slack), k * sy + ((k * ((j & 2) ? 1.0 : -1.0) >= 0) ? slack : -slack), k * sz};   // outwards by the slack
-    for (int c = 0; c < 3; c++) F[j][c] = L.origin[c] + L.global_[3 * c] * fl[0] + L.global_[3 * c + 1] * fl[1] + L.global_[3 * c + 2] * fl[2];
-    F[j][0] -= cx; F[j][1] -= cy; F[j][2] -= cz;
+    const double kk = pm.focal_scale;
+    const double fl[3] = {kk * sx + ((kk * ((kj & 1u) ? 1.0 : -1.0) >= 0) ? slack : -slack), kk * sy + ((kk * ((kj & 2u) ? 1.0 : -1.0) >= 0) ? slack : -slack), kk * sz};   // outwards by the slack
+    for (int c = 0; c < 3; c++) fk[c] = L.origin[c] + L.global_[3 * c] * fl[0] + L.global_[3 * c + 1] * fl[1] + L.global_[3 * c + 2] * fl[2];
+    fk[0] -= cx; fk[1] -= cy; fk[2] -= cz;
   }
-  double D[16][3];                                                      // corner-ray directions (unit)
-  for (int i = 0; i < 4; i++)
-    for (int j = 0; j < 4; j++) {
-      const double v[3] = {F[j][0] - A[i][0], F[j][1] - A[i][1], F[j][2] - A[i][2]};
-      const double l = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-      for (int c = 0; c < 3; c++) D[4 * i + j][c] = v[c] / l;
-    }
+  double Dk[3];
+  {
+    const double v[3] = {fk[0] - a_[0], fk[1] - a_[1], fk[2] - a_[2]};
+    const double inv_l = 1.0 / sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    for (int c = 0; c < 3; c++) Dk[c] = v[c] * inv_l;                  // unit up to two roundings: far inside every tolerance below
+  }
   uint32_t mask = 0u, bit = 1u;
   const DevPlane* pl = sc.planes;
   const DevTriFilter* tr = sc.tri_filters;
   for (uint32_t pi = 0; pi < sc.n_planes; ++pi, ++pl) {
     const double n[3] = {pl->n[0], pl->n[1], pl->n[2]}, d0 = pl->d0;
     const uint32_t nt = pl->n_tris & 0x7fffffffu, np = pl->n_pairs;
-    // does the plane cut A or F?  (all corners strictly on one side, with the slack)
+    // does the plane cut A or F?  (all corners strictly on one side, with the slack; the lanes of a pixel hold every corner of both)
     bool all = false;
     {
-      double lo = 1e300, hi = -1e300;
-      for (int j = 0; j < 4; j++) { const double sgn = n[0] * F[j][0] + n[1] * F[j][1] + n[2] * F[j][2] - d0; lo = fmin(lo, sgn); hi = fmax(hi, sgn); }
-      if (!(lo > 10.0 * slack || hi < -10.0 * slack)) all = true;
-      lo = 1e300; hi = -1e300;
-      for (int i = 0; i < 4; i++) { const double sgn = n[0] * A[i][0] + n[1] * A[i][1] + n[2] * A[i][2] - d0; lo = fmin(lo, sgn); hi = fmax(hi, sgn); }
-      if (!(lo > 10.0 * slack || hi < -10.0 * slack)) all = true;
+      const double sf = n[0] * fk[0] + n[1] * fk[1] + n[2] * fk[2] - d0;
+      if (!(all16(sf > 10.0 * slack) || all16(sf < -10.0 * slack))) all = true;
+      const double sa = n[0] * a_[0] + n[1] * a_[1] + n[2] * a_[2] - d0;
+      if (!(all16(sa > 10.0 * slack) || all16(sa < -10.0 * slack))) all = true;
     }
-    double P[16][3], rho_max = 0, t_max = -1e300;
-    int n_pos = 0, n_neg = 0;
-    for (int k = 0; k < 16 && !all; k++) {
-      const double* a_ = A[k >> 2];
-      const double nd = n[0] * D[k][0] + n[1] * D[k][1] + n[2] * D[k][2];
-      if (!(fabs(nd) >= 4.0 * AMBER_GRAZING)) { all = true; break; }    // grazing (or NaN): no convexity argument
-      if (nd > 0) n_pos++; else n_neg++;
-      const double t = (d0 - (n[0] * a_[0] + n[1] * a_[1] + n[2] * a_[2])) / nd;
-      for (int c = 0; c < 3; c++) P[k][c] = a_[c] + t * D[k][c];
-      rho_max = fmax(rho_max, 1.0 / fabs(nd));
-      t_max = fmax(t_max, t);
-    }
-    if (!all && n_pos != 0 && n_neg != 0) all = true;
-    if (all) {
-      for (uint32_t k = 0; k < 2u * np + nt; k++, bit <<= 1) mask |= bit;
+    const double nd = n[0] * Dk[0] + n[1] * Dk[1] + n[2] * Dk[2];
+    if (any16(!(fabs(nd) >= 4.0 * AMBER_GRAZING))) all = true;       // a corner ray grazes the plane (or NaN): no convexity argument
+    if (any16(nd > 0) && any16(!(nd > 0))) all = true;                // corner rays meet the plane from both sides
+    if (all) {                                                         // (uniform over the pixel's 16 lanes)
+      for (uint32_t r = 0; r < 2u * np + nt; r++, bit <<= 1) mask |= bit;
       tr += np + nt;
       continue;
     }
+    const double inv_nd = 1.0 / nd;
+    const double t = (d0 - (n[0] * a_[0] + n[1] * a_[1] + n[2] * a_[2])) * inv_nd;
+    const double P[3] = {a_[0] + t * Dk[0], a_[1] + t * Dk[1], a_[2] + t * Dk[2]};
+    const double rho_max = Max16(fabs(inv_nd)) * 1.000001, t_max = Max16(t);
     if (t_max < static_cast<double>(AMBER_KEPS) - static_cast<double>(pl->kt) * rho_max - slack) {   // every ray meets the plane behind its origin
       bit <<= (2u * np + nt); tr += np + nt;
       continue;
     }
     const double ptol = static_cast<double>(pl->ktol) * rho_max;
     for (uint32_t r = 0; r < np + nt; ++r, ++tr) {
-      const double g0 = sqrt(double(tr->c[0][0]) * tr->c[0][0] + double(tr->c[1][0]) * tr->c[1][0] + double(tr->c[2][0]) * tr->c[2][0]);
-      const double g1 = sqrt(double(tr->c[0][1]) * tr->c[0][1] + double(tr->c[1][1]) * tr->c[1][1] + double(tr->c[2][1]) * tr->c[2][1]);
+      // |gradient| of the two affine rows, bounded by their 1-norms
+      const double g0 = fabs(double(tr->c[0][0])) + fabs(double(tr->c[1][0])) + fabs(double(tr->c[2][0]));
+      const double g1 = fabs(double(tr->c[0][1])) + fabs(double(tr->c[1][1])) + fabs(double(tr->c[2][1]));
       const double tol = ptol + (g0 + g1) * slack + 1e-6;               // barycentric units
-      double mx[6] = {-1e300, -1e300, -1e300, -1e300, -1e300, -1e300};
-      for (int k = 0; k < 16; k++) {
-        const double u = tr->c[0][0] * P[k][0] + tr->c[1][0] * P[k][1] + tr->c[2][0] * P[k][2] + tr->c[3][0];
-        const double v = tr->c[0][1] * P[k][0] + tr->c[1][1] * P[k][1] + tr->c[2][1] * P[k][2] + tr->c[3][1];
-        // pair record: (u, v) = (beta, alpha) of the first triangle; the second one's coordinates are (-beta, 1 - alpha, beta + alpha)
-        mx[0] = fmax(mx[0], u); mx[1] = fmax(mx[1], v); mx[2] = fmax(mx[2], 1.0 - u - v);
-        mx[3] = fmax(mx[3], -u); mx[4] = fmax(mx[4], 1.0 - v); mx[5] = fmax(mx[5], u + v);
-      }
-      const bool keep1 = !(mx[0] < -tol || mx[1] < -tol || mx[2] < -tol);                  // NaN -> keep
-      mask |= keep1 ? bit : 0u; bit <<= 1;
+      const double u = tr->c[0][0] * P[0] + tr->c[1][0] * P[1] + tr->c[2][0] * P[2] + tr->c[3][0];
+      const double v = tr->c[0][1] * P[0] + tr->c[1][1] * P[1] + tr->c[2][1] * P[2] + tr->c[3][1];
+      // a triangle is dropped only if ONE of its coordinates is below -tol on all 16 corner rays.
+      // pair record: (u, v) = (beta, alpha) of the first triangle; the second one's coordinates are (-beta, 1 - alpha, beta + alpha)
+      const bool drop1 = all16(u < -tol) || all16(v < -tol) || all16(1.0 - u - v < -tol);   // a NaN coordinate votes "keep"
+      mask |= drop1 ? 0u : bit; bit <<= 1;
       if (r < np) {
-        const bool keep2 = !(mx[3] < -tol || mx[4] < -tol || mx[5] < -tol);
-        mask |= keep2 ? bit : 0u; bit <<= 1;
+        const bool drop2 = all16(-u < -tol) || all16(1.0 - v < -tol) || all16(u + v < -tol);
+        mask |= drop2 ? 0u : bit; bit <<= 1;
       }
     }
   }
   // spheres: the central ray against the sphere inflated by the beam's half width at the sphere's depth
-  {
+  if (sc.n_sphere_filters) {
     double ac[3] = {0, 0, 0}, fc[3] = {0, 0, 0};
-    for (int i = 0; i < 4; i++) for (int c = 0; c < 3; c++) { ac[c] += 0.25 * A[i][c]; fc[c] += 0.25 * F[i][c]; }
+    for (int i = 0; i < 4; i++) for (int c = 0; c < 3; c++) { ac[c] += 0.25 * pm.ap[i][c]; fc[c] += 0.25 * __shfl(fk[c], i, 16); }   // lanes 0..3 of the pixel hold F[0..3]
     double dc[3] = {fc[0] - ac[0], fc[1] - ac[1], fc[2] - ac[2]};
-    const double lc = sqrt(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]);
-    for (int c = 0; c < 3; c++) dc[c] /= lc;
+    const double inv_lc = 1.0 / sqrt(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]);
+    for (int c = 0; c < 3; c++) dc[c] *= inv_lc;
+    const double inv_dd = 1.0 / (Dk[0] * dc[0] + Dk[1] * dc[1] + Dk[2] * dc[2]);
+    const double off = (a_[0] - ac[0]) * dc[0] + (a_[1] - ac[1]) * dc[1] + (a_[2] - ac[2]) * dc[2];
     auto half_width = [&](double tau) {                                // largest distance of a corner ray from the central one in the plane at depth tau
-      double w2 = 0;
-      for (int k = 0; k < 16; k++) {
-        const double* a_ = A[k >> 2];
-        const double dd = D[k][0] * dc[0] + D[k][1] * dc[1] + D[k][2] * dc[2];
-        const double off = (a_[0] - ac[0]) * dc[0] + (a_[1] - ac[1]) * dc[1] + (a_[2] - ac[2]) * dc[2];
-        const double s_ = (tau - off) / dd;
-        double e2 = 0;
-        for (int c = 0; c < 3; c++) { const double e = a_[c] + s_ * D[k][c] - (ac[c] + tau * dc[c]); e2 += e * e; }
-        w2 = fmax(w2, e2);
-      }
-      return sqrt(w2);
+      const double s_ = (tau - off) * inv_dd;
+      double e2 = 0;
+      for (int c = 0; c < 3; c++) { const double e = a_[c] + s_ * Dk[c] - (ac[c] + tau * dc[c]); e2 += e * e; }
+      return sqrt(Max16(fmax(0.0, e2)));                               // (fmax(0, NaN) = 0: a NaN ray is skipped, as the serial loop's fmax did)
     };
     const DevSphereFilter* sp = sc.sphere_filters;
-    for (uint32_t k = 0; k < sc.n_sphere_filters; ++k, ++sp, bit <<= 1) {
+    for (uint32_t r_ = 0; r_ < sc.n_sphere_filters; ++r_, ++sp, bit <<= 1) {
       const double co[3] = {sp->c[0] - ac[0], sp->c[1] - ac[1], sp->c[2] - ac[2]};
       const double r = sqrt(static_cast<double>(sp->r2)) * 1.001 + slack;
       const double tau = co[0] * dc[0] + co[1] * dc[1] + co[2] * dc[2];
@@ -631,7 +663,7 @@ __global__ void pixel_mask_kernel(const DevScene sc, const PixelMaskArgs pm, uin
       mask |= miss ? 0u : bit;
     }
   }
-  out[p] = mask & ~sc.blade_mask;
+  if (live && k == 0u) out[p] = mask & ~sc.blade_mask;
 }
 
 // Engine BVH worker.  Same work queue, item walk and accumulation order as pt_megakernel, but the closest-hit query
@@ -997,11 +1029,15 @@ struct amber_hip_pt {
   bool pending = false, pending_checked = true;   // a launch whose record counter has not been looked at yet; checked = it cannot have run out of slots
   uint32_t pending_first = 0, pending_n = 0;
   bool density_known = false;
+  double test_density_scale = 0;            // AMBER_TEST_RECORD_DENSITY_SCALE, read once at create (0 = off): a test hook that mis-sizes the record buffer
   double rec_density = 0;                   // record slots used per path, as the last launch measured it
   int32_t* d_bvh_stack = nullptr;  size_t bvh_stack_ints = 0;     // pt_bvh_pool_kernel: deep traversal-stack levels
   float* d_carried = nullptr;      size_t carried_floats = 0;     // ... and carried measurements
   unsigned long long* d_sig = nullptr;  uint64_t sig_paths = 0;   // amber_hip_pt_signatures
   uint32_t* d_pixel_mask = nullptr;  bool pixel_mask_ready = false, pixel_mask_on = true;   // two-phase engine: primary-ray candidates per band pixel
+  std::vector<uint32_t> prog_order;         // two-phase engine: scene index of the object in filter-program slot k (the bit positions of the masks)
+  float pixel_mask_ms = 0;                  // duration of pixel_mask_kernel (amber_hip_kat_pixel_masks)
+  uint32_t lens_kind = 0; float lens_sensor_distance = 0, lens_focus_distance = 0;   // host copies of the lens constants pixel_mask_kernel's arguments derive from
   float aperture_rect[4][3] = {};           // world corners of the blades' bounding rectangle in the lens plane (pixel_mask_kernel)
   int n_cus = 256;
   uint32_t row_begin = 0, row_end = 0, stripe_rows = 0, stripe_period = 0, local_rows = 0;
@@ -1186,6 +1222,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     std::fprintf(stderr, "amber_hip: filter program: %zu planes (%u share the previous plane's normal), %u pair records, %u single records, %zu spheres, always mask %#x\n",
                  fprog.planes.size(), shared, pairs, singles, fprog.spheres.size(), fprog.always_mask);
   }
+  h->prog_order = fprog.order;
   for (uint32_t i = 0; i < L.n_blades; i++)            // filter-program slot of every aperture blade (self-candidate trip)
     for (uint32_t k = 0; k < fprog.n_prog_tris; k++)
       if (fprog.order[k] == L.first_blade_object + i) blades[i].slot = static_cast<int32_t>(k);
@@ -1310,6 +1347,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     }
   }
   { const char* ev = std::getenv("AMBER_PIXEL_MASK"); h->pixel_mask_on = !(ev && ev[0] == '0'); }
+  if (const char* ts = std::getenv("AMBER_TEST_RECORD_DENSITY_SCALE")) h->test_density_scale = std::atof(ts);   // the environment is read at create only
   sc.n_objects = s->n_objects; sc.max_depth = params->max_depth;
   h->n_materials = s->n_materials;
   DevLens lens{};
@@ -1328,6 +1366,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   lens.sd2 = static_cast<double>(L.sensor_distance) * static_cast<double>(L.sensor_distance);
   lens.n_blades = L.n_blades; lens.n_blades_f = static_cast<float>(L.n_blades);
   lens.kind = L.kind;
+  h->lens_kind = L.kind; h->lens_sensor_distance = L.sensor_distance; h->lens_focus_distance = L.focus_distance;
   { volatile float area = sensor->scene_width * sensor->scene_height; volatile float inv = 1.0f / area; lens.inv_scene_area = inv; }
   sc.sensor.w = sensor->width; sc.sensor.h = sensor->height;
   sc.sensor.wf = static_cast<float>(sensor->width); sc.sensor.hf = static_cast<float>(sensor->height);
@@ -1476,6 +1515,9 @@ namespace {
 constexpr uint64_t kMaxPathsPerLaunch = 1ull << 30;       // q and its bitmap index stay 32-bit; bitmap 128 MiB
 constexpr uint64_t kMaxRecordSlots = 48ull << 20;         // 28 B per slot (record + sorted measurement): 1.3 GiB at most
 
+// log2 of (waves of a grid of n_blocks workgroups of 4) rounded up to a power of two: RenderArgs.claim_shift
+uint32_t ClaimShift(uint32_t n_blocks) { uint32_t sh = 0; while ((1ull << sh) < static_cast<uint64_t>(n_blocks) * 4u) ++sh; return sh; }
+
 uint32_t PathBlocks(const amber_hip_pt* h, uint64_t n_paths) {
   const bool bvh = h->hit_engine == AMBER_ENGINE_BVH;
   uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * (bvh ? static_cast<uint32_t>(AMBER_BVH_POOL_WGS) : ResidentBlocksPerCu(h->hit_engine, h->bvh_depth));
@@ -1508,6 +1550,26 @@ int EnsureLaunchCtl(amber_hip_pt* h) {                                       // 
     h->d_rec_count = h->d_launch_ctl + 1;
     h->d_rays_launch = reinterpret_cast<unsigned long long*>(h->d_launch_ctl + 2);
   }
+  return AMBER_OK;
+}
+
+// Two-phase engine, once per handle: the candidate mask of every band pixel's eye rays (pixel_mask_kernel), enqueued on the render
+// stream in front of the handle's first launch.  timed: bracket the kernel with events and wait (amber_hip_kat_pixel_masks).
+int EnsurePixelMasks(amber_hip_pt* h, uint32_t n_pixels, bool timed) {
+  if (!(h->two_phase && h->pixel_mask_on) || h->pixel_mask_ready || n_pixels == 0) return AMBER_OK;
+  HIP_TRY(hipMalloc(&h->d_pixel_mask, static_cast<size_t>(n_pixels) * sizeof(uint32_t)));
+  PixelMaskArgs pm{};
+  for (int i = 0; i < 4; i++) for (int c = 0; c < 3; c++) pm.ap[i][c] = static_cast<double>(h->aperture_rect[i][c]) - static_cast<double>(h->scene.fp_center[c]);
+  pm.inv_w = 1.0 / static_cast<double>(h->scene.sensor.wf); pm.inv_h = 1.0 / static_cast<double>(h->scene.sensor.hf);
+  pm.focal_scale = h->lens_kind == 1u ? -(8.0 * static_cast<double>(h->scene.fp_reach) + 1.0) / static_cast<double>(h->lens_sensor_distance)
+                                      : static_cast<double>(h->lens_focus_distance) / -static_cast<double>(h->lens_sensor_distance);
+  pm.row_begin = h->row_begin; pm.stripe_rows = h->stripe_rows; pm.stripe_period = h->stripe_period; pm.n_pixels = n_pixels;
+  struct Events { hipEvent_t a = nullptr, b = nullptr; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evs;
+  if (timed) { HIP_TRY(hipEventCreate(&evs.a)); HIP_TRY(hipEventCreate(&evs.b)); HIP_TRY(hipEventRecord(evs.a, h->stream)); }
+  hipLaunchKernelGGL(pixel_mask_kernel, dim3((n_pixels + 15u) / 16u), dim3(256), 0, h->stream, h->scene, pm, h->d_pixel_mask);   // 16 lanes per pixel
+  HIP_TRY(hipGetLastError());
+  if (timed) { HIP_TRY(hipEventRecord(evs.b, h->stream)); HIP_TRY(hipEventSynchronize(evs.b)); HIP_TRY(hipEventElapsedTime(&h->pixel_mask_ms, evs.a, evs.b)); }
+  h->pixel_mask_ready = true;
   return AMBER_OK;
 }
 
@@ -1566,15 +1628,7 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
       h->bvh_stack_ints = stack_ints;
     }
   }
-  if (h->two_phase && h->pixel_mask_on && !h->pixel_mask_ready) {         // once per handle: the candidates of every band pixel's eye rays
-    HIP_TRY(hipMalloc(&h->d_pixel_mask, static_cast<size_t>(n_pixels) * sizeof(uint32_t)));
-    PixelMaskArgs pm{};
-    std::memcpy(pm.ap, h->aperture_rect, sizeof pm.ap);
-    pm.row_begin = h->row_begin; pm.stripe_rows = h->stripe_rows; pm.stripe_period = h->stripe_period; pm.n_pixels = n_pixels;
-    hipLaunchKernelGGL(pixel_mask_kernel, dim3((n_pixels + 127u) / 128u), dim3(128), 0, h->stream, h->scene, pm, h->d_pixel_mask);
-    HIP_TRY(hipGetLastError());
-    h->pixel_mask_ready = true;
-  }
+  { const int rc = EnsurePixelMasks(h, n_pixels, false); if (rc != AMBER_OK) return rc; }
   RenderArgs a{};
   a.pixel_mask = h->pixel_mask_ready ? h->d_pixel_mask : nullptr;
   a.scene = h->scene; a.flags = h->d_flags; a.touched = h->d_touched; a.records = h->d_records; a.rec_count = h->d_rec_count; a.rec_capacity = h->rec_capacity;
@@ -1582,6 +1636,7 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
   a.bvh_stack = h->d_bvh_stack; a.carried = h->d_carried; a.sig = sig;
   a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first; a.n_samples = n;
   a.n_chunks = (n + AMBER_ACCUM_CHUNK - 1) / AMBER_ACCUM_CHUNK; a.n_items = static_cast<uint32_t>(n_paths);
+  a.claim_shift = ClaimShift(n_blocks);
   HIP_TRY(hipMemsetAsync(h->d_launch_ctl, 0, 4 * sizeof(unsigned int), h->stream));
   // The bitmap is cleared by the reduction itself where it can be (whole words per pixel); the host clears all of it only when a
   // launch left it dirty: the first use, sample counts that are not multiples of 32, signature launches, a launch that ran out of slots.
@@ -1643,7 +1698,7 @@ int ResolvePending(amber_hip_pt* h) {
 int RenderPassPaths(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint32_t n_pixels) {
   uint64_t max_samples = kMaxPathsPerLaunch / n_pixels / AMBER_ACCUM_CHUNK * AMBER_ACCUM_CHUNK;
   if (max_samples == 0) return Fail(AMBER_EINVAL, "band too large for one launch");
-  const uint64_t slack = std::getenv("AMBER_TEST_RECORD_DENSITY_SCALE") ? 64u : RecordSlack(h);   // (test hook: no cushion either)
+  const uint64_t slack = h->test_density_scale > 0 ? 64u : RecordSlack(h);   // (test hook: no cushion either)
   uint32_t done = 0;
   while (done < n_samples) {
     // the previous launch must stand before the next one adds to the framebuffer (the order of the sums is part of the
@@ -1658,7 +1713,7 @@ int RenderPassPaths(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, 
       slots = static_cast<uint64_t>(n_pixels) * n + slack;
     } else {
       double density = h->rec_density;
-      if (const char* ts = std::getenv("AMBER_TEST_RECORD_DENSITY_SCALE")) density *= std::atof(ts);   // test hook: a wrong estimate must only cost a repeated launch
+      if (h->test_density_scale > 0) density *= h->test_density_scale;   // test hook: a wrong estimate must only cost a repeated launch
       const double per_sample = std::max(1e-9, density * 1.5) * static_cast<double>(n_pixels);   // slots one sample of the band needs, with margin
       const uint64_t all = static_cast<uint64_t>(n_pixels) * n;
       const double want = per_sample * n;
@@ -1684,7 +1739,7 @@ int RenderPassPaths(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, 
 }
 }  // namespace
 
-extern "C" int RenderPassBvhItems(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint32_t n_pixels, unsigned long long* sig);
+static int RenderPassBvhItems(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint32_t n_pixels, unsigned long long* sig);   // internal: not part of the ABI
 
 int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples) {
   if (!h) return Fail(AMBER_EINVAL, "null handle");
@@ -1699,7 +1754,7 @@ int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
 }
 
 // sig != null (amber_hip_pt_signatures): one launch of the signature instantiation; nothing reaches the framebuffer or the ray total
-int RenderPassBvhItems(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint32_t n_pixels, unsigned long long* sig) {
+static int RenderPassBvhItems(amber_hip_pt* h, uint32_t first_sample, uint32_t n_samples, uint32_t n_pixels, unsigned long long* sig) {
   // engine BVH, default scheduler (pt_bvh_megakernel: lanes own (pixel, chunk) items).  A launch covers at most kMaxPartialFloats
   // of per-item sums and < 2^31 items; longer passes are split on chunk boundaries, which leaves the summation order unchanged
   const uint64_t kMaxPartialFloats = 768ull << 20;    // 3 GiB
@@ -1803,6 +1858,7 @@ int amber_hip_lt_trace_range(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
     uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth);
     const uint32_t by_work = (a.n_items + 255u) / 256u;
     if (by_work < n_blocks) n_blocks = by_work;
+    a.claim_shift = ClaimShift(n_blocks);
     if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (bvh) {
       if (h->bvh_depth <= 24) hipLaunchKernelGGL((pt_bvh_megakernel<true, 24>), dim3(n_blocks), dim3(256), 0, h->stream, a);
@@ -2083,6 +2139,8 @@ int amber_hip_kat_traversal_rate(amber_hip_pt* h, uint32_t n, const float* origi
   if (!h || !origins || !dirs || !out_t || !out_object || n == 0) return Fail(AMBER_EINVAL, "bad argument");
   if (h->hit_engine != AMBER_ENGINE_BVH) return Fail(AMBER_EINVAL, "the handle's engine is not BVH");
   if (refill_min == 0 || refill_min > 64) return Fail(AMBER_EINVAL, "refill_min must be in [1, 64]");
+  const uint64_t n_virtual = static_cast<uint64_t>(n) * (repeats ? repeats : 1u);
+  if (n_virtual > 0xfffffeffull) return Fail(AMBER_EINVAL, "n * repeats must stay below 2^32");
   HIP_TRY(hipSetDevice(h->device));
   { const int rc = ResolvePending(h); if (rc != AMBER_OK) return rc; }
   std::vector<float4> packed(2ull * n);
@@ -2096,11 +2154,10 @@ int amber_hip_kat_traversal_rate(amber_hip_pt* h, uint32_t n, const float* origi
   const uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * (waves >= 4 && waves <= 8 ? waves : 5u);
   HIP_TRY(d_stack.alloc(static_cast<size_t>(n_blocks) * 256u * AMBER_BVH_STACK));
   HIP_TRY(hipMemcpy(d_rays.p, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  struct Events { hipEvent_t a = nullptr, b = nullptr; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evs;   // released on every exit path
+  HIP_TRY(hipEventCreate(&evs.a)); HIP_TRY(hipEventCreate(&evs.b));
+  const hipEvent_t e0 = evs.a, e1 = evs.b;
   double best = 1e300;
-  const uint64_t n_virtual = static_cast<uint64_t>(n) * (repeats ? repeats : 1u);
-  if (n_virtual > 0xfffffeffull) return Fail(AMBER_EINVAL, "n * repeats must stay below 2^32");
   const uint32_t nv = static_cast<uint32_t>(n_virtual);
   for (uint32_t rep = 0; rep < 2u; rep++) {                              // a warm-up launch and the measured one
     HIP_TRY(hipMemsetAsync(d_next.p, 0, sizeof(unsigned int), h->stream));
@@ -2117,7 +2174,6 @@ int amber_hip_kat_traversal_rate(amber_hip_pt* h, uint32_t n, const float* origi
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     if (rep == 1u || ms < best) best = ms;
   }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   std::vector<float2> res(n);
   HIP_TRY(hipMemcpy(res.data(), d_out.p, n * sizeof(float2), hipMemcpyDeviceToHost));
   if (out_rounds) HIP_TRY(hipMemcpy(out_rounds, d_rounds.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -2129,6 +2185,26 @@ int amber_hip_kat_traversal_rate(amber_hip_pt* h, uint32_t n, const float* origi
     out_t[i] = slot < 0 ? std::nanf("") : res[i].x;
   }
   if (best_ms) *best_ms = best;
+  return AMBER_OK;
+}
+
+int amber_hip_kat_pixel_masks(amber_hip_pt* h, uint32_t* out_mask, uint32_t* out_slot_of_object, uint32_t* out_always_mask, double* kernel_ms) {
+  if (!h) return Fail(AMBER_EINVAL, "null handle");
+  if (!h->two_phase) return Fail(AMBER_EINVAL, "pixel masks belong to the two-phase engine");
+  HIP_TRY(hipSetDevice(h->device));
+  { const int rc = ResolvePending(h); if (rc != AMBER_OK) return rc; }
+  const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
+  const bool was_ready = h->pixel_mask_ready;
+  { const int rc = EnsurePixelMasks(h, n_pixels, true); if (rc != AMBER_OK) return rc; }
+  if (!h->pixel_mask_ready) return Fail(AMBER_EINVAL, "pixel masks are switched off (AMBER_PIXEL_MASK=0) or the band is empty");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (out_mask) HIP_TRY(hipMemcpy(out_mask, h->d_pixel_mask, static_cast<size_t>(n_pixels) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (out_slot_of_object) {
+    for (uint32_t i = 0; i < h->scene.n_objects; i++) out_slot_of_object[i] = 0xffffffffu;
+    for (size_t k = 0; k < h->prog_order.size(); k++) if (h->prog_order[k] < h->scene.n_objects) out_slot_of_object[h->prog_order[k]] = static_cast<uint32_t>(k);
+  }
+  if (out_always_mask) *out_always_mask = h->scene.always_mask | h->scene.blade_mask;
+  if (kernel_ms) *kernel_ms = was_ready ? -1.0 : static_cast<double>(h->pixel_mask_ms);
   return AMBER_OK;
 }
 

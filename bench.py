@@ -13,9 +13,14 @@ started by a launcher; under a launcher (RANK / WORLD_SIZE in the environment) i
 Prints ONE JSON line on rank 0.  `value` = rays of all ranks / max-over-ranks wall time of the K timed
 steps (inputs resident in HBM; barrier + synchronize on both sides).
 
-After the timed steps, and outside `value`, the N = 1 run also measures the other BASELINE configurations on this one GPU
-(`secondary`): config 3 at its full size, and ONE rank's share of configs 4 and 5 (its stripes of the real frame, one launch
-of the real samples-per-launch; config 5 with max depth 16).
+After the timed steps, and outside `value`, the N = 1 run starts ONE child process (`--side-child`; a child, never an exec; the
+headline numbers are already on disk in gpurun_out/bench_headline.json by then, and a fault, hang or time-out of the child costs only
+its own fields) that measures on this one GPU:
+  `secondary`         the other BASELINE configurations: config 3 at its full size, and ONE rank's share of configs 4 and 5 (its stripes
+                      of the real frame, one launch of the real samples-per-launch; config 5 with max depth 16);
+  `projected_scaling` every rank's COMPLETE step of the headline job at N = 1 / 2 / 4 / 8 (clear, launch, record kernels, sync, the RCCL
+                      gather of its rows run as a one-rank collective), max over the ranks' shares -- a projection, labelled as such;
+  `cold_start`        create -> first downloaded frame of the headline job on a new handle (`cold_wall_ms`).
 """
 from __future__ import annotations
 
@@ -101,6 +106,12 @@ def cpu_baseline(amber_amd, width: int, spp_job: int, seed: int, many_s: float =
     spp = max(1, min(spp_job, int(many_s / max(dt1 / 4, 1e-3))))
     casts, dt = timed(5, spp, cores)
     out = {"value": round(casts / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "nproc": nproc,
+           "sampler": "xorshift per (pixel, sample) -- the reference draws from one mt19937_64 per thread, about 13 % of its run time "
+                      "(BASELINE.md section 2): this port is FASTER than the reference itself would be on these cores",
+           "reference_calibration": None,
+           "reference_calibration_reason": "the ratio port / true reference (SURVEY 8(d)) cannot be measured: the reference does not build in this image "
+                                           "(boost headers absent, stand-ins not allowed); the survey's own figure for the unmodified reference is 1.46 Mrays/s "
+                                           "per core of a 2.1 GHz Xeon (BASELINE.md section 2)",
            "sample": f"Cornell {width}x{width} @ {spp} spp of the {spp_job} ({casts} rays in {dt:.2f} s), oracle: XorShift sampler, "
                      f"reference BVH, host libm, {cores} threads (nproc {nproc}, cgroup CPU quota {usable}); scale linearly in spp"}
     if cores > 1:                                                         # also ONE thread, >= 2 s of it
@@ -129,7 +140,7 @@ def latest_profile_summary():
 
 
 def secondary_workloads(amber_amd, np, seed: int, device: int):
-    """BASELINE configs 3, 4 and 5 on THIS GPU, after the timed steps and outside `value` (VERDICT r02 item 2): config 3 whole;
+    """BASELINE configs 3, 4 and 5 on THIS GPU, outside `value` (VERDICT r02 item 2): config 3 whole;
     for the multi-GPU configs the share of rank 0 -- its interleaved 8-row stripes of the real frame -- for ONE launch of the
     real samples-per-launch (1024).  Every entry: kernel time by hipEvents, rays, Mrays/s, the section-8(d) contract fraction."""
     from amber_amd import scenes
@@ -173,6 +184,150 @@ def secondary_workloads(amber_amd, np, seed: int, device: int):
     return out
 
 
+def projected_scaling(amber_amd, torch, seed: int, device: int, width: int, spp: int, reps: int = 3):
+    """What a step of the headline job would cost on N GPUs, measured on ONE: every rank's share (its interleaved 8-row stripes, as
+    `stripe_partition` deals them) runs its COMPLETE step here -- clear, the launch, the rank / scan / place / reduce kernels, the host
+    synchronisation, and the gather of its rows through RCCL as a one-rank collective on the render stream (launch + re-ordering cost;
+    the transfer of the other ranks' rows over xGMI is estimated, see `xgmi_estimate_ms`) -- and the step of N ranks is the slowest
+    share (the bench takes the max over ranks).  A PROJECTION: no run on more than one GPU exists for this line."""
+    import numpy as np
+    from amber_amd.distributed import RowGatherer, band_tensor, stripe_partition
+    import torch.distributed as dist
+
+    collective = dist.is_available() and dist.is_initialized()
+    sensor = amber_amd.Sensor.default(width, width)
+    scene = amber_amd.HostScene.cornell_box()
+    out = {"what": "PROJECTED from one GPU: step wall of the slowest rank's share, every share run alone on this GPU (strong scaling of the headline job); "
+                   "not a multi-GPU measurement", "spp": spp, "reps": reps,
+           "step_includes": ["clear", "pt_megakernel", "rec_rank/scan/place + reduce_flagged", "host sync"] + (["1-rank RCCL gather + row re-ordering on the render stream"] if collective else []),
+           "gather": "rccl, one rank" if collective else None, "per_n": []}
+    base = base_k = None
+    for n in (1, 2, 4, 8):
+        parts = stripe_partition(width, n)
+        walls, kerns, gathers, rays = [], [], [], []
+        for part in parts:
+            pt = amber_amd.PathTracer(scene, sensor, seed=seed, device=device, rows=part["rows"], stripe=part["stripe"])
+            stream = torch.cuda.ExternalStream(pt.stream(), device=torch.device("cuda", device))
+            fb = band_tensor(pt, f"cuda:{device}")
+            own = [dict(rows=(0, len(part["index"])), stripe=None, index=np.arange(len(part["index"])))]
+            gather = RowGatherer(own, width, 0, 1, fb.device, force_collective=collective)
+            pt.render_pass(0, 8); pt.sync(); pt.clear()
+            best, best_k, best_g = 1e9, 0.0, 0.0
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pt.clear()                                              # (also resets the handle's launch timer)
+                pt.render_pass(0, spp)
+                pt.sync()
+                g_ms = 0.0
+                if collective:
+                    with torch.cuda.stream(stream):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(stream); gather(fb); e1.record(stream)
+                    torch.cuda.synchronize()
+                    g_ms = e0.elapsed_time(e1)
+                wall = (time.perf_counter() - t0) * 1e3
+                _, k_ms = pt.kernel_time()
+                if wall < best:
+                    best, best_k, best_g = wall, k_ms, g_ms
+            walls.append(best); kerns.append(best_k); gathers.append(best_g); rays.append(pt.ray_count())
+            del fb, gather
+            pt.close()
+        step = max(walls)
+        if n == 1:
+            base, base_k = step, max(kerns)
+        band_bytes = len(parts[0]["index"]) * width * 12
+        out["per_n"].append({"n_gpus": n, "step_wall_ms": round(step, 3), "mean_share_wall_ms": round(sum(walls) / len(walls), 3),
+                             "kernel_ms_of_slowest_share": round(max(kerns), 3), "gather_ms": round(max(gathers), 4) if collective else None,
+                             "xgmi_estimate_ms": round(band_bytes / 120e9 * 1e3, 4) if n > 1 else 0.0,
+                             "projected_speedup": round(base / step, 3),
+                             "projected_speedup_by_kernel_time": round(base_k / max(kerns), 3) if max(kerns) > 0 else None})
+    out["note"] = ("xgmi_estimate_ms = one rank's rows (bytes) / 120 GB/s of one xGMI link (7 links x ~153 GB/s per GPU, 0.8 efficiency; the root ingests the other "
+                   "ranks' rows on distinct links concurrently): NOT included in step_wall_ms")
+    return out
+
+
+def cold_start(amber_amd, seed: int, device: int, width: int, spp: int):
+    """What a user of the CLI waits for at the start of a render (application.cc:120-215): a NEW handle on the headline job -- create
+    (scene flattening and upload), the per-pixel candidate masks, the one-chunk record-density probe, the first full launch and the
+    download of the frame.  The process is warm (HIP initialised, code objects loaded); the handle is not."""
+    import numpy as np
+    scene = amber_amd.HostScene.cornell_box()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        pt = amber_amd.PathTracer(scene, amber_amd.Sensor.default(width, width), seed=seed, device=device)
+        t1 = time.perf_counter()
+        pt.render_pass(0, 8)                                                # what amber_hip_pt_render_pass does first anyway: the probe chunk
+        pt.sync()
+        t2 = time.perf_counter()
+        pt.render_pass(8, spp - 8)
+        img, rays = pt.download()
+        t3 = time.perf_counter()
+        n_launch, ms = pt.kernel_time()
+        pt.close()
+        cur = {"cold_wall_ms": round((t3 - t0) * 1e3, 3), "create_ms": round((t1 - t0) * 1e3, 3), "create_to_end_of_first_launch_ms": round((t2 - t0) * 1e3, 3),
+               "first_launch_incl_pixel_masks_ms": round((t2 - t1) * 1e3, 3), "rest_and_download_ms": round((t3 - t2) * 1e3, 3),
+               "launches": n_launch, "kernel_ms_total": round(ms, 3), "rays": int(rays)}
+        if best is None or cur["cold_wall_ms"] < best["cold_wall_ms"]:
+            best = cur
+    best["what"] = f"new handle, Cornell {width}x{width} @ {spp} spp: create -> frame downloaded (best of 3; warm process)"
+    return best
+
+
+def side_child(args):
+    """`bench.py --side-child`: the measurements that follow the headline (module docstring), in a process of their own.  One JSON line on
+    the saved stdout; RCCL's banner and everything else goes to stderr."""
+    import numpy as np
+    import torch
+    import amber_amd
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    device = 0
+    torch.cuda.set_device(device)
+    out = {}
+    try:
+        out["cold_start"] = cold_start(amber_amd, args.seed, device, args.width, args.spp)
+    except Exception as e:
+        out["cold_start"] = None; out["cold_start_error"] = str(e)[:200]
+    try:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", device))
+        except Exception as e:                                             # the projection still runs, without the gather
+            out["projected_scaling_gather_error"] = str(e)[:200]
+        out["projected_scaling"] = projected_scaling(amber_amd, torch, args.seed, device, args.width, args.spp)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception as e:
+        out["projected_scaling"] = None; out["projected_scaling_error"] = str(e)[:200]
+    try:
+        out["secondary"] = secondary_workloads(amber_amd, np, args.seed, device)
+    except Exception as e:
+        out["secondary"] = None; out["secondary_error"] = str(e)[:200]
+    os.write(json_fd, (json.dumps({"side": out}) + "\n").encode())
+
+
+def run_side_child(args, timeout_s: float = 420.0):
+    """Starts side_child as a child process and returns its dict (or an error entry).  The parent has released its GPU buffers."""
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--side-child", "--seed", str(args.seed), "--width", str(args.width), "--spp", str(args.spp)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"side_error": f"the side-measurement child did not finish in {timeout_s:.0f} s"}
+    for line in r.stdout.splitlines():
+        if line.startswith('{"side"'):
+            return json.loads(line)["side"]
+    return {"side_error": f"the side-measurement child ended with code {r.returncode} and no result"}
+
+
 def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -211,13 +366,17 @@ def main():
     ap.add_argument("--spp-per-launch", type=int, default=1024)
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the configs 3 / 4 / 5 measurements that follow the timed steps (N = 1)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the child process that follows the timed steps at N = 1 (configs 3 / 4 / 5, projected scaling, cold start)")
+    ap.add_argument("--side-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single GPU: every rank uses device 0 and the gather runs over gloo on host copies")
     ap.add_argument("--engine", default="auto", choices=["auto", "list", "two_phase", "bvh", "wavefront"],
                     help="closest-hit / scheduling engine (default: auto = the fastest valid one; others for comparison)")
     args = ap.parse_args()
 
+    if args.side_child:
+        side_child(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
 
@@ -391,12 +550,26 @@ def main():
                 out["roofline"]["measured_copy_bw"] = None
                 out["roofline"]["measured_copy_bw_error"] = str(e)[:120]
         if world == 1 and not args.no_secondary:
+            # The headline is measured: make it durable before anything else can go wrong, then run the side measurements
+            # in a child process -- a GPU fault or a hang there costs only `secondary` / `projected_scaling` / `cold_start`.
             try:
-                tracer.close()                                         # free the headline handle's buffers first
-                out["secondary"] = secondary_workloads(amber_amd, np, args.seed, local_rank)
-            except Exception as e:                                     # never lose the bench line over the side measurements
-                out["secondary"] = None
-                out["secondary_error"] = str(e)[:200]
+                side_file = ROOT / "gpurun_out" / "bench_headline.json"
+                side_file.parent.mkdir(exist_ok=True)
+                side_file.write_text(json.dumps(out) + "\n")
+            except Exception:
+                pass
+            del fb, img, gather                                        # aliases of the handle's framebuffer: gone before the handle is
+            tracer.close()                                             # the child gets the whole GPU
+            torch.cuda.empty_cache()
+            side = run_side_child(args)
+            out["secondary"] = side.get("secondary")
+            out["projected_scaling"] = side.get("projected_scaling")
+            cold = side.get("cold_start")
+            out["cold_start"] = cold
+            out["config"]["cold_wall_ms"] = cold.get("cold_wall_ms") if cold else None    # next to wall_s_per_step: create -> first downloaded frame, new handle
+            for k, v in side.items():
+                if k.endswith("_error"):
+                    out[k] = v
         if not args.no_cpu_baseline and world == 1:                    # reported at N = 1 only
             out["cpu_baseline"], out["parity"] = cpu_baseline(amber_amd, W, args.spp, args.seed)
         sys.stdout.flush()

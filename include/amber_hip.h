@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define AMBER_HIP_ABI_VERSION 1
+#define AMBER_HIP_ABI_VERSION 2   /* 2 (round 4): entry points added since 1 (signatures, traversal rate, lt ranges, stream); a stream-ordered read of
+                                    amber_hip_pt_device_framebuffer() needs amber_hip_pt_sync() first when a launch may have run out of record slots */
 
 /* Accumulation granule: within a render pass the samples of a pixel are summed sequentially in chunks of
  * AMBER_ACCUM_CHUNK consecutive samples (starting at first_sample), and the chunk sums are added to the
@@ -231,6 +232,13 @@ int amber_hip_pt_signatures(amber_hip_pt*, uint32_t first_sample, uint32_t n_sam
  * section 5) that doubles as a known-answer test of the traversal. */
 int amber_hip_kat_traversal_rate(amber_hip_pt*, uint32_t n, const float* origins, const float* dirs, uint32_t waves, uint32_t refill_min,
                                  uint32_t repeats, float* out_t, int32_t* out_object, double* best_ms, uint32_t* out_rounds);
+/* Two-phase engine: the per-pixel candidate masks of the primary rays (pixel_mask_kernel; computed now if the handle has not rendered yet).
+ * out_mask: one word per band pixel, bit k = the object in filter-program slot k can be hit by SOME eye ray of the pixel (aperture blades
+ * excluded: they are added per ray).  out_slot_of_object: n_objects entries, the slot of every scene object (0xffffffff: none).
+ * out_always_mask: the slots that are candidates of EVERY ray whatever the pixel (objects the filter program has no record for, and the
+ * aperture blades, which a primary ray adds itself).  kernel_ms: duration of the mask kernel if this call ran it, else -1.
+ * Any pointer may be NULL. */
+int amber_hip_kat_pixel_masks(amber_hip_pt*, uint32_t* out_mask, uint32_t* out_slot_of_object, uint32_t* out_always_mask, double* kernel_ms);
 /* the engine's sin/cos/pow on device: mode 0 = sincos(x[i]) -> out[2i], out[2i+1] ; mode 1 = pow(x[2i], x[2i+1]) -> out[i] ;
  * mode 2 / 3 = x[i]^4 / x[i]^5 in binary64 -> out[2i], out[2i+1] = low, high word of the double */
 int amber_hip_kat_math(int device, int mode, uint32_t n, const float* x, float* out);

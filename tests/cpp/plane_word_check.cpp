@@ -39,6 +39,20 @@ int main() {
       n++;
     }
   }
+  // a scene with no extent on an axis, away from the origin: the grid of that axis must keep a usable step, the planes
+  // of the flat box must be found in a few steps, stay conservative and inside the promised reach |value| <= 1 + one binary16 step
+  for (double coord : {1234.5, -0.37, 6.0e5, 0.0, 1e-20}) {
+    float mid, half;
+    F16AxisGrid(coord, coord, mid, half);
+    if (!(half > 0.0f) || (coord != 0.0 && !(half >= std::fabs(mid) * 9e-7f))) { bad++; std::printf("degenerate axis at %g: half %g\n", coord, half); }
+    const float c = static_cast<float>(coord);
+    const uint32_t w = PlaneWord(c, c, mid, half);
+    const double vlo = F16Value(w & 0xffffu), vhi = F16Value(w >> 16);
+    if (!(double(mid) + vlo * half <= c) || !(double(mid) + vhi * half >= c) || std::fabs(vlo) > 1.001 || std::fabs(vhi) > 1.001) {
+      bad++; std::printf("degenerate axis at %g: planes %g %g (values %g %g)\n", coord, double(mid) + vlo * half, double(mid) + vhi * half, vlo, vhi);
+    }
+    n++;
+  }
   std::printf("%ld boxes, %ld violations, %ld planes not tight\n", n, bad, loose);
   return (bad == 0 && loose == 0 && n > 100000) ? 0 : 1;
 }

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(amber):
     assert declared == set(ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.amber_hip_abi_version() == 1
+    assert lib.amber_hip_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header(amber):

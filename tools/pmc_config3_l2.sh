@@ -1,5 +1,6 @@
 #!/bin/bash
-ROOT=${GRAFT_REPO_ROOT}
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/r03z/l2; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 for pass in "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCP_TCC_READ_REQ_sum"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
