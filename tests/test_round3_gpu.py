@@ -179,10 +179,10 @@ def test_a_launch_that_runs_out_of_record_slots_is_repeated(amber, cornell):
     sn = amber.Sensor.default(W, H)
     # rows that look at the floor only see light by reflection; rows at the top look straight at the ceiling light: a band
     # handle over the whole frame whose first launch is ONE sample (density of that one sample), then 63 more
-    pt = amber.PathTracer(hs, sn, seed=11)
     import os
-    os.environ["AMBER_TEST_RECORD_DENSITY_SCALE"] = "0.02"              # test hook: pretend the measured density was 50x lower
+    os.environ["AMBER_TEST_RECORD_DENSITY_SCALE"] = "0.02"              # test hook (read once, at create): pretend the measured density was 50x lower
     try:
+        pt = amber.PathTracer(hs, sn, seed=11)
         pt.render_pass(0, 8)
         pt.render_pass(8, 56)                                           # sized 50x too small: runs out of slots, is repeated
         img, rays = pt.download()
