@@ -1243,7 +1243,7 @@ __device__ __forceinline__ V3 Radiance(const DevMaterial& m, V3 normal, V3 dir_o
 __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 dir_out, uint64_t& rng, V3& dir_in, V3& weight) {
   const V3 rho = ld3(m.rho);
   const uint32_t kind = m.kind;
-#ifdef AMBER_HOIST_MIRROR   /* diagnostic only ("the stamps build that lost rays"): the common-subexpression form of commit 778d0a2 */
+#ifdef AMBER_HOIST_MIRROR   /* diagnostic only (EXPERIMENTS.md, "the diagnostic build that lost 5 % of its rays"): the common-subexpression form of commit 778d0a2 */
   const float hoisted_cos_o = Dot(dir_out, normal);
   const V3 hoisted_mirror = PerfectReflection(dir_out, normal, hoisted_cos_o);
 #define AMBER_COS_O() hoisted_cos_o

@@ -32,7 +32,7 @@ extern "C" {
 /* Accumulation granule: within a render pass the samples of a pixel are summed sequentially in chunks of
  * AMBER_ACCUM_CHUNK consecutive samples (starting at first_sample), and the chunk sums are added to the
  * framebuffer in chunk order.  Part of the numerical contract (the oracle restates it).  8 keeps the work queue
- * fine-grained: with 32 the tail of an 8-way sharded render cost 10 %. */
+ * fine-grained: with 32 the tail of an 8-way sharded render cost 10 % (EXPERIMENTS.md, multi-GPU). */
 #define AMBER_ACCUM_CHUNK 8u
 
 enum {

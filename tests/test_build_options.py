@@ -61,7 +61,7 @@ def test_diagnostic_build_renders_the_same_paths():
     """The -DAMBER_STAMPS build (tools/stamps.py, tools/bvh_counters.py) adds clocks and counters, nothing else: every engine
     must cast exactly the rays of engine LIST and produce its image, every time.  Round 2's stamped two-phase kernel lost 5 % of
     its rays, differently in every run: hipcc had placed VGPR spill stores in front of the `s_or_b64 exec` of a join block, so the
-    Phong lanes reloaded stale scratch (tools/check_spill_placement.py lints the ISA for the pattern).  The
+    Phong lanes reloaded stale scratch (EXPERIMENTS.md; tools/check_spill_placement.py lints the ISA for the pattern).  The
     product library runs the same loop: its kernels are built at their register caps, where such spills would appear first."""
     subprocess.run(["make", "-C", str(ROOT / "amber_amd" / "csrc"), "stamps"], check=True, capture_output=True, timeout=900)
     for lib in ("libamber_hip_stamps.so", "libamber_hip.so"):

@@ -151,7 +151,7 @@ def test_stripe_partition_covers_every_row_once():
 
 def test_no_spill_code_in_front_of_an_exec_restore():
     """The compiled product kernels are free of the one hipcc miscompile this code base has met (tools/check_spill_placement.py,
-    DESIGN.md section 7): VGPR spill stores / reloads placed before the `s_or_b64 exec` of a join block run for the lanes of the
+    EXPERIMENTS.md): VGPR spill stores / reloads placed before the `s_or_b64 exec` of a join block run for the lanes of the
     `if` body only, and the others later read stale scratch -- round 2's diagnostic build lost 5 % of its rays that way.
     hipcc cross-compiles without a GPU, so this runs everywhere; the known-bad pattern itself is a fixture."""
     import shutil

@@ -8,7 +8,7 @@ and as a light, Cylinder and triangle lights, lt itself -- are checked here the 
 two images must agree within their Monte-Carlo error.
 
 The scene uses only configurations in which the REFERENCE'S OWN arithmetic lets the two converge.  Three reference
-properties (restated faithfully by oracle and engine, found with tools/convergence_probe.py) break
+properties (restated faithfully by oracle and engine, EXPERIMENTS.md "the reference's own validation method") break
 the agreement and are pinned by the second test instead of being "fixed":
   * prelude::SphereSA (sampling.h:185-199) returns (cos t cos p, cos t sin p, sin t): only the z >= 0 half of the sphere,
     non-uniformly -- a sphere LIGHT emits differently in lt than pt sees it;

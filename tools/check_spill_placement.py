@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Lint of the compiled gfx950 ISA for one miscompile of ROCm 7.2's hipcc ("the stamps build that lost rays").
+"""Lint of the compiled gfx950 ISA for one miscompile of ROCm 7.2's hipcc (EXPERIMENTS.md, "the diagnostic build that lost 5 % of its rays").
 
 At the join block of a divergent `if` the compiler re-enables the lanes with `s_or_b64 exec, exec, sN`.  A VGPR spill store
 (or reload) that the register allocator places at the top of such a block must come AFTER that instruction; when a scalar

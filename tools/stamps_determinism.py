@@ -1,5 +1,5 @@
 """Ray counts and image hashes of every engine, several times over, with the library named by AMBER_AMD_LIB: a diagnostic build
-must cast exactly the product's rays, every time (the stamps build that lost 5 % of its rays).
+must cast exactly the product's rays, every time (EXPERIMENTS.md: the diagnostic build that lost 5 % of its rays).
     AMBER_AMD_LIB=libamber_hip_<variant>.so python tools/stamps_determinism.py [rounds] [spp]"""
 import hashlib, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)

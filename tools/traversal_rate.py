@@ -1,4 +1,4 @@
-"""How fast is engine BVH's traversal on its own?    Builds a realistic ray set of BASELINE config 3 (1M
+"""How fast is engine BVH's traversal on its own?  (EXPERIMENTS.md, engine BVH.)  Builds a realistic ray set of BASELINE config 3 (1M
 spheres) -- exact eye rays plus the secondary rays of traced paths (origin = the previous hit point, direction towards the next) --
 and runs them through bvh_trace_rate_kernel: the render kernels' resumable traversal in a kernel that does nothing else, at 4, 5,
 6 and 8 waves per SIMD and several refill thresholds.  Checks every answer against amber_hip_kat_cast.
