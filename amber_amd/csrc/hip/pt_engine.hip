@@ -535,6 +535,7 @@ struct PixelMaskArgs {
   double ap[4][3];                // corners of the aperture's bounding rectangle in the lens plane (inflated), RELATIVE TO THE FILTER CENTRE; pinhole: the origin
   double inv_w, inv_h;            // 1 / sensor width, height (pixels)
   double focal_scale;             // thin lens: -focus_distance / sensor_distance; pinhole: -(8 reach + 1) / sensor_distance (a point far along the ray)
+  uint32_t planes_cut_a;          // bit i: plane i of the filter program passes within the slack of the aperture rectangle (the same for every pixel: tested on the host)
   uint32_t row_begin, stripe_rows, stripe_period, n_pixels;
 };
 // SIXTEEN LANES PER PIXEL, lane k = corner ray a_(k >> 2) -> f_(k & 3) (round 4).  Round 3's kernel ran one thread per pixel with the 16
@@ -599,8 +600,7 @@ __global__ void __launch_bounds__(256) pixel_mask_kernel(const DevScene sc, cons
     {
       const double sf = n[0] * fk[0] + n[1] * fk[1] + n[2] * fk[2] - d0;
       if (!(all16(sf > 10.0 * slack) || all16(sf < -10.0 * slack))) all = true;
-      const double sa = n[0] * a_[0] + n[1] * a_[1] + n[2] * a_[2] - d0;
-      if (!(all16(sa > 10.0 * slack) || all16(sa < -10.0 * slack))) all = true;
+      if ((pm.planes_cut_a >> (pi & 31u)) & 1u) all = true;            // the aperture's side of the same question: pixel-independent
     }
     const double nd = n[0] * Dk[0] + n[1] * Dk[1] + n[2] * Dk[2];
     if (any16(!(fabs(nd) >= 4.0 * AMBER_GRAZING))) all = true;       // a corner ray grazes the plane (or NaN): no convexity argument
@@ -1036,8 +1036,9 @@ struct amber_hip_pt {
   unsigned long long* d_sig = nullptr;  uint64_t sig_paths = 0;   // amber_hip_pt_signatures
   uint32_t* d_pixel_mask = nullptr;  bool pixel_mask_ready = false, pixel_mask_on = true;   // two-phase engine: primary-ray candidates per band pixel
   std::vector<uint32_t> prog_order;         // two-phase engine: scene index of the object in filter-program slot k (the bit positions of the masks)
+  std::vector<DevPlane> host_planes;        // ... and its plane records (pixel_mask_kernel's wave-uniform tests are made on the host)
   float pixel_mask_ms = 0;                  // duration of pixel_mask_kernel (amber_hip_kat_pixel_masks)
-  uint32_t lens_kind = 0; float lens_sensor_distance = 0, lens_focus_distance = 0;   // host copies of the lens constants pixel_mask_kernel's arguments derive from
+  uint32_t lens_kind = 0; float lens_sensor_distance = 0, lens_focus_distance = 0, lens_origin[3] = {0, 0, 0};   // host copies of the lens constants pixel_mask_kernel's arguments derive from
   float aperture_rect[4][3] = {};           // world corners of the blades' bounding rectangle in the lens plane (pixel_mask_kernel)
   int n_cus = 256;
   uint32_t row_begin = 0, row_end = 0, stripe_rows = 0, stripe_period = 0, local_rows = 0;
@@ -1223,6 +1224,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
                  fprog.planes.size(), shared, pairs, singles, fprog.spheres.size(), fprog.always_mask);
   }
   h->prog_order = fprog.order;
+  h->host_planes = fprog.planes;
   for (uint32_t i = 0; i < L.n_blades; i++)            // filter-program slot of every aperture blade (self-candidate trip)
     for (uint32_t k = 0; k < fprog.n_prog_tris; k++)
       if (fprog.order[k] == L.first_blade_object + i) blades[i].slot = static_cast<int32_t>(k);
@@ -1367,6 +1369,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   lens.n_blades = L.n_blades; lens.n_blades_f = static_cast<float>(L.n_blades);
   lens.kind = L.kind;
   h->lens_kind = L.kind; h->lens_sensor_distance = L.sensor_distance; h->lens_focus_distance = L.focus_distance;
+  for (int c = 0; c < 3; c++) h->lens_origin[c] = L.origin[c];
   { volatile float area = sensor->scene_width * sensor->scene_height; volatile float inv = 1.0f / area; lens.inv_scene_area = inv; }
   sc.sensor.w = sensor->width; sc.sensor.h = sensor->height;
   sc.sensor.wf = static_cast<float>(sensor->width); sc.sensor.hf = static_cast<float>(sensor->height);
@@ -1564,6 +1567,24 @@ int EnsurePixelMasks(amber_hip_pt* h, uint32_t n_pixels, bool timed) {
   pm.focal_scale = h->lens_kind == 1u ? -(8.0 * static_cast<double>(h->scene.fp_reach) + 1.0) / static_cast<double>(h->lens_sensor_distance)
                                       : static_cast<double>(h->lens_focus_distance) / -static_cast<double>(h->lens_sensor_distance);
   pm.row_begin = h->row_begin; pm.stripe_rows = h->stripe_rows; pm.stripe_period = h->stripe_period; pm.n_pixels = n_pixels;
+  {
+    // "does plane i cut the aperture rectangle?" -- the kernel's own expressions (binary64, the slack of its first lines), evaluated once
+    const DevScene& sc = h->scene;
+    const double cx = sc.fp_center[0], cy = sc.fp_center[1], cz = sc.fp_center[2], reach = sc.fp_reach;
+    const double world_mag = std::max(std::max(std::fabs(cx), std::max(std::fabs(cy), std::fabs(cz))) + reach,
+                                      std::max(std::fabs(double(h->lens_origin[0])), std::max(std::fabs(double(h->lens_origin[1])), std::fabs(double(h->lens_origin[2])))));
+    const double slack = 1e-5 * reach + 32.0 * 5.9604644775390625e-08 * world_mag;
+    pm.planes_cut_a = h->host_planes.size() > 32 ? 0xffffffffu : 0u;
+    for (size_t i = 0; i < h->host_planes.size() && i < 32; i++) {
+      const DevPlane& q = h->host_planes[i];
+      bool above = true, below = true;
+      for (int k = 0; k < 4; k++) {
+        const double sa = double(q.n[0]) * pm.ap[k][0] + double(q.n[1]) * pm.ap[k][1] + double(q.n[2]) * pm.ap[k][2] - double(q.d0);
+        above = above && sa > 10.0 * slack; below = below && sa < -10.0 * slack;
+      }
+      if (!(above || below)) pm.planes_cut_a |= 1u << i;
+    }
+  }
   struct Events { hipEvent_t a = nullptr, b = nullptr; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evs;
   if (timed) { HIP_TRY(hipEventCreate(&evs.a)); HIP_TRY(hipEventCreate(&evs.b)); HIP_TRY(hipEventRecord(evs.a, h->stream)); }
   hipLaunchKernelGGL(pixel_mask_kernel, dim3((n_pixels + 15u) / 16u), dim3(256), 0, h->stream, h->scene, pm, h->d_pixel_mask);   // 16 lanes per pixel
