@@ -619,6 +619,9 @@ __device__ __forceinline__ void ClosestHitList(const DevScene& sc, V3 o, V3 d, H
 //  only, object records gathered from the LDS copy; the (t, index) tie rule makes the visiting order irrelevant.
 //  The result is identical to ClosestHitList (tests: full-image and per-ray equality of both engines).
 #define AMBER_GRAZING 1e-3f
+#ifndef AMBER_SHARED_WEIGHT_QUOTIENT
+#define AMBER_SHARED_WEIGHT_QUOTIENT 1
+#endif
 __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const DevObject* lds_objects, V3 o_world, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM,
                                                    const bool use_premask = false, const uint32_t premask = 0u) {
   best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;
@@ -1541,7 +1544,25 @@ __device__ __forceinline__ bool PathShade(const DevScene& sc, const DevObject* l
   if (sc.max_depth && casts >= sc.max_depth) return false;                   // build-side extension (BASELINE config 5)
   o = pos; d = dir_in;                                                       // :155 Ray(pos, UnitVector3) -- no renormalisation
   origin_slot = (kEngine == ENGINE_TWO_PHASE && static_cast<uint32_t>(h.slot) < sc.n_prog_tris) ? h.slot : -1;
+#if AMBER_SHARED_WEIGHT_QUOTIENT
+  {
+    // :156  weight *= scatter.Weight() / p -- three binary32 divisions by the same p.  A component of the scatter weight that has the
+    // bits of the first one has the first one's quotient, and +0 / p is +0 (p > 0 here: a path with p = 0 has ended above): grey, white,
+    // mirror, glass and single-channel materials need ONE division.  The other two run only if some lane of the wave holds a weight
+    // that is neither (wave-uniform branch; the same IEEE quotients either way).
+    const uint32_t bx = __float_as_uint(sw.x), by = __float_as_uint(sw.y), bz = __float_as_uint(sw.z);
+    const float qx = sw.x / p_rr;
+    float qy = by == bx ? qx : 0.0f, qz = bz == bx ? qx : 0.0f;
+    const bool hard_y = !(by == bx || (by == 0u && p_rr > 0.0f)), hard_z = !(bz == bx || (bz == 0u && p_rr > 0.0f));
+    if (__ballot(hard_y || hard_z) != 0ull) {
+      if (hard_y) qy = sw.y / p_rr;
+      if (hard_z) qz = sw.z / p_rr;
+    }
+    weight = weight * v3(qx, qy, qz);
+  }
+#else
   weight = weight * (sw / p_rr);                                             // :156
+#endif
   return true;
 }
 
