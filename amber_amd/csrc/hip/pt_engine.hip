@@ -674,6 +674,9 @@ __global__ void __launch_bounds__(256) pixel_mask_kernel(const DevScene sc, cons
 // hit resolution, material sampling, Russian roulette, regeneration -- starts their next rays and resumes.  Lanes
 // never wait for more than a batch to fill; results do not depend on the schedule (paths are independent and a
 // lane's samples are still summed in order).
+#ifndef AMBER_BVH_SUM_IN_LDS
+#define AMBER_BVH_SUM_IN_LDS 1
+#endif
 #ifndef AMBER_BVH_SHADE_BATCH
 #define AMBER_BVH_SHADE_BATCH 52   // config 3 at 128 spp, one process (descent budget 5): 24 -> 173 ms, 32 -> 172, 40 -> 166, 48 -> 162, 52 -> 160, 56 -> 160.5, 60 -> 164, 64 (wait for all lanes) -> 181
 #endif
@@ -689,12 +692,21 @@ __global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
   __shared__ int32_t lds_stack[kStack * 256];
+#if AMBER_BVH_SUM_IN_LDS
+  // the item's running sum is touched once per PATH (2.6 rays): it lives in LDS ([component][thread]: conflict-free), not in three of
+  // the 96 registers the traversal loop is short of -- the compiler used to keep it in scratch
+  __shared__ float lds_sum[6 * 256];                       // rows 0-2: the item's sum; rows 3-5: the measurement of the path in flight.  (Two more rows for y, z of the
+                                                           // throughput -- what the compiler spills next -- make 32 KB per workgroup: five no longer fit a CU, 113 ms instead of 101 at 128 spp)
+  float* const my_sum = lds_sum + threadIdx.x;
+#endif
 
   uint32_t pool_next = 0, pool_end = 0;
   bool exhausted = false;
   bool lane_done = false, have_item = false, alive = false, traversing = false;
   uint32_t s = 0, s_end = 0, pixel = 0, slot = 0;          // the pixel's x, y are recomputed where a path starts: two registers less
+#if !AMBER_BVH_SUM_IN_LDS
   V3 sum = v3(0.f, 0.f, 0.f), meas = v3(0.f, 0.f, 0.f);
+#endif
   V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), w = v3(0.f, 0.f, 0.f);
   uint64_t rng = 1;
   uint32_t casts = 0;
@@ -717,7 +729,11 @@ __global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4
     if (need && have_item) {                                // item finished: publish its sum
       if (!kLight) {
         float* p = a.partial + static_cast<size_t>(slot) * 3u;
+#if AMBER_BVH_SUM_IN_LDS
+        p[0] = my_sum[0]; p[1] = my_sum[256]; p[2] = my_sum[512];
+#else
         p[0] = sum.x; p[1] = sum.y; p[2] = sum.z;
+#endif
       }
       have_item = false;
     }
@@ -747,7 +763,11 @@ __global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4
         s = a.first_sample + chunk * AMBER_ACCUM_CHUNK;
         const uint32_t left = a.first_sample + a.n_samples - s;
         s_end = s + (left < AMBER_ACCUM_CHUNK ? left : AMBER_ACCUM_CHUNK);
+#if AMBER_BVH_SUM_IN_LDS
+        my_sum[0] = 0.f; my_sum[256] = 0.f; my_sum[512] = 0.f;
+#else
         sum = v3(0.f, 0.f, 0.f);
+#endif
         have_item = true;
         need = false;
       }
@@ -770,7 +790,11 @@ __global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4
         GenerateEyeRay(sc, pixel - py * sc.sensor.w, py, rng, o, d, ew, origin_slot);
         w = v3(ew, ew, ew);
       }
+#if AMBER_BVH_SUM_IN_LDS
+      my_sum[768] = 0.f; my_sum[1024] = 0.f; my_sum[1280] = 0.f;
+#else
       meas = v3(0.f, 0.f, 0.f);
+#endif
       casts = 0;
       alive = true;
       ++s;
@@ -794,6 +818,9 @@ __global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4
     AMBER_CLK(6);
     rays_wave += static_cast<uint32_t>(__popcll(__ballot(alive && !traversing)));
     if (alive && !traversing) {                             // shade the lanes whose closest hit is known
+#if AMBER_BVH_SUM_IN_LDS
+      V3 meas = v3(my_sum[768], my_sum[1024], my_sum[1280]);  // the measurement is read and written once per bounce: LDS, not registers held across the traversal
+#endif
       if (kLight) {
         const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, pixel, s - 1u, sc.sensor.size_f};
         alive = PathShade<false, ENGINE_BVH, true>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_SHADE_STAMP_ARG, &sink);
@@ -810,8 +837,15 @@ __global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4
       } else {
         alive = PathShade<false, ENGINE_BVH, false>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_SHADE_STAMP_ARG, nullptr);
       }
+#if AMBER_BVH_SUM_IN_LDS
+      if (alive) { my_sum[768] = meas.x; my_sum[1024] = meas.y; my_sum[1280] = meas.z; }
+#endif
       if (alive) { BvhBegin(sc, o, d, tr, hit); traversing = true; }
+#if AMBER_BVH_SUM_IN_LDS
+      else { my_sum[0] = my_sum[0] + meas.x; my_sum[256] = my_sum[256] + meas.y; my_sum[512] = my_sum[512] + meas.z; }   // sequential sum over the item's samples
+#else
       else sum = sum + meas;                                // sequential sum over the item's samples
+#endif
     }
     AMBER_CLK(5);
   }
