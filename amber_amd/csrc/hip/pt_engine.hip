@@ -1235,6 +1235,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     bvh = amber_bvh::BuildBvh(objs);
     if (bvh.depth > static_cast<uint32_t>(amber_bvh::kMaxDepth)) { amber_hip_pt_destroy(h); return Fail(AMBER_EINVAL, "BVH deeper than the device stack"); }
     h->bvh_depth = bvh.depth;
+    if (std::getenv("AMBER_DEBUG_BVH")) std::fprintf(stderr, "amber_hip: BVH of %u objects: %zu nodes, depth %u\n", s->n_objects, bvh.nodes.size(), bvh.depth);
   }
   amber_filter::FilterProgram fprog;
   float fp_center[3] = {0, 0, 0}, fp_reach = 0;
