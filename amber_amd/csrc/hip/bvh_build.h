@@ -226,7 +226,7 @@ struct FlatBvh {
 
 // The tree the device traverses (DevBvhNodeQ): child boxes on a 16-bit grid over the bounds of all node boxes, min planes
 // rounded down and max planes up (checked in exact arithmetic: gmin and step are binary32, q * step and the sum are exact
-// in binary64), leaf references re-encoded as first*8 + all_spheres*4 + count.
+// in binary64), leaf references re-encoded as first*16 + all_triangles*8 + all_spheres*4 + count.
 struct QuantizedBvh {
   std::vector<DevBvhNodeQ> nodes;
   float gmin[3] = {0, 0, 0}, step[3] = {1, 1, 1}, reach[3] = {0, 0, 0};   // plane = gmin + value * step ; reach >= |value * step| for every stored value
@@ -303,19 +303,21 @@ inline uint32_t EmptyPlaneWord() {                            // min above max: 
   return 0x0000ffffu;                                         // min 65535, max 0
 #endif
 }
-template <typename IsSphere>
-inline int32_t QuantizedLeafRef(int32_t ref, IsSphere is_sphere_slot) {
+// Device leaf reference: -(ref + 1) = first * 16 + all_triangles * 8 + all_spheres * 4 + count (count <= 3; first < 2^27).
+// `kind_of_slot(slot)` = primitive kind of the object in leaf-order slot `slot` (0 triangle, 1 sphere, ...).
+template <typename KindOfSlot>
+inline int32_t QuantizedLeafRef(int32_t ref, KindOfSlot kind_of_slot) {
   if (ref >= 0) return ref;
   const uint32_t r = static_cast<uint32_t>(-(ref + 1));
   const uint32_t first = r >> 3, count = r & 7u;
-  bool all = count > 0;
-  for (uint32_t k = 0; k < count; k++) all = all && is_sphere_slot(first + k);
-  return -static_cast<int32_t>(first * 8u + (all ? 4u : 0u) + count) - 1;
+  bool spheres = count > 0, tris = count > 0;
+  for (uint32_t k = 0; k < count; k++) { const uint32_t kind = kind_of_slot(first + k); spheres = spheres && kind == 1u; tris = tris && kind == 0u; }
+  return -static_cast<int32_t>(first * 16u + (tris ? 8u : 0u) + (spheres ? 4u : 0u) + count) - 1;
 }
-template <typename IsSphere>
-inline QuantizedBvh QuantizeBvh(const std::vector<DevBvhNode>& bin, int32_t root_ref, IsSphere is_sphere_slot) {
+template <typename KindOfSlot>
+inline QuantizedBvh QuantizeBvh(const std::vector<DevBvhNode>& bin, int32_t root_ref, KindOfSlot kind_of_slot) {
   QuantizedBvh out;
-  out.root_ref = QuantizedLeafRef(root_ref, is_sphere_slot);
+  out.root_ref = QuantizedLeafRef(root_ref, kind_of_slot);
   if (bin.empty()) return out;
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   auto child_box = [](const DevBvhNode& nd, int side, float mn[3], float mx[3]) {
@@ -352,8 +354,8 @@ inline QuantizedBvh QuantizeBvh(const std::vector<DevBvhNode>& bin, int32_t root
       float mn[3], mx[3]; child_box(nd, side, mn, mx);
       for (int c = 0; c < 3; c++) q.w[3 * side + c] = PlaneWord(mn[c], mx[c], out.gmin[c], out.step[c]);   // one word per axis: min | max << 16
     }
-    q.left = QuantizedLeafRef(nd.left, is_sphere_slot);
-    q.right = QuantizedLeafRef(nd.right, is_sphere_slot);
+    q.left = QuantizedLeafRef(nd.left, kind_of_slot);
+    q.right = QuantizedLeafRef(nd.right, kind_of_slot);
   }
   return out;
 }
@@ -366,10 +368,10 @@ struct QuantizedBvh4 {
   int32_t root_ref = -1;
   uint32_t depth = 0;
 };
-template <typename IsSphere>
-inline QuantizedBvh4 CollapseBvh4(const std::vector<DevBvhNode>& bin, int32_t root_ref, const QuantizedBvh& grid, IsSphere is_sphere_slot) {
+template <typename KindOfSlot>
+inline QuantizedBvh4 CollapseBvh4(const std::vector<DevBvhNode>& bin, int32_t root_ref, const QuantizedBvh& grid, KindOfSlot kind_of_slot) {
   QuantizedBvh4 out;
-  out.root_ref = QuantizedLeafRef(root_ref, is_sphere_slot);
+  out.root_ref = QuantizedLeafRef(root_ref, kind_of_slot);
   if (bin.empty() || root_ref < 0) return out;
   struct Kid { int32_t ref; float mn[3], mx[3]; };
   auto kids_of = [&](int32_t node, Kid k[2]) {
@@ -409,7 +411,7 @@ inline QuantizedBvh4 CollapseBvh4(const std::vector<DevBvhNode>& bin, int32_t ro
         todo.push_back(Job{kid[i].ref, idx, job.depth + 1});
         q.child[i] = static_cast<int32_t>(idx);
       } else {
-        q.child[i] = QuantizedLeafRef(kid[i].ref, is_sphere_slot);
+        q.child[i] = QuantizedLeafRef(kid[i].ref, kind_of_slot);
       }
     }
     out.nodes[job.me] = q;

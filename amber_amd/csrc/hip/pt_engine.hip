@@ -1033,6 +1033,7 @@ struct amber_hip_pt {
   DevBvhNodeQ* d_bvh_nodes = nullptr;
   DevBvhNodeQ4* d_bvh_nodes4 = nullptr;      // AMBER_BVH_WIDE builds only
   float4* d_bvh_spheres = nullptr;
+  float4* d_bvh_tris = nullptr;
   uint32_t* d_bvh_prims = nullptr;
   DevObject* d_bvh_objects = nullptr;
   bool two_phase = false;
@@ -1106,7 +1107,7 @@ struct DevBuf {
 int ValidateScene(const AmberFlatScene* s, const AmberSensor* sensor) {
   if (!s || !sensor) return Fail(AMBER_EINVAL, "null scene or sensor");
   if (!s->objects || s->n_objects == 0) return Fail(AMBER_EINVAL, "scene has no objects");
-  if (s->n_objects >= (1u << 28)) return Fail(AMBER_EINVAL, "too many objects (BVH leaf references hold 28-bit offsets)");
+  if (s->n_objects >= (1u << 27)) return Fail(AMBER_EINVAL, "too many objects (BVH leaf references hold 27-bit offsets)");
   if (!s->materials || s->n_materials == 0) return Fail(AMBER_EINVAL, "scene has no materials");
   if (sensor->width == 0 || sensor->height == 0) return Fail(AMBER_EINVAL, "empty sensor");
   if (static_cast<uint64_t>(sensor->width) * sensor->height >= (1ull << 32)) return Fail(AMBER_EINVAL, "sensor too large");
@@ -1297,13 +1298,13 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMalloc(&h->d_lights, (lights.size() + 1) * sizeof(DevLight)));
   if (!lights.empty()) HIP_TRY_H(hipMemcpy(h->d_lights, lights.data(), lights.size() * sizeof(DevLight), hipMemcpyHostToDevice));
   // engine BVH: quantised nodes, leaf-order permutation, object records and compact sphere records in leaf order
-  amber_bvh::QuantizedBvh qbvh = amber_bvh::QuantizeBvh(bvh.nodes, bvh.root_ref, [&](uint32_t slot) { return (objs[bvh.prim_index[slot]].kind & 0xffu) == AMBER_PRIM_SPHERE; });
+  amber_bvh::QuantizedBvh qbvh = amber_bvh::QuantizeBvh(bvh.nodes, bvh.root_ref, [&](uint32_t slot) { return objs[bvh.prim_index[slot]].kind & 0xffu; });
   HIP_TRY_H(hipMalloc(&h->d_bvh_nodes, (qbvh.nodes.size() + 1) * sizeof(DevBvhNodeQ)));
   HIP_TRY_H(hipMalloc(&h->d_bvh_prims, (bvh.prim_index.size() + 1) * sizeof(uint32_t)));
   if (!qbvh.nodes.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_nodes, qbvh.nodes.data(), qbvh.nodes.size() * sizeof(DevBvhNodeQ), hipMemcpyHostToDevice));
 #if AMBER_BVH_WIDE
   {
-    amber_bvh::QuantizedBvh4 q4 = amber_bvh::CollapseBvh4(bvh.nodes, bvh.root_ref, qbvh, [&](uint32_t slot) { return (objs[bvh.prim_index[slot]].kind & 0xffu) == AMBER_PRIM_SPHERE; });
+    amber_bvh::QuantizedBvh4 q4 = amber_bvh::CollapseBvh4(bvh.nodes, bvh.root_ref, qbvh, [&](uint32_t slot) { return objs[bvh.prim_index[slot]].kind & 0xffu; });
     HIP_TRY_H(hipMalloc(&h->d_bvh_nodes4, (q4.nodes.size() + 1) * sizeof(DevBvhNodeQ4)));
     if (!q4.nodes.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_nodes4, q4.nodes.data(), q4.nodes.size() * sizeof(DevBvhNodeQ4), hipMemcpyHostToDevice));
     qbvh.root_ref = q4.root_ref;
@@ -1318,6 +1319,20 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
       leaf_order[k] = ob;
       leaf_spheres[k] = (ob.kind & 0xffu) == AMBER_PRIM_SPHERE ? make_float4(ob.a[0], ob.a[1], ob.a[2], ob.radius) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // compact triangle records of the leaves (IntersectTriangleLeaf): three float4 per leaf-order slot, only when the scene has triangles
+    bool any_tri = false;
+    for (const DevObject& ob : leaf_order) any_tri = any_tri || (ob.kind & 0xffu) == AMBER_PRIM_TRIANGLE;
+    std::vector<float4> leaf_tris(any_tri ? 3 * leaf_order.size() : 0);
+    for (size_t k = 0; any_tri && k < leaf_order.size(); k++) {
+      const DevObject& ob = leaf_order[k];
+      if ((ob.kind & 0xffu) != AMBER_PRIM_TRIANGLE) { leaf_tris[3 * k] = leaf_tris[3 * k + 1] = leaf_tris[3 * k + 2] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+      float idx; const uint32_t scene_index = bvh.prim_index[k]; std::memcpy(&idx, &scene_index, 4);
+      leaf_tris[3 * k] = make_float4(ob.a[0], ob.a[1], ob.a[2], ob.e1[0]);
+      leaf_tris[3 * k + 1] = make_float4(ob.e1[1], ob.e1[2], ob.e2[0], ob.e2[1]);
+      leaf_tris[3 * k + 2] = make_float4(ob.e2[2], idx, 0.f, 0.f);
+    }
+    HIP_TRY_H(hipMalloc(&h->d_bvh_tris, (leaf_tris.size() + 3) * sizeof(float4)));
+    if (!leaf_tris.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_tris, leaf_tris.data(), leaf_tris.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY_H(hipMalloc(&h->d_bvh_objects, (leaf_order.size() + 1) * sizeof(DevObject)));
     HIP_TRY_H(hipMalloc(&h->d_bvh_spheres, (leaf_spheres.size() + 1) * sizeof(float4)));
     if (!leaf_order.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_objects, leaf_order.data(), leaf_order.size() * sizeof(DevObject), hipMemcpyHostToDevice));
@@ -1343,7 +1358,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades;
   sc.planes = h->d_planes; sc.tri_filters = h->d_tri_filters; sc.sphere_filters = h->d_sphere_filters;
   sc.n_planes = static_cast<uint32_t>(fprog.planes.size()); sc.n_simple_planes = fprog.n_simple_planes; sc.n_sphere_filters = static_cast<uint32_t>(fprog.spheres.size());
-  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_nodes4 = h->d_bvh_nodes4; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_spheres = h->d_bvh_spheres; sc.bvh_root = qbvh.root_ref;
+  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_nodes4 = h->d_bvh_nodes4; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_spheres = h->d_bvh_spheres; sc.bvh_tris = h->d_bvh_tris; sc.bvh_root = qbvh.root_ref;
   for (int c = 0; c < 3; c++) { sc.bvh_gmin[c] = qbvh.gmin[c]; sc.bvh_step[c] = qbvh.step[c]; sc.bvh_reach[c] = qbvh.reach[c]; }
   {
     // per-ray box margin of engine BVH (BvhBegin): centre and half diagonal of the scene bounds, 1 / smallest sphere radius
@@ -2054,6 +2069,7 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_bvh_nodes) (void)hipFree(h->d_bvh_nodes);
   if (h->d_bvh_nodes4) (void)hipFree(h->d_bvh_nodes4);
   if (h->d_bvh_spheres) (void)hipFree(h->d_bvh_spheres);
+  if (h->d_bvh_tris) (void)hipFree(h->d_bvh_tris);
   if (h->d_bvh_prims) (void)hipFree(h->d_bvh_prims);
   if (h->d_bvh_objects) (void)hipFree(h->d_bvh_objects);
   if (h->d_wf) (void)hipFree(h->d_wf);
