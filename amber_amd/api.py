@@ -71,7 +71,7 @@ class HostStats(C.Structure):
 PRIM_TRIANGLE, PRIM_SPHERE, PRIM_DISK, PRIM_CYLINDER = 0, 1, 2, 3
 MAT_LAMBERTIAN, MAT_PHONG, MAT_SPECULAR, MAT_REFRACTION, MAT_DIFFUSE_LIGHT, MAT_EYE = 0, 1, 2, 3, 4, 5
 ENGINE_AUTO, ENGINE_LIST, ENGINE_TWO_PHASE, ENGINE_BVH, ENGINE_WAVEFRONT = 0, 1, 2, 3, 4
-PT_FLAG_NULL_STREAM, PT_FLAG_BVH_POOL = 1, 2
+PT_FLAG_NULL_STREAM, PT_FLAG_BVH_POOL, PT_FLAG_BVH_ITEMS = 1, 2, 4
 
 # every symbol include/amber_hip.h and include/amber_host.h declare
 ABI_SYMBOLS = [

@@ -1215,10 +1215,10 @@ __device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack,
   return BvhRoundOn(sc, stack, o, d, tr, best AMBER_STAMP_ARG);
 }
 
-__device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, HitRec& best) {
+__device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, HitRec& best, const int stack_cap = AMBER_BVH_STACK) {
   BvhTrav tr;
   BvhBegin(sc, o, d, tr, best);
-  while (BvhRound(sc, lds_stack, o, d, tr, best)) {}
+  while (BvhRound(sc, lds_stack, o, d, tr, best, stack_cap)) {}
   if (__any(tr.overflow)) { if (tr.overflow) ClosestHitLeafList(sc, o, d, best); }
   BvhResolveIndex(sc, best);                                       // callers of this form report the object
 }
@@ -1227,9 +1227,9 @@ enum { ENGINE_LIST = 1, ENGINE_TWO_PHASE = 2, ENGINE_BVH = 3 };
 
 template <int kEngine>
 __device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3 o, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM,
-                                           const bool use_premask = false, const uint32_t premask = 0u) {
+                                           const bool use_premask = false, const uint32_t premask = 0u, const int bvh_stack_cap = AMBER_BVH_STACK) {
   if (kEngine == ENGINE_TWO_PHASE) ClosestHitTwoPhase(sc, lds_objects, o, d, origin_slot, best AMBER_STAMP_ARG, use_premask, premask);
-  else if (kEngine == ENGINE_BVH) ClosestHitBvh(sc, lds_stack, o, d, best);
+  else if (kEngine == ENGINE_BVH) ClosestHitBvh(sc, lds_stack, o, d, best, bvh_stack_cap);
   else ClosestHitList(sc, o, d, best);
   AMBER_STAMP(3);
 }
@@ -1553,9 +1553,9 @@ __device__ __forceinline__ bool PathShade(const DevScene& sc, const DevObject* l
 template <bool kTrace, int kEngine, bool kLight = false>
 __device__ __forceinline__ bool PathStep(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3& o, V3& d, V3& weight, V3& measurement,
                                          uint64_t& rng, uint32_t& casts, int& origin_slot, Bounce* trace AMBER_STAMP_PARAM, const SplatSink* sink = nullptr,
-                                         const bool use_premask = false, const uint32_t premask = 0u) {
+                                         const bool use_premask = false, const uint32_t premask = 0u, const int bvh_stack_cap = AMBER_BVH_STACK) {
   HitRec h;
-  ClosestHit<kEngine>(sc, lds_objects, lds_stack, o, d, origin_slot, h AMBER_STAMP_ARG, use_premask, premask);
+  ClosestHit<kEngine>(sc, lds_objects, lds_stack, o, d, origin_slot, h AMBER_STAMP_ARG, use_premask, premask, bvh_stack_cap);
   return PathShade<kTrace, kEngine, kLight>(sc, lds_objects, h, o, d, weight, measurement, rng, casts, origin_slot, trace AMBER_STAMP_ARG, sink);
 }
 

@@ -181,14 +181,25 @@ __device__ __forceinline__ void CloseRecords(const RenderArgs& a, uint32_t rec_n
 // {casts | carried-flag, origin slot, signature hashes}.
 template <bool kLight> struct PoolLayout { static constexpr int kChunks = 4; };
 
+// Traversal-stack entries of pt_megakernel<ENGINE_BVH> (a deeper tree renders with pt_bvh_megakernel): 12 KB of LDS next to the 16-KB
+// pool, five workgroups per CU (16 entries: four).  Where the two schedulers cross over (tools/mesh_workloads.py, 1024^2 @ 256 spp, a room
+// with a tessellated ball): Cornell's tree of depth 6, 30.7 ms against 44.2 for pt_bvh_megakernel; 1.3 k triangles, depth 12: 52.7 against
+// 54.7; 5 k triangles, depth 14 (built with 16 entries): 64.9 against 57.6 -- beyond depth 12 the resumable item kernel wins.
+#ifndef AMBER_PATH_BVH_STACK
+#define AMBER_PATH_BVH_STACK 12
+#endif
 template <int kEngine, bool kLight = false, bool kSig = false>
-__global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megakernel(const RenderArgs a) {
+__global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 5 : AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megakernel(const RenderArgs a) {
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
   constexpr bool kTwoPhase = kEngine == ENGINE_TWO_PHASE;
   constexpr int kChunks = PoolLayout<kLight>::kChunks;
   __shared__ DevObject lds_objects[kTwoPhase ? AMBER_MAX_LDS_OBJECTS : 1];
   __shared__ uint4 lds_pool[4][64 * kChunks];                 // [wave][slot * kChunks + chunk]
+  // engine BVH on a SHALLOW tree (mid-size scenes, RenderPassPaths): the closest hit is one uninterrupted per-lane traversal (ClosestHitBvh),
+  // its stack [level][thread] in LDS -- a few dozen node visits differ little between the lanes of a wave, so nothing has to be resumable,
+  // and the path-granular scheduling above (coherent primary rounds, no lane waits for a shading batch) is what a small scene gains most from
+  __shared__ int32_t lds_stack[kEngine == ENGINE_BVH ? AMBER_PATH_BVH_STACK * 256 : 1];
   if (kTwoPhase) StageObjects(sc, lds_objects);
   const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, and the compiler knows it: what derives from it stays in SGPRs
   uint4* pool = lds_pool[wave_in_block];
@@ -339,15 +350,15 @@ __global__ void __launch_bounds__(256, AMBER_MEGAKERNEL_WAVES_PER_SIMD) pt_megak
       if (kLight) {
         const uint32_t plocal = q / a.n_samples;
         const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, a.path_offset + plocal, a.first_sample + (q - plocal * a.n_samples), sc.sensor.size_f};
-        alive = PathStep<false, kEngine, true>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, &sink);
+        alive = PathStep<false, kEngine, true>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, &sink, false, 0u, AMBER_PATH_BVH_STACK);
       } else if (kSig) {
         Bounce b;
-        alive = PathStep<true, kEngine>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, &b AMBER_STAMP_ARG, nullptr, primary, premask);
+        alive = PathStep<true, kEngine>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, origin_slot, &b AMBER_STAMP_ARG, nullptr, primary, premask, AMBER_PATH_BVH_STACK);
         sig_obj = Fnv32(sig_obj, static_cast<uint32_t>(b.object));
         if (b.object >= 0) sig_t = Fnv32(sig_t, __float_as_uint(b.t));
         if (!alive) a.sig[q] = static_cast<unsigned long long>(sig_obj) | (static_cast<unsigned long long>(sig_t) << 32);
       } else {
-        alive = PathStep<false, kEngine>(sc, lds_objects, nullptr, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, nullptr, primary, premask);
+        alive = PathStep<false, kEngine>(sc, lds_objects, lds_stack, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_STAMP_ARG, nullptr, primary, premask, AMBER_PATH_BVH_STACK);
       }
       if (!kLight) {
         const bool nz = (__float_as_uint(meas.x) | __float_as_uint(meas.y) | __float_as_uint(meas.z)) != 0u;   // anything but +0 (RGB)
@@ -1051,6 +1062,7 @@ struct amber_hip_pt {
   float* d_partial = nullptr;               // pt_bvh_megakernel: per-item sums
   size_t partial_floats = 0;
   bool bvh_pool = false;                    // engine BVH renders with pt_bvh_pool_kernel (AMBER_PT_FLAG_BVH_POOL / AMBER_BVH_POOL=1) instead of pt_bvh_megakernel
+  bool bvh_paths = false;                   // engine BVH on a shallow tree (depth <= AMBER_PATH_BVH_STACK): pt_megakernel<ENGINE_BVH>, the path-granular scheduler (AMBER_BVH_PATHS=0/1 overrides)
   // path-granular accumulation (RenderPassPaths): bitmap, records in arrival order, measurements in path order, ranks
   uint32_t* d_flags = nullptr;  size_t flag_words = 0;   bool flags_dirty = true;   // dirty: must be cleared before the next launch
   uint32_t* d_touched = nullptr; size_t touched_words = 0;
@@ -1236,6 +1248,9 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     bvh = amber_bvh::BuildBvh(objs);
     if (bvh.depth > static_cast<uint32_t>(amber_bvh::kMaxDepth)) { amber_hip_pt_destroy(h); return Fail(AMBER_EINVAL, "BVH deeper than the device stack"); }
     h->bvh_depth = bvh.depth;
+    h->bvh_paths = !h->bvh_pool && !(params->reserved & AMBER_PT_FLAG_BVH_ITEMS) && h->engine != AMBER_ENGINE_WAVEFRONT && bvh.depth <= static_cast<uint32_t>(AMBER_PATH_BVH_STACK);
+    { const char* ev = std::getenv("AMBER_BVH_PATHS"); if (ev && ev[0] == '0') h->bvh_paths = false; }
+    { const char* ev = std::getenv("AMBER_BVH_PATHS_MAX_DEPTH"); if (ev && static_cast<uint32_t>(std::atoi(ev)) < bvh.depth) h->bvh_paths = false; }   // measurement hook
     if (std::getenv("AMBER_DEBUG_BVH")) std::fprintf(stderr, "amber_hip: BVH of %u objects: %zu nodes, depth %u\n", s->n_objects, bvh.nodes.size(), bvh.depth);
   }
   amber_filter::FilterProgram fprog;
@@ -1572,7 +1587,7 @@ constexpr uint64_t kMaxRecordSlots = 48ull << 20;         // 28 B per slot (reco
 uint32_t ClaimShift(uint32_t n_blocks) { uint32_t sh = 0; while ((1ull << sh) < static_cast<uint64_t>(n_blocks) * 4u) ++sh; return sh; }
 
 uint32_t PathBlocks(const amber_hip_pt* h, uint64_t n_paths) {
-  const bool bvh = h->hit_engine == AMBER_ENGINE_BVH;
+  const bool bvh = h->hit_engine == AMBER_ENGINE_BVH && !h->bvh_paths;
   uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * (bvh ? static_cast<uint32_t>(AMBER_BVH_POOL_WGS) : ResidentBlocksPerCu(h->hit_engine, h->bvh_depth));
   const uint64_t by_work = (n_paths + 255u) / 256u;
   if (by_work < n_blocks) n_blocks = static_cast<uint32_t>(by_work);
@@ -1646,7 +1661,7 @@ int EnsurePixelMasks(amber_hip_pt* h, uint32_t n_pixels, bool timed) {
 
 int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, unsigned long long* sig) {
   const uint64_t n_paths = static_cast<uint64_t>(n_pixels) * n;
-  const bool bvh = h->hit_engine == AMBER_ENGINE_BVH;
+  const bool bvh = h->hit_engine == AMBER_ENGINE_BVH && !h->bvh_paths;       // pt_bvh_pool_kernel (bvh_paths: pt_megakernel<ENGINE_BVH>)
   const size_t need_words = static_cast<size_t>((n_paths + 31u) / 32u) + 4u;
   if (need_words > h->flag_words) {
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1720,10 +1735,12 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
   HIP_TRY(hipEventRecord(ev.first, h->stream));
   if (sig) {
     if (bvh) hipLaunchKernelGGL((pt_bvh_pool_kernel<true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else if (h->bvh_paths) hipLaunchKernelGGL((pt_megakernel<ENGINE_BVH, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL((pt_megakernel<ENGINE_LIST, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
   } else {
     if (bvh) hipLaunchKernelGGL((pt_bvh_pool_kernel<false>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else if (h->bvh_paths) hipLaunchKernelGGL((pt_megakernel<ENGINE_BVH>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL((pt_megakernel<ENGINE_LIST>), dim3(n_blocks), dim3(256), 0, h->stream, a);
   }
@@ -1820,7 +1837,7 @@ int amber_hip_pt_render_pass(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
   const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
   if (n_pixels == 0) return AMBER_OK;                    // empty band
   if (h->engine == AMBER_ENGINE_WAVEFRONT) return RenderPassWavefront(h, first_sample, n_samples);
-  if (h->hit_engine != AMBER_ENGINE_BVH || h->bvh_pool) return RenderPassPaths(h, first_sample, n_samples, n_pixels);
+  if (h->hit_engine != AMBER_ENGINE_BVH || h->bvh_pool || h->bvh_paths) return RenderPassPaths(h, first_sample, n_samples, n_pixels);
   return RenderPassBvhItems(h, first_sample, n_samples, n_pixels, nullptr);
 }
 
@@ -2284,7 +2301,7 @@ int amber_hip_pt_signatures(amber_hip_pt* h, uint32_t first_sample, uint32_t n_s
   if (!h || !out || n_samples == 0) return Fail(AMBER_EINVAL, "bad argument");
   if (static_cast<uint64_t>(first_sample) + n_samples > 0xffffffffull) return Fail(AMBER_EINVAL, "sample index overflow");
   if (h->engine == AMBER_ENGINE_WAVEFRONT) return Fail(AMBER_EINVAL, "signatures come from the work-queue kernels (engines list, two_phase, bvh)");
-  const bool bvh_items = h->hit_engine == AMBER_ENGINE_BVH && !h->bvh_pool;        // pt_bvh_megakernel's signature instantiation
+  const bool bvh_items = h->hit_engine == AMBER_ENGINE_BVH && !h->bvh_pool && !h->bvh_paths;        // pt_bvh_megakernel's signature instantiation
   const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
   const uint64_t n = static_cast<uint64_t>(n_pixels) * n_samples;
   if (n == 0) return AMBER_OK;

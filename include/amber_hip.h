@@ -136,8 +136,11 @@ typedef struct {
 } AmberPtParams;
 enum {
   AMBER_PT_FLAG_NULL_STREAM = 1u,
-  AMBER_PT_FLAG_BVH_POOL = 2u     /* engine BVH: schedule with the per-wave ray pool (pt_bvh_pool_kernel) instead of the default
+  AMBER_PT_FLAG_BVH_POOL = 2u,    /* engine BVH: schedule with the per-wave ray pool (pt_bvh_pool_kernel) instead of the default
                                      (pt_bvh_megakernel).  Same results bit for bit; measured slower on the 1M-sphere scene. */
+  AMBER_PT_FLAG_BVH_ITEMS = 4u    /* engine BVH: always pt_bvh_megakernel.  By default a tree of depth <= 12 (scenes of a few hundred
+                                     objects) renders with the path-granular kernel and a one-shot per-lane traversal
+                                     (pt_megakernel<ENGINE_BVH>): same results bit for bit, faster on shallow trees. */
 };
 
 /* All engines are the same persistent work-queue kernel; they differ in how a lane finds its closest hit.

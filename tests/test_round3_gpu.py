@@ -40,7 +40,7 @@ def test_product_kernel_signatures_against_the_oracle(amber, cornell):
     W = H = 256
     rows, spp, seed = (100, 108), 64, 12345
     so = osc.path_signatures(W, H, seed, 0, spp, rows, threads=16)
-    for engine, flags in ((amber.ENGINE_TWO_PHASE, 0), (amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_POOL)):
+    for engine, flags in ((amber.ENGINE_TWO_PHASE, 0), (amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_ITEMS), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_POOL)):
         pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=seed, rows=rows, engine=engine, flags=flags)
         pt.render_pass(0, 8)                                           # state left by a render must not matter
         img0, rays0 = pt.download()
@@ -139,7 +139,7 @@ def test_path_records_when_most_paths_reach_a_light(amber):
     ref, cnt = osc.render_xorshift(W, H, 5, 0, spp)
     assert (ref.sum(axis=2) > 0).mean() > 0.9
     lit_paths = None
-    for engine, flags in ((amber.ENGINE_TWO_PHASE, 0), (amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_POOL),
+    for engine, flags in ((amber.ENGINE_TWO_PHASE, 0), (amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_ITEMS), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_POOL),
                           (amber.ENGINE_WAVEFRONT, 0)):
         pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=5, engine=engine, flags=flags)
         pt.render_pass(0, spp)
@@ -235,7 +235,7 @@ def test_bvh_pool_scheduler_is_bit_identical(amber):
         sc, _ = scene_for_seed(seed, scaled=bool(scaled), extreme=bool(extreme))
         hf = amber.HostScene.create(**sc)
         res = []
-        for eng, fl in ((amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, POOL)):
+        for eng, fl in ((amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_ITEMS), (amber.ENGINE_BVH, POOL)):
             pt = amber.PathTracer(hf, amber.Sensor.default(48, 40), seed=seed, engine=eng, flags=fl)
             pt.render_pass(0, 6); res.append(pt.download()); pt.close()
         for img, rays in res[1:]:
@@ -314,7 +314,7 @@ def test_fresh_fuzz_scenes(amber):
         sc, rng = scene_for_seed(seed, scaled=scaled, extreme=extreme)
         n_obj = len(sc["objects"]) + max(1, sc["n_blades"])
         hs = amber.HostScene.create(**sc)
-        engines = [(amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, POOL), (amber.ENGINE_WAVEFRONT, 0)] + ([(amber.ENGINE_TWO_PHASE, 0)] if n_obj <= 32 else [])
+        engines = [(amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_ITEMS), (amber.ENGINE_BVH, POOL), (amber.ENGINE_WAVEFRONT, 0)] + ([(amber.ENGINE_TWO_PHASE, 0)] if n_obj <= 32 else [])
         ref = None
         for e, fl in engines:
             pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=seed, engine=e, flags=fl)

@@ -33,10 +33,11 @@ for seed in range(first_seed, first_seed + n_scenes):
     sc, rng = scene_for_seed(seed, scaled=scaled, extreme=extreme)
     n_obj = len(sc["objects"]) + max(1, sc["n_blades"])
     hs = A.HostScene.create(**sc)
-    engines = [A.ENGINE_LIST, A.ENGINE_BVH, A.ENGINE_WAVEFRONT] + ([A.ENGINE_TWO_PHASE] if n_obj <= 32 else [])
+    # engine BVH twice: its default scheduler (pt_megakernel<ENGINE_BVH> on these shallow trees) and pt_bvh_megakernel (PT_FLAG_BVH_ITEMS)
+    engines = [(A.ENGINE_LIST, 0), (A.ENGINE_BVH, 0), (A.ENGINE_BVH, A.api.PT_FLAG_BVH_ITEMS), (A.ENGINE_WAVEFRONT, 0)] + ([(A.ENGINE_TWO_PHASE, 0)] if n_obj <= 32 else [])
     ref = None
-    for e in engines:
-        pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=seed, engine=e)
+    for e, fl in engines:
+        pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=seed, engine=e, flags=fl)
         pt.render_pass(0, spp)
         img, rays = pt.download(); pt.close()
         if ref is None:

@@ -26,7 +26,10 @@ def stamps(pt):
     return list(z)
 
 
-def run(label, hs, W, H, spp, engine=A.ENGINE_AUTO):
+def run(label, hs, W, H, spp, engine=A.ENGINE_AUTO, paths=None):
+    """paths: None = the library's choice; False / True = AMBER_BVH_PATHS=0 / unset (pt_bvh_megakernel against pt_megakernel<ENGINE_BVH> on shallow trees)"""
+    if paths is False: os.environ["AMBER_BVH_PATHS"] = "0"
+    else: os.environ.pop("AMBER_BVH_PATHS", None)
     t = time.time(); pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=1, engine=engine); t_create = time.time() - t
     pt.render_pass(0, 8); pt.sync(); pt.clear()
     base = stamps(pt) if COUNTERS else None
@@ -55,14 +58,18 @@ for name in names:
         hs = A.HostScene.cornell_box()
         spp = SPP or 256
         t2 = run("Cornell, two-phase (auto)", hs, 1024, 1024, spp, A.ENGINE_TWO_PHASE) if not COUNTERS else None
+        ti = run("Cornell, ENGINE_BVH, item kernel", hs, 1024, 1024, spp, A.ENGINE_BVH, paths=False)
         tb = run("Cornell, ENGINE_BVH", hs, 1024, 1024, spp, A.ENGINE_BVH)
-        if t2: print("      engine BVH / two-phase = %.2fx" % (tb / t2))
+        if t2: print("      engine BVH / two-phase = %.2fx (item kernel %.2fx)" % (tb / t2, ti / t2))
     else:
-        wl = WL.room_mesh(3) if name == "room_mesh" else (WL.terrain_mesh(16, 56) if name == "terrain" else WL.terrain_mesh(4, 56))
+        if name.startswith("room_mesh"): wl = WL.room_mesh(int(name[9:] or 3))
+        else: wl = WL.terrain_mesh(16, 56) if name == "terrain" else WL.terrain_mesh(int(name.split("_")[1]), int(name.split("_")[2]))
         d = tempfile.mkdtemp()
         t = time.time(); path = wl.write(d); t_w = time.time() - t
         t = time.time(); hs = A.HostScene.import_file(path); t_i = time.time() - t
         print("%s: %d triangles; OBJ written in %.1f s, imported in %.1f s" % (wl.name, wl.n_triangles, t_w, t_i), flush=True)
-        if name == "room_mesh": run(wl.name + " (engine auto = BVH)", hs, 1024, 1024, SPP or 256)
+        if name.startswith("room_mesh"):
+            run(wl.name + " (BVH, item kernel)", hs, 1024, 1024, SPP or 256, paths=False)
+            run(wl.name + " (engine auto = BVH)", hs, 1024, 1024, SPP or 256)
         else: run(wl.name + " (engine auto = BVH)", hs, 1920, 1080, SPP or 64)
     hs.close()

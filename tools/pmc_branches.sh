@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_${TAG}_branches
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_BRANCH SQ_IFETCH SQ_INSTS SQ_INST_CYCLES_SALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc" -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/stdout.log" 2>&1 || echo "pmc failed"
+rocprofv3 --pmc SQ_INSTS_BRANCH SQ_IFETCH SQ_INSTS SQ_INST_CYCLES_SALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc" -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/stdout.log" 2>&1 || echo "pmc failed"
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 tot = collections.defaultdict(float); n = collections.Counter()

@@ -12,12 +12,23 @@ for f in $OUT/pmc_*.log; do tail -n 1 $f; done | sort | uniq -c
 python3 - "$OUT" "$KERNEL" <<'PY'
 import csv, glob, sys, collections
 out, kern = sys.argv[1], sys.argv[2]
+import re
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
+names = {}
 for f in glob.glob(out + "/pmc_*/*/*_counter_collection.csv"):
     rows = [r for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
     ids = sorted({int(r["Dispatch_Id"]) for r in rows})
     for r in rows:
-        agg[r["Counter_Name"]][ids.index(int(r["Dispatch_Id"]))] += float(r["Counter_Value"])
+        i = ids.index(int(r["Dispatch_Id"]))
+        agg[r["Counter_Name"]][i] += float(r["Counter_Value"])
+        names[i] = re.sub(r"^.*?(pt_\w+?kernel)(<[^>]*>)?.*$", r"\1\2", r["Kernel_Name"])[:28]     # (the same script dispatches the same kernels in every pass)
 n = max(len(v) for v in agg.values())
-for k in sorted(agg): print("%-40s" % k + " ".join("%14.6g" % agg[k].get(i, float("nan")) for i in range(n)))
+print("%-40s" % "dispatch of" + " ".join("%28s" % names.get(i, "?") for i in range(n)))
+for k in sorted(agg): print("%-40s" % k + " ".join("%28.6g" % agg[k].get(i, float("nan")) for i in range(n)))
+d = {k: agg[k] for k in agg}
+def col(name, i): return d.get(name, {}).get(i, float("nan"))
+print("%-40s" % "lane utilisation (VALU)" + " ".join("%28.3f" % (col("SQ_THREAD_CYCLES_VALU", i) / (col("SQ_ACTIVE_INST_VALU", i) * 64)) for i in range(n)))
+print("%-40s" % "SQ_WAIT_ANY / SQ_WAVE_CYCLES" + " ".join("%28.3f" % (col("SQ_WAIT_ANY", i) / col("SQ_WAVE_CYCLES", i)) for i in range(n)))
+print("%-40s" % "SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES" + " ".join("%28.3f" % (col("SQ_WAIT_INST_ANY", i) / col("SQ_WAVE_CYCLES", i)) for i in range(n)))
+print("%-40s" % "SIMD cycles per VALU wave-instruction" + " ".join("%28.3f" % (col("SQ_ACTIVE_INST_VALU", i) * 4 / col("SQ_INSTS_VALU", i)) for i in range(n)))
 PY
