@@ -81,6 +81,7 @@ struct RenderArgs {
   uint32_t n_chunks, n_items;   // pt_bvh_megakernel: items = (pixel, chunk); path-granular kernels: n_items = paths of the launch
   uint32_t path_offset;      // light tracing: index of the first light path of this launch's range (amber_hip_lt_trace_range)
   uint32_t claim_shift;      // pt_megakernel: log2 of the grid's wave count rounded up to a power of two (tapered claims)
+  uint32_t shade_batch;      // pt_bvh_megakernel: lanes that must have finished their traversal before the wave shades (the handle's choice, BvhShadeBatch)
 };
 
 // FNV-1a-32 step over the four bytes of v (path signatures: amber_hip_kat_signatures, amber_hip_pt_signatures)
@@ -818,7 +819,7 @@ __global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4
     for (;;) {                                              // traversal rounds until a batch of lanes is ready to shade
       const unsigned long long tm = __ballot(traversing);
       if (tm == 0ull) break;
-      if (__popcll(__ballot(alive && !traversing)) >= AMBER_BVH_SHADE_BATCH) break;
+      if (static_cast<uint32_t>(__popcll(__ballot(alive && !traversing))) >= a.shade_batch) break;
       if (traversing) {
         AMBER_COUNT_ROUNDS(2);
         traversing = BvhRound(sc, lds_stack, o, d, tr, hit, kStack AMBER_STAMP_ARG);
@@ -1062,6 +1063,7 @@ struct amber_hip_pt {
   float* d_partial = nullptr;               // pt_bvh_megakernel: per-item sums
   size_t partial_floats = 0;
   bool bvh_pool = false;                    // engine BVH renders with pt_bvh_pool_kernel (AMBER_PT_FLAG_BVH_POOL / AMBER_BVH_POOL=1) instead of pt_bvh_megakernel
+  uint32_t bvh_shade_batch = AMBER_BVH_SHADE_BATCH;   // pt_bvh_megakernel's shading batch for this scene (BvhShadeBatch)
   bool bvh_paths = false;                   // engine BVH on a shallow tree (depth <= AMBER_PATH_BVH_STACK): pt_megakernel<ENGINE_BVH>, the path-granular scheduler (AMBER_BVH_PATHS=0/1 overrides)
   // path-granular accumulation (RenderPassPaths): bitmap, records in arrival order, measurements in path order, ranks
   uint32_t* d_flags = nullptr;  size_t flag_words = 0;   bool flags_dirty = true;   // dirty: must be cleared before the next launch
@@ -1249,6 +1251,16 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     if (bvh.depth > static_cast<uint32_t>(amber_bvh::kMaxDepth)) { amber_hip_pt_destroy(h); return Fail(AMBER_EINVAL, "BVH deeper than the device stack"); }
     h->bvh_depth = bvh.depth;
     h->bvh_paths = !h->bvh_pool && !(params->reserved & AMBER_PT_FLAG_BVH_ITEMS) && h->engine != AMBER_ENGINE_WAVEFRONT && bvh.depth <= static_cast<uint32_t>(AMBER_PATH_BVH_STACK);
+    // The shading batch of pt_bvh_megakernel.  While a wave collects finished lanes they idle through the rounds of the others, and a round
+    // over triangle leaves costs about twice a round over sphere leaves (45 against 20 vector instructions per leaf object before any
+    // root / quotient), so idle lanes are dearer in a mesh: tools/shade_batch_sweep.py (profiles/r05_shade_batch_sweep.txt) -- 1M spheres
+    // best at 52 (49.7 ms at 64 spp; 40: 52.3), 1M-triangle terrain at 32 (62.1; 40: 63.8; 52: 68.5), 82k-triangle room at 36-44 (32.8; 52: 33.9).
+    {
+      bool any_triangle = false;
+      for (const DevObject& ob : objs) any_triangle = any_triangle || (ob.kind & 0xffu) == AMBER_PRIM_TRIANGLE;
+      h->bvh_shade_batch = any_triangle ? 40u : static_cast<uint32_t>(AMBER_BVH_SHADE_BATCH);
+    }
+    { const char* ev = std::getenv("AMBER_BVH_SHADE_BATCH"); if (ev && std::atoi(ev) >= 1 && std::atoi(ev) <= 64) h->bvh_shade_batch = static_cast<uint32_t>(std::atoi(ev)); }   // measurement hook
     { const char* ev = std::getenv("AMBER_BVH_PATHS"); if (ev && ev[0] == '0') h->bvh_paths = false; }
     { const char* ev = std::getenv("AMBER_BVH_PATHS_MAX_DEPTH"); if (ev && static_cast<uint32_t>(std::atoi(ev)) < bvh.depth) h->bvh_paths = false; }   // measurement hook
     if (std::getenv("AMBER_DEBUG_BVH")) std::fprintf(stderr, "amber_hip: BVH of %u objects: %zu nodes, depth %u\n", s->n_objects, bvh.nodes.size(), bvh.depth);
@@ -1869,7 +1881,7 @@ static int RenderPassBvhItems(amber_hip_pt* h, uint32_t first_sample, uint32_t n
     RenderArgs a{};
     a.scene = h->scene; a.partial = h->d_partial; a.ray_count = sig ? h->d_rays_launch : h->d_rays; a.next_item = h->d_next; a.stamps = h->d_stamps; a.hashed_seed = h->hashed_seed;
     a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first_sample + done; a.n_samples = n;
-    a.n_chunks = n_chunks; a.n_items = n_pixels * n_chunks; a.sig = sig;
+    a.n_chunks = n_chunks; a.n_items = n_pixels * n_chunks; a.sig = sig; a.shade_batch = h->bvh_shade_batch;
     // persistent workers: one workgroup of 4 waves per CU and resident wave slot, fewer if the queue is short
     uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth);
     const uint32_t by_work = (a.n_items + 255u) / 256u;
@@ -1942,7 +1954,7 @@ int amber_hip_lt_trace_range(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
     a.scene = h->scene; a.ray_count = h->d_rays; a.next_item = h->d_next;
     a.splats = h->d_splats; a.splat_count = h->d_splat_count; a.splat_capacity = dev_capacity; a.hashed_seed = h->hashed_seed_lt;
     a.n_pixels = n_paths; a.first_sample = first_sample + done; a.n_samples = n; a.path_offset = path_begin;
-    a.n_chunks = n_chunks; a.n_items = static_cast<uint32_t>(n_work);
+    a.n_chunks = n_chunks; a.n_items = static_cast<uint32_t>(n_work); a.shade_batch = h->bvh_shade_batch;
     uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth);
     const uint32_t by_work = (a.n_items + 255u) / 256u;
     if (by_work < n_blocks) n_blocks = by_work;
