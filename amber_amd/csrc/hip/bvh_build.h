@@ -303,6 +303,10 @@ inline uint32_t EmptyPlaneWord() {                            // min above max: 
   return 0x0000ffffu;                                         // min 65535, max 0
 #endif
 }
+// -DAMBER_BVH_TRI_LEAVES=0 (measurement): leaves of triangles keep round 4's generic per-object test (64-byte record, three divisions each).
+#ifndef AMBER_BVH_TRI_LEAVES
+#define AMBER_BVH_TRI_LEAVES 1
+#endif
 // Device leaf reference: -(ref + 1) = first * 16 + all_triangles * 8 + all_spheres * 4 + count (count <= 3; first < 2^27).
 // `kind_of_slot(slot)` = primitive kind of the object in leaf-order slot `slot` (0 triangle, 1 sphere, ...).
 template <typename KindOfSlot>
@@ -312,6 +316,9 @@ inline int32_t QuantizedLeafRef(int32_t ref, KindOfSlot kind_of_slot) {
   const uint32_t first = r >> 3, count = r & 7u;
   bool spheres = count > 0, tris = count > 0;
   for (uint32_t k = 0; k < count; k++) { const uint32_t kind = kind_of_slot(first + k); spheres = spheres && kind == 1u; tris = tris && kind == 0u; }
+#if !AMBER_BVH_TRI_LEAVES
+  tris = false;
+#endif
   return -static_cast<int32_t>(first * 16u + (tris ? 8u : 0u) + (spheres ? 4u : 0u) + count) - 1;
 }
 template <typename KindOfSlot>

@@ -226,5 +226,5 @@ def terrain_mesh(patches: int = 16, k: int = 56, gap: float = 1e-5) -> MeshWorkl
                 seams.append(stitch(edges[(i, j + 1)]["south"], edges[(i, j)]["north"]))
     b.add_group("seams", WHITE, np.concatenate(seams))
     _box(b, "pillar", MIRROR, (0.45, -0.9, -0.6), (0.7, 0.3, -0.35), turn=0.5)
-    cam = (0.0, 0.35, 3.7, 0.0, -0.28, -0.96, 0.0, 0.96, -0.28)
+    cam = (0.0, 0.63, 3.3, 0.0, -0.28, -0.96, 0.0, 0.96, -0.28)        # pitched down 16 degrees: the terrain fills the 16:9 frame from its front edge to the back wall
     return MeshWorkload(f"terrain_{patches}x{k}", cam, _ROOM_MTL, list(_ROOM_MATERIALS), b.vertices(), b.groups)

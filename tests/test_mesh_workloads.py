@@ -1,0 +1,86 @@
+"""The imported-mesh workloads of engine BVH (amber_amd/workloads.py): where the reference's `--scene` users land
+(/root/reference/src/amber/cli/application.cc:74-87, import.cc:49-167: every imported scene is a triangle mesh under Scene::Create<BVH>).
+
+CPU: the generators' OBJ + MTL text read back through cli::ImportScene gives exactly the arrays they promise (object order, vertex bits,
+materials, lens).  GPU: a band of each workload at its bench frame against the oracle with the config-3 assertions (tests/bvh_parity.py) --
+0 differing pixels and equal ray counts against oracle(List), every difference from the reference's BVH classified and bounded:
+  (i)   the Cornell box through ENGINE_BVH (both schedulers: pt_megakernel<ENGINE_BVH> on the shallow tree, pt_bvh_megakernel),
+  (ii)  Cornell-like room + 1 304-triangle mesh,
+  (iii) 1.04 M-triangle displaced terrain with needle triangles at the seams.
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as O
+from amber_amd import workloads as WL
+from bvh_parity import bits, check_band
+
+
+def _import(amber, wl, tmp_path):
+    return amber.HostScene.import_file(wl.write(tmp_path))
+
+
+@pytest.mark.parametrize("make", [lambda: WL.room_mesh(2), lambda: WL.terrain_mesh(3, 8)], ids=["room_mesh", "terrain"])
+def test_generated_obj_imports_as_promised(amber, oracle, tmp_path, make):
+    wl = make()
+    kw = wl.arrays()
+    n = len(kw["kinds"])
+    assert n == wl.n_triangles
+    objs, mats, lens = _import(amber, wl, tmp_path).flatten()
+    arr = np.frombuffer(objs, dtype=np.dtype([("kind", np.uint32), ("material", np.uint32), ("p", np.float32, (12,))]))
+    assert len(arr) == n + 6 and lens.first_blade_object == n and lens.n_blades == 6          # aperture objects last (import.cc:155-157)
+    assert (arr["kind"][:n] == 0).all()
+    assert np.array_equal(bits(arr["p"][:n, :9]), bits(kw["params"]))
+    for i in range(0, n, max(1, n // 97)):
+        m, (kind, rho, param) = mats[arr["material"][i]], kw["materials"][kw["material_index"][i]]
+        assert m.kind == kind and tuple(m.rho[:]) == tuple(np.float32(x) for x in rho) and m.param == np.float32(param), i
+    # the lens of the `#camera` line: same bits as the oracle's MakeThinLens on the expected transform (import.cc:130-154)
+    osc = O.Scene.create_arrays(**kw, accel=O.ACCEL_LIST | O.BLADES_LAST)
+    origin, g_, l_, fd, sd, pa = osc.lens()
+    assert np.array_equal(bits(lens.origin[:]), bits(origin)) and np.array_equal(bits(lens.global_[:]), bits(g_)) and np.array_equal(bits(lens.local_[:]), bits(l_))
+    assert bits([lens.focus_distance, lens.sensor_distance, lens.p_area]).tolist() == bits([fd, sd, pa]).tolist()
+
+
+def test_terrain_seams_are_needles():
+    wl = WL.terrain_mesh(4, 16)
+    p = wl.arrays()["params"].astype(np.float64).reshape(-1, 3, 3)
+    e = np.stack([np.linalg.norm(p[:, 1] - p[:, 0], axis=1), np.linalg.norm(p[:, 2] - p[:, 1], axis=1), np.linalg.norm(p[:, 0] - p[:, 2], axis=1)], 1)
+    area2 = np.linalg.norm(np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), axis=1)
+    aspect = e.max(1) ** 2 / np.maximum(area2, 1e-300)
+    seams = sum(len(f) for name, _, f in wl.groups if name == "seams")
+    assert seams > 0 and (aspect > 100).sum() >= seams * 0.6 and aspect.max() > 1000 and np.median(aspect) < 4
+
+
+@pytest.mark.gpu
+def test_cornell_through_engine_bvh_band_against_both_oracles(amber, oracle):
+    """(i) the engine switch at 33 objects: config 2's frame through ENGINE_BVH, both of its schedulers."""
+    hs, osc = amber.HostScene.cornell_box(), O.Scene.cornell(O.ACCEL_BVH_CONS)
+    for flags, name in ((0, "Cornell, pt_megakernel<ENGINE_BVH>"), (amber.api.PT_FLAG_BVH_ITEMS, "Cornell, pt_bvh_megakernel")):
+        check_band(amber, hs, osc, 1024, 1024, 12345, 64, (600, 632), max_ref_pixels=8, max_ref_ray_delta=64, engine=amber.ENGINE_BVH, flags=flags, label=name)
+
+
+@pytest.mark.gpu
+def test_room_mesh_band_against_both_oracles(amber, oracle, tmp_path):
+    """(ii) a typical imported scene: 1 304 triangles, the tree 12 deep -> the path-granular kernel; and the item kernel."""
+    wl = WL.room_mesh(3)
+    hs, osc = _import(amber, wl, tmp_path), O.Scene.create_arrays(**wl.arrays(), accel=O.ACCEL_BVH_CONS | O.BLADES_LAST)
+    for flags, name in ((0, "room mesh, engine auto"), (amber.api.PT_FLAG_BVH_ITEMS, "room mesh, pt_bvh_megakernel")):
+        st = check_band(amber, hs, osc, 1024, 1024, 7, 64, (640, 672), max_ref_pixels=32, max_ref_ray_delta=256, flags=flags, label=name)
+        assert st["lit"] > 0.25
+
+
+@pytest.mark.gpu
+def test_terrain_band_against_both_oracles(amber, oracle, tmp_path):
+    """(iii) 1.04 M triangles, 40 000 of them needles: two bands of the bench frame (the far terrain under grazing rays; the near one)."""
+    wl = WL.terrain_mesh(16, 56)
+    assert wl.n_triangles > 1_000_000
+    hs, osc = _import(amber, wl, tmp_path), O.Scene.create_arrays(**wl.arrays(), accel=O.ACCEL_BVH_CONS | O.BLADES_LAST)
+    for rows in ((200, 224), (800, 824)):
+        st = check_band(amber, hs, osc, 1920, 1080, 3, 32, rows, max_ref_pixels=256, max_ref_ray_delta=2048, label="terrain")
+        assert st["lit"] > 0.25
+    # the product kernel's paths one by one (hit-object sequence, hit distances): 4 rows at 8 spp
+    osc.set_accel(O.ACCEL_BVH_CONS)
+    so = osc.path_signatures(1920, 1080, 3, 0, 8, (700, 704), threads=16)
+    pt = amber.PathTracer(hs, amber.Sensor.default(1920, 1080), seed=3, rows=(700, 704))
+    assert np.array_equal(pt.render_signatures(0, 8), so)
+    pt.close()

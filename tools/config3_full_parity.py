@@ -33,9 +33,9 @@ for name, accel in (("List via the conservative BVH", O.ACCEL_BVH_CONS), ("refer
 cons, refb = res[O.ACCEL_BVH_CONS][0], res[O.ACCEL_BVH][0]
 gpu_vs_ref = (bits(img) != bits(refb)).any(axis=2); cons_vs_ref = (bits(cons) != bits(refb)).any(axis=2)
 print("(ii) set of pixels GPU != reference BVH equals set of pixels List != reference BVH:", bool(np.array_equal(gpu_vs_ref, cons_vs_ref)))
-from test_config3_parity_gpu import classify_pixels
+from bvh_parity import classify_pixels
 pixels = list(zip(*np.nonzero(gpu_vs_ref)))
-t = time.time(); causes = classify_pixels(osc, pixels, spp=spp, seed=seed); dt = time.time() - t
+t = time.time(); causes = classify_pixels(osc, W, H, seed, pixels, spp); dt = time.time() - t
 tally = {}
 unattributed = 0
 for px, found in causes.items():
