@@ -36,6 +36,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+ENGINES = {"auto": 0, "list": 1, "two_phase": 2, "bvh": 3, "wavefront": 4}     # AMBER_ENGINE_* (include/amber_hip.h)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 BYTES_PER_RAY = 96.0      # algorithmic ray-state bytes per bounce (DESIGN.md "Roofline")
 
@@ -147,11 +148,11 @@ def secondary_workloads(amber_amd, np, seed: int, device: int):
     from amber_amd.distributed import stripe_partition
     out = []
 
-    def run(name, scene, W, H, spp, engine_name, max_depth=0, world=1, warm=8):
+    def run(name, scene, W, H, spp, engine_name, max_depth=0, world=1, warm=8, engine=0, flags=0):
         part = stripe_partition(H, world)[0]
         t0 = time.perf_counter()
         pt = amber_amd.PathTracer(scene, amber_amd.Sensor.default(W, H), seed=seed, device=device, max_depth=max_depth,
-                                  rows=part["rows"], stripe=part["stripe"])
+                                  rows=part["rows"], stripe=part["stripe"], engine=engine, flags=flags)
         t_create = time.perf_counter() - t0
         pt.render_pass(0, warm); pt.sync(); pt.clear()                       # first launch of a handle: page-in + record-density probe
         t0 = time.perf_counter()
@@ -181,10 +182,39 @@ def secondary_workloads(amber_amd, np, seed: int, device: int):
                    cornell, 2048, 2048, 1024, "work-queue megakernel, two-phase closest hit", world=4))
     out.append(run("config 5: 3840x2160 @ 8192 spp, max depth 16, on 8 GPUs -- rank 0's stripes, one 1024-spp launch of its 8",
                    cornell, 3840, 2160, 1024, "work-queue megakernel, two-phase closest hit", max_depth=16, world=8))
+    # Engine BVH where the reference's `--scene` users land (application.cc:74-87, import.cc:49-167): triangle meshes
+    # written as OBJ + MTL (amber_amd/workloads.py) and read back through cli::ImportScene, and the engine switch at 33 objects itself.
+    import tempfile
+    from amber_amd import workloads
+    two = run("Cornell 1024x1024 @ 1024 spp, two-phase (the headline kernel, for the ratio below)", cornell, 1024, 1024, 1024, "two-phase")
+    e = run("mesh (i): the Cornell box through ENGINE_BVH, config 2's frame (1024x1024 @ 1024 spp) -- the engine switch at 33 objects",
+            cornell, 1024, 1024, 1024, "path-granular megakernel, one-shot per-lane BVH traversal (tree depth 6 <= 12)", engine=amber_amd.ENGINE_BVH)
+    e["kernel_ms_over_two_phase"] = round(e["kernel_ms"] / two["kernel_ms"], 3) if two["kernel_ms"] > 0 else None
+    e["two_phase_kernel_ms"] = two["kernel_ms"]
+    out.append(e)
+    e = run("mesh (i'): the same through pt_bvh_megakernel (AMBER_PT_FLAG_BVH_ITEMS), the scheduler of deep trees",
+            cornell, 1024, 1024, 1024, "item megakernel, resumable per-lane BVH traversal", engine=amber_amd.ENGINE_BVH, flags=amber_amd.api.PT_FLAG_BVH_ITEMS)
+    e["kernel_ms_over_two_phase"] = round(e["kernel_ms"] / two["kernel_ms"], 3) if two["kernel_ms"] > 0 else None
+    out.append(e)
+    cornell.close()
+    with tempfile.TemporaryDirectory() as tmp:
+        for wl, W, H, spp, what in ((workloads.room_mesh(3), 1024, 1024, 256, "mesh (ii): Cornell-like room + bumpy icosphere, imported OBJ"),
+                                    (workloads.terrain_mesh(16, 56), 1920, 1080, 64, "mesh (iii): displaced terrain with needle triangles at the tile seams, imported OBJ")):
+            t0 = time.perf_counter()
+            path = wl.write(tmp)
+            t_write = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            hs = amber_amd.HostScene.import_file(path)
+            t_import = time.perf_counter() - t0
+            e = run(f"{what}: {wl.n_triangles} triangles, {W}x{H} @ {spp} spp", hs, W, H, spp,
+                    "engine auto = BVH: two-stage triangle leaves; path-granular kernel for trees of depth <= 12, item kernel beyond")
+            e["obj_write_s"], e["import_s"] = round(t_write, 3), round(t_import, 3)
+            out.append(e)
+            hs.close()
     return out
 
 
-def projected_scaling(amber_amd, torch, seed: int, device: int, width: int, spp: int, reps: int = 3):
+def projected_scaling(amber_amd, torch, seed: int, device: int, width: int, spp: int, reps: int = 3, engine: int = 0):
     """What a step of the headline job would cost on N GPUs, measured on ONE: every rank's share (its interleaved 8-row stripes, as
     `stripe_partition` deals them) runs its COMPLETE step here -- clear, the launch, the rank / scan / place / reduce kernels, the host
     synchronisation, and the gather of its rows through RCCL as a one-rank collective on the render stream (launch + re-ordering cost;
@@ -206,7 +236,7 @@ def projected_scaling(amber_amd, torch, seed: int, device: int, width: int, spp:
         parts = stripe_partition(width, n)
         walls, kerns, gathers, rays = [], [], [], []
         for part in parts:
-            pt = amber_amd.PathTracer(scene, sensor, seed=seed, device=device, rows=part["rows"], stripe=part["stripe"])
+            pt = amber_amd.PathTracer(scene, sensor, seed=seed, device=device, rows=part["rows"], stripe=part["stripe"], engine=engine)
             stream = torch.cuda.ExternalStream(pt.stream(), device=torch.device("cuda", device))
             fb = band_tensor(pt, f"cuda:{device}")
             own = [dict(rows=(0, len(part["index"])), stripe=None, index=np.arange(len(part["index"])))]
@@ -247,7 +277,7 @@ def projected_scaling(amber_amd, torch, seed: int, device: int, width: int, spp:
     return out
 
 
-def cold_start(amber_amd, seed: int, device: int, width: int, spp: int):
+def cold_start(amber_amd, seed: int, device: int, width: int, spp: int, engine: int = 0):
     """What a user of the CLI waits for at the start of a render (application.cc:120-215): a NEW handle on the headline job -- create
     (scene flattening and upload), the per-pixel candidate masks, the one-chunk record-density probe, the first full launch and the
     download of the frame.  The process is warm (HIP initialised, code objects loaded); the handle is not."""
@@ -256,7 +286,7 @@ def cold_start(amber_amd, seed: int, device: int, width: int, spp: int):
     best = None
     for _ in range(3):
         t0 = time.perf_counter()
-        pt = amber_amd.PathTracer(scene, amber_amd.Sensor.default(width, width), seed=seed, device=device)
+        pt = amber_amd.PathTracer(scene, amber_amd.Sensor.default(width, width), seed=seed, device=device, engine=engine)
         t1 = time.perf_counter()
         pt.render_pass(0, 8)                                                # what amber_hip_pt_render_pass does first anyway: the probe chunk
         pt.sync()
@@ -288,7 +318,8 @@ def side_child(args):
     torch.cuda.set_device(device)
     out = {}
     try:
-        out["cold_start"] = cold_start(amber_amd, args.seed, device, args.width, args.spp)
+        out["cold_start"] = cold_start(amber_amd, args.seed, device, args.width, args.spp, engine=ENGINES[args.engine])
+        out["cold_start"]["engine"] = args.engine
     except Exception as e:
         out["cold_start"] = None; out["cold_start_error"] = str(e)[:200]
     try:
@@ -299,7 +330,8 @@ def side_child(args):
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", device))
         except Exception as e:                                             # the projection still runs, without the gather
             out["projected_scaling_gather_error"] = str(e)[:200]
-        out["projected_scaling"] = projected_scaling(amber_amd, torch, args.seed, device, args.width, args.spp)
+        out["projected_scaling"] = projected_scaling(amber_amd, torch, args.seed, device, args.width, args.spp, engine=ENGINES[args.engine])
+        out["projected_scaling"]["engine"] = args.engine
         if dist.is_initialized():
             dist.destroy_process_group()
     except Exception as e:
@@ -313,7 +345,7 @@ def side_child(args):
 
 def run_side_child(args, timeout_s: float = 420.0):
     """Starts side_child as a child process and returns its dict (or an error entry).  The parent has released its GPU buffers."""
-    cmd = [sys.executable, str(Path(__file__).resolve()), "--side-child", "--seed", str(args.seed), "--width", str(args.width), "--spp", str(args.spp)]
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--side-child", "--seed", str(args.seed), "--width", str(args.width), "--spp", str(args.spp), "--engine", args.engine]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
@@ -334,6 +366,94 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
+def dist_timeout_s() -> float:
+    """Seconds a rank waits for the others at the rendezvous and at the first barrier before it gives up (AMBER_BENCH_DIST_TIMEOUT_S, default 120)."""
+    return float(os.environ.get("AMBER_BENCH_DIST_TIMEOUT_S", "120"))
+
+
+def watchdog(seconds: float, rank: int, what: str):
+    """A rank that is stuck in `what` for `seconds` EXITS (code 3) instead of holding the GPU lease: the launcher then ends the other ranks
+    and returns non-zero.  os._exit from a timer thread: no exec, no clean-up that could block on the very collective that hangs."""
+    import threading
+
+    def fire():
+        sys.stderr.write(f"bench.py: rank {rank}: {what} did not complete in {seconds:.0f} s -- giving up (exit 3)\n")
+        sys.stderr.flush()
+        os._exit(3)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def rendezvous(torch, backend: str, rank: int, world: int, device=None):
+    """init_process_group + the first barrier, both under a time-out (a rank that fails must make the run exit non-zero,
+    not hang).  AMBER_BENCH_KILL_RANK=r makes rank r die right after the rendezvous (the test of exactly that)."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    limit = dist_timeout_s()
+    dog = watchdog(limit + 5.0, rank, f"the {backend} rendezvous of {world} ranks")
+    kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=limit))
+    if device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, **kw)
+    dog.cancel()
+    if os.environ.get("AMBER_BENCH_KILL_RANK") == str(rank):
+        sys.stderr.write(f"bench.py: rank {rank}: AMBER_BENCH_KILL_RANK -- exiting 17 before the first barrier\n")
+        sys.stderr.flush()
+        os._exit(17)
+    dog = watchdog(limit + 5.0, rank, "the first barrier")
+    dist.barrier()
+    dog.cancel()
+    return dist
+
+
+def per_rank_table(torch, dist, world: int, device, row):
+    """all_gather of one float64 row per rank -> list of dicts (rank 0 prints it): what makes a first real N > 1 run diagnosable from its one line."""
+    keys = ("rank", "device", "rows", "rays", "kernel_ms", "step_wall_ms", "gather_ms")
+    mine = torch.tensor([float(row[k]) for k in keys], dtype=torch.float64, device=device)
+    if dist is None or world == 1:
+        got = [mine]
+    else:
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+    out = []
+    for t in got:
+        v = t.tolist()
+        out.append({"rank": int(v[0]), "device": int(v[1]), "rows": int(v[2]), "rays": int(v[3]), "kernel_ms": round(v[4], 3),
+                    "step_wall_ms": round(v[5], 3), "gather_ms": round(v[6], 4)})
+    return out
+
+
+def dist_selftest(args) -> int:
+    """`bench.py --gpus N --dist-selftest` (under the launcher `--gpus N` starts): the multi-rank plumbing on the CPU -- rendezvous and first
+    barrier with their time-outs, stripe partition, the single gather (gloo) of stand-in rows, the per-rank table, one JSON line on rank 0."""
+    import numpy as np
+    import torch
+    from amber_amd.distributed import RowGatherer, stripe_partition
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist = rendezvous(torch, "gloo", rank, world) if world > 1 else None
+    W = H = args.width
+    parts = stripe_partition(H, world)
+    mine = parts[rank]
+    rows = torch.from_numpy((np.asarray(mine["index"], np.float32)[:, None, None] + np.zeros((1, W, 3), np.float32)).copy())   # row y holds the value y
+    gather = RowGatherer(parts, W, rank, world, "cpu")
+    t0 = time.perf_counter()
+    img = gather(rows)
+    g_ms = (time.perf_counter() - t0) * 1e3
+    table = per_rank_table(torch, dist, world, "cpu", dict(rank=rank, device=-1, rows=len(mine["index"]), rays=len(mine["index"]) * W, kernel_ms=0.0,
+                                                           step_wall_ms=g_ms, gather_ms=g_ms))
+    ok = True
+    if rank == 0:
+        ok = bool(np.array_equal(img.numpy()[:, 0, 0], np.arange(H, dtype=np.float32)))
+        print(json.dumps({"selftest": "dist", "n_gpus": world, "backend": "gloo", "gathered_rows_in_order": ok, "per_rank": table}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (never exec: nothing here has
     touched the GPU yet, and nothing will in this parent), relay rank 0's JSON line, propagate the exit code."""
@@ -345,7 +465,7 @@ def spawn_ranks(n: int) -> int:
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     lines = []
     for line in proc.stdout:
-        if line.startswith('{"metric"'):
+        if line.startswith('{"metric"') or line.startswith('{"selftest"'):
             lines.append(line)
         else:
             sys.stderr.write(line)
@@ -370,6 +490,10 @@ def main():
     ap.add_argument("--side-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single GPU: every rank uses device 0 and the gather runs over gloo on host copies")
+    ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the oracle check of 16 rows of the gathered image on rank 0 after the timed steps")
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="CPU-only self-test of the multi-rank plumbing (gloo): rendezvous with its time-outs, first barrier, the row gather on stand-in rows, "
+                         "the per-rank table; no GPU, no render (tests/test_distributed_cpu.py)")
     ap.add_argument("--engine", default="auto", choices=["auto", "list", "two_phase", "bvh", "wavefront"],
                     help="closest-hit / scheduling engine (default: auto = the fastest valid one; others for comparison)")
     args = ap.parse_args()
@@ -379,6 +503,9 @@ def main():
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
+
+    if args.dist_selftest:
+        raise SystemExit(dist_selftest(args))
 
     import numpy as np
     import torch
@@ -408,13 +535,8 @@ def main():
         sys.stdout.flush()
         json_fd = os.dup(1)
         os.dup2(2, 1)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = "gloo" if args.rehearse_on_one_gpu else "nccl"
-        if backend == "gloo":
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist = rendezvous(torch, backend, rank, world, torch.device("cuda", local_rank) if backend == "nccl" else None)
 
     W = H = args.width
     sensor = amber_amd.Sensor.default(W, H)
@@ -424,7 +546,7 @@ def main():
     # The handle renders on a stream of its own; the gather is enqueued on THAT stream (torch sees it as an external
     # stream), so the collective is ordered after the render without a host synchronisation in between.
     tracer = amber_amd.PathTracer(scene, sensor, seed=args.seed, device=local_rank, rows=mine["rows"], stripe=mine["stripe"],
-                                  engine={"auto": 0, "list": 1, "two_phase": 2, "bvh": 3, "wavefront": 4}[args.engine])
+                                  engine=ENGINES[args.engine])
     render_stream = torch.cuda.ExternalStream(tracer.stream(), device=torch.device("cuda", local_rank))
     fb = band_tensor(tracer, f"cuda:{local_rank}")
     launches = [(s, min(args.spp_per_launch, args.spp - s)) for s in range(0, args.spp, args.spp_per_launch)]
@@ -432,6 +554,7 @@ def main():
 
     collective = world > 1 or force_collective
     gather_events = []                                                 # (start, end) on the render stream: the gather + row re-ordering of a step
+    gather_host_ms = []                                                # the gloo rehearsal: host time of the gather call
 
     def step(timed=False):
         tracer.clear()
@@ -439,7 +562,11 @@ def main():
             tracer.render_pass(first, n)
         if args.rehearse_on_one_gpu and world > 1:
             tracer.sync()
-            return gather(fb.cpu())                                # gloo: host tensors
+            tg = time.perf_counter()
+            img_ = gather(fb.cpu())                                # gloo: host tensors
+            if timed:
+                gather_host_ms.append((time.perf_counter() - tg) * 1e3)
+            return img_
         if collective:
             tracer.sync()                                          # a launch that ran out of record slots is repeated HERE: the
                                                                    # gather below must not ship a framebuffer that still misses it
@@ -465,10 +592,13 @@ def main():
     t0 = time.perf_counter()
     total_rays_local, kernel_ms, n_launch = 0, 0.0, 0
     img = None
+    step_walls = []                                                    # this rank's own step: clear -> launches -> gather enqueued -> its stream drained
     for _ in range(args.steps):
+        ts = time.perf_counter()
         img = step(timed=True)
         # ray counter and kernel times are read after the step's work is enqueued; download syncs the stream
         total_rays_local += tracer.ray_count()
+        step_walls.append((time.perf_counter() - ts) * 1e3)
         nl, ms = tracer.kernel_time()
         kernel_ms += ms; n_launch += nl
     fence()
@@ -486,6 +616,12 @@ def main():
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         dist.all_reduce(g, op=dist.ReduceOp.MAX)
     dt_max, rays, kern_ms, gather_ms = float(t.item()), int(r.item()), float(k.item()), float(g.item())
+    per_rank = None
+    if collective:
+        own_gather = (sum(gms) / len(gms)) if gms else ((sum(gather_host_ms) / len(gather_host_ms)) if gather_host_ms else 0.0)
+        per_rank = per_rank_table(torch, dist, world, red_dev, dict(rank=rank, device=local_rank, rows=len(mine["index"]), rays=total_rays_local,
+                                                                    kernel_ms=kernel_ms / max(n_launch, 1), step_wall_ms=sum(step_walls) / max(len(step_walls), 1),
+                                                                    gather_ms=own_gather))
 
     if rank == 0 and os.environ.get("AMBER_BENCH_SAVE_IMAGE") and img is not None:
         torch.cuda.synchronize()
@@ -522,6 +658,22 @@ def main():
             out["gather_ms"] = round(gather_ms, 4)                     # per step: the gather + re-ordering into global row order, on the render stream (max over ranks)
         if backend == "nccl":
             out["rccl_ranks"] = world
+        if per_rank is not None:
+            # rays: over the timed steps; kernel_ms: mean per launch; step_wall_ms: the rank's own step until its stream has drained (the gather included:
+            # on rank 0 that waits for every rank's rows); gather_ms: the collective + re-ordering on the render stream (host time in the gloo rehearsal)
+            out["per_rank"] = per_rank
+        if world > 1 and not args.no_parity and img is not None:
+            # the checker's leg of an N > 1 run: 16 rows of the GATHERED image (row sums of all samples) against the oracle, on rank 0, outside the timed region
+            try:
+                sys.path.insert(0, str(ROOT / "tests"))
+                from parity_rows import compare_image_rows
+                if not args.rehearse_on_one_gpu:
+                    torch.cuda.synchronize()
+                out["parity"] = compare_image_rows(img.detach().cpu().numpy().reshape(H, W, 3), W, args.spp, args.seed, threads=max(1, host_cores()[1]),
+                                                   launches=launches)
+            except Exception as e:                                     # the headline must survive its checker
+                out["parity"] = None
+                out["parity_error"] = str(e)[:200]
         profs = sorted((ROOT / "profiles").glob("r*_hbm_traffic.json"))      # latest committed rocprofv3 PMC summary
         if profs and args.engine == "auto" and args.spp == 1024 and args.width == 1024:
             try:

@@ -80,3 +80,31 @@ def compare_rows(amber, width: int = 1024, spp: int = 1024, seed: int = 12345, b
         pt.close()
     out["cast_delta"] = out["rays_gpu"] - out["rays_oracle"]
     return out
+
+
+def compare_image_rows(image: np.ndarray, width: int, spp: int, seed: int, bands=None, threads: int = 8, math: int = O.MATH_LIBM,
+                       accel: int = O.ACCEL_BVH, tol: float = 1e-4, launches=None) -> dict:
+    """The image leg of compare_rows for an image rendered ELSEWHERE -- bench.py's gathered image of an N > 1 run (row sums over all samples
+    of the Cornell box, width x width): the rows of `bands` against the oracle, bits and the north star's tolerance.  `launches` =
+    [(first_sample, n)] as the bench issued them (the summation order splits on launch boundaries)."""
+    bands = bands_for(width) if bands is None else bands
+    osc = O.Scene.cornell(accel)
+    out = dict(rows=0, pixels=0, pixels_differing=0, pixels_over_tol=0, max_rel_l2=0.0, rays_oracle=0, bands=[list(b) for b in bands], tolerance=tol,
+               against=f"oracle(XorShift, {'BVH' if accel == O.ACCEL_BVH else 'List'}, live libm) on rows of the gathered image")
+    for y0, y1 in bands:
+        full = np.zeros((width, width, 3), np.float32)
+        for first, n in (launches or [(0, spp)]):
+            part = np.zeros((width, width, 3), np.float32)
+            _, cnt = osc.render_xorshift(width, width, seed, first, n, math=math, threads=threads, rows=(y0, y1), out=part)
+            full[y0:y1] = full[y0:y1] + part[y0:y1]                     # launches add onto the framebuffer in order
+            out["rays_oracle"] += int(cnt.casts)
+        g, o = np.ascontiguousarray(image[y0:y1], np.float32), full[y0:y1]
+        out["rows"] += y1 - y0
+        out["pixels"] += (y1 - y0) * width
+        out["pixels_differing"] += int((g.view(np.uint32) != o.view(np.uint32)).any(axis=2).sum())
+        err = np.sqrt(((g.astype(np.float64) - o) ** 2).sum(axis=2))
+        ref = np.sqrt((o.astype(np.float64) ** 2).sum(axis=2))
+        rel = np.where(ref > 0, err / np.where(ref > 0, ref, 1), np.where(err > 0, np.inf, 0.0))
+        out["pixels_over_tol"] += int((rel > tol).sum())
+        out["max_rel_l2"] = float(max(out["max_rel_l2"], rel.max()))
+    return out

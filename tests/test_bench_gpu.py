@@ -44,6 +44,26 @@ def test_plain_gpus_flag_starts_its_own_ranks(amber, tmp_path):
     ref, rays = _reference_image(amber, 256, 64)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
     assert line["config"]["rays_per_step"] == rays
+    # what makes a first real N > 1 run diagnosable from its one line: a per-rank table that sums to the totals ...
+    table = line["per_rank"]
+    assert [r["rank"] for r in table] == [0, 1, 2] and all(r["device"] == 0 for r in table)           # the rehearsal: every rank on GPU 0
+    assert sum(r["rows"] for r in table) == 256 and sum(r["rays"] for r in table) == rays * line["steps"]
+    assert all(r["kernel_ms"] > 0 and r["step_wall_ms"] >= r["kernel_ms"] and r["gather_ms"] >= 0 for r in table)
+    assert max(r["step_wall_ms"] for r in table) <= line["ms_per_step"] * 1.5 + 50
+    # ... and the oracle's verdict on 16 rows of the GATHERED image
+    par = line["parity"]
+    assert par["rows"] == 16 and par["pixels"] == 16 * 256 and par["pixels_differing"] == 0 and par["pixels_over_tol"] == 0
+
+
+def test_a_dead_rank_ends_the_gpu_run_with_an_error(amber, tmp_path):
+    """The same flow with rank 1 killed after the rendezvous: non-zero exit, no JSON line, well inside the time-out."""
+    import time
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", AMBER_BENCH_KILL_RANK="1", AMBER_BENCH_DIST_TIMEOUT_S="20")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--gpus", "3", "--rehearse-on-one-gpu",
+                        "--width", "64", "--spp", "8"], capture_output=True, text=True, env=e, timeout=300)
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith('{"metric"')], p.stdout
+    assert time.time() - t0 < 120
 
 
 def test_rccl_gather_is_ordered_after_the_render(amber, tmp_path):
