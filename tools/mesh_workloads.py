@@ -28,6 +28,7 @@ def stamps(pt):
 
 def run(label, hs, W, H, spp, engine=A.ENGINE_AUTO, paths=None):
     """paths: None = the library's choice; False / True = AMBER_BVH_PATHS=0 / unset (pt_bvh_megakernel against pt_megakernel<ENGINE_BVH> on shallow trees)"""
+    if COUNTERS and paths is None: return 0.0                # the counter sites belong to pt_bvh_megakernel: only the item kernel is counted
     if paths is False: os.environ["AMBER_BVH_PATHS"] = "0"
     else: os.environ.pop("AMBER_BVH_PATHS", None)
     t = time.time(); pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=1, engine=engine); t_create = time.time() - t
@@ -71,5 +72,5 @@ for name in names:
         if name.startswith("room_mesh"):
             run(wl.name + " (BVH, item kernel)", hs, 1024, 1024, SPP or 256, paths=False)
             run(wl.name + " (engine auto = BVH)", hs, 1024, 1024, SPP or 256)
-        else: run(wl.name + " (engine auto = BVH)", hs, 1920, 1080, SPP or 64)
+        else: run(wl.name + " (engine auto = BVH)", hs, 1920, 1080, SPP or 64, paths=False if COUNTERS else None)
     hs.close()
