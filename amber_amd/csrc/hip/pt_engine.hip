@@ -1044,6 +1044,7 @@ struct amber_hip_pt {
   DevObject* d_prog_objects = nullptr;
   DevBvhNodeQ* d_bvh_nodes = nullptr;
   DevBvhNodeQ4* d_bvh_nodes4 = nullptr;      // AMBER_BVH_WIDE builds only
+  uint4* d_bvh_fat = nullptr;                // AMBER_BVH_FAT builds only
   float4* d_bvh_spheres = nullptr;
   float4* d_bvh_tris = nullptr;
   uint32_t* d_bvh_prims = nullptr;
@@ -1248,6 +1249,20 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   amber_bvh::FlatBvh bvh;
   if (h->hit_engine == AMBER_ENGINE_BVH) {
     bvh = amber_bvh::BuildBvh(objs);
+    const bool debug_bvh = std::getenv("AMBER_DEBUG_BVH") != nullptr;
+    auto report = [&](const char* what) {
+      const amber_bvh::BvhQuality q = amber_bvh::MeasureBvh(bvh.nodes, bvh.root_ref);
+      std::fprintf(stderr, "amber_hip: BVH %s: SAH inner-node term %.3f, leaf term %.3f (x objects %.3f), leaf volume / scene volume %.3f; %u inner nodes, %u leaves, %u levels\n",
+                   what, q.inner_area, q.leaf_area, q.leaf_object_area, q.leaf_volume, q.inner, q.leaves, q.depth);
+    };
+    if (debug_bvh) report("as built");
+    if (const char* ev = std::getenv("AMBER_BVH_ROTATE")) {                   // measurement hook (EXPERIMENTS.md, round 5): tree rotations after the build
+      const int passes = std::atoi(ev);
+      if (passes > 0) {
+        const size_t n_rot = amber_bvh::RotateBvh(bvh.nodes, bvh.root_ref, passes);
+        if (debug_bvh) { std::fprintf(stderr, "amber_hip: BVH: %zu rotations in <= %d passes\n", n_rot, passes); report("after rotations"); }
+      }
+    }
     if (bvh.depth > static_cast<uint32_t>(amber_bvh::kMaxDepth)) { amber_hip_pt_destroy(h); return Fail(AMBER_EINVAL, "BVH deeper than the device stack"); }
     h->bvh_depth = bvh.depth;
     h->bvh_paths = !h->bvh_pool && !(params->reserved & AMBER_PT_FLAG_BVH_ITEMS) && h->engine != AMBER_ENGINE_WAVEFRONT && bvh.depth <= static_cast<uint32_t>(AMBER_PATH_BVH_STACK);
@@ -1329,6 +1344,21 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMalloc(&h->d_bvh_nodes, (qbvh.nodes.size() + 1) * sizeof(DevBvhNodeQ)));
   HIP_TRY_H(hipMalloc(&h->d_bvh_prims, (bvh.prim_index.size() + 1) * sizeof(uint32_t)));
   if (!qbvh.nodes.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_nodes, qbvh.nodes.data(), qbvh.nodes.size() * sizeof(DevBvhNodeQ), hipMemcpyHostToDevice));
+#if AMBER_BVH_FAT
+  {
+    // every inner node followed by copies of its children's records (zeros for a leaf child: never read)
+    std::vector<DevBvhNodeQ> fat(3 * qbvh.nodes.size());
+    for (size_t i = 0; i < qbvh.nodes.size(); i++) {
+      const DevBvhNodeQ& nd = qbvh.nodes[i];
+      fat[3 * i] = nd;
+      std::memset(&fat[3 * i + 1], 0, 2 * sizeof(DevBvhNodeQ));
+      if (nd.left >= 0) fat[3 * i + 1] = qbvh.nodes[nd.left];
+      if (nd.right >= 0) fat[3 * i + 2] = qbvh.nodes[nd.right];
+    }
+    HIP_TRY_H(hipMalloc(&h->d_bvh_fat, (fat.size() + 3) * sizeof(DevBvhNodeQ)));
+    if (!fat.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_fat, fat.data(), fat.size() * sizeof(DevBvhNodeQ), hipMemcpyHostToDevice));
+  }
+#endif
 #if AMBER_BVH_WIDE
   {
     amber_bvh::QuantizedBvh4 q4 = amber_bvh::CollapseBvh4(bvh.nodes, bvh.root_ref, qbvh, [&](uint32_t slot) { return objs[bvh.prim_index[slot]].kind & 0xffu; });
@@ -1385,7 +1415,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades;
   sc.planes = h->d_planes; sc.tri_filters = h->d_tri_filters; sc.sphere_filters = h->d_sphere_filters;
   sc.n_planes = static_cast<uint32_t>(fprog.planes.size()); sc.n_simple_planes = fprog.n_simple_planes; sc.n_sphere_filters = static_cast<uint32_t>(fprog.spheres.size());
-  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_nodes4 = h->d_bvh_nodes4; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_spheres = h->d_bvh_spheres; sc.bvh_tris = h->d_bvh_tris; sc.bvh_root = qbvh.root_ref;
+  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_nodes4 = h->d_bvh_nodes4; sc.bvh_fat = h->d_bvh_fat; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_spheres = h->d_bvh_spheres; sc.bvh_tris = h->d_bvh_tris; sc.bvh_root = qbvh.root_ref;
   for (int c = 0; c < 3; c++) { sc.bvh_gmin[c] = qbvh.gmin[c]; sc.bvh_step[c] = qbvh.step[c]; sc.bvh_reach[c] = qbvh.reach[c]; }
   {
     // per-ray box margin of engine BVH (BvhBegin): centre and half diagonal of the scene bounds, 1 / smallest sphere radius
@@ -2097,6 +2127,7 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_prog_objects) (void)hipFree(h->d_prog_objects);
   if (h->d_bvh_nodes) (void)hipFree(h->d_bvh_nodes);
   if (h->d_bvh_nodes4) (void)hipFree(h->d_bvh_nodes4);
+  if (h->d_bvh_fat) (void)hipFree(h->d_bvh_fat);
   if (h->d_bvh_spheres) (void)hipFree(h->d_bvh_spheres);
   if (h->d_bvh_tris) (void)hipFree(h->d_bvh_tris);
   if (h->d_bvh_prims) (void)hipFree(h->d_bvh_prims);
