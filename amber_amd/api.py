@@ -391,20 +391,20 @@ class PathTracer:
         return out
 
     def pixel_masks(self):
-        """(masks (rows, width) uint32, slot of every scene object (n_objects,) uint32, ms of the mask kernel or -1 if it had run before)."""
+        """(masks (rows, width) uint32, duration of pixel_mask_kernel in ms): the candidate mask of every band pixel's eye rays (two-phase engine)."""
         rows, width, _ = self.band_shape
         masks = np.zeros((rows, width), np.uint32)
         ms = C.c_double()
         _check(load_library().amber_hip_kat_pixel_masks(self._h, masks.ctypes.data, None, None, C.byref(ms)))
         return masks, ms.value
 
-    def object_slots(self, n_objects: int) -> np.ndarray:
-        """Filter-program slot (mask bit) of every scene object; 0xffffffff = none."""
+    def object_slots(self, n_objects: int):
+        """(filter-program slot (mask bit) of every scene object, 0xffffffff = none; mask of the slots that are candidates of every ray -- objects
+        without a filter record and the aperture blades).  Works with AMBER_PIXEL_MASK=0 and on an empty band: it does not need the mask kernel."""
         slots = np.zeros(n_objects, np.uint32)
         always = C.c_uint32()
         _check(load_library().amber_hip_kat_pixel_masks(self._h, None, slots.ctypes.data, C.byref(always), None))
-        self.always_mask = always.value          # slots that are candidates of every ray (no filter record; aperture blades)
-        return slots
+        return slots, always.value
 
     def render_signatures(self, first_sample: int, n_samples: int) -> np.ndarray:
         """kat_signatures' layout and meaning, produced by the PRODUCT render kernel (its signature instantiation)."""

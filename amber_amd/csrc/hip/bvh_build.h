@@ -274,73 +274,9 @@ inline BvhQuality MeasureBvh(const std::vector<DevBvhNode>& nodes, int32_t root_
   return q;
 }
 
-// Tree rotations (Kensler 2008), one post-build optimisation pass over the finished topology: at every inner node N = {A, B} with an
-// inner child A = {A1, A2}, exchanging B with A1 or A2 changes only A's box -- A' = {B, A2} or {A1, B} -- and is taken when area(A')
-// is smaller (the SAH's inner-node term; leaf boxes and the leaf order do not change).  Children first, repeated until a pass finds
-// nothing (at most `max_passes`).  A rotation that would make N's subtree deeper is not taken: the traversal stack, and with it the
-// number of resident workgroups, is chosen from the tree's depth.  Returns the number of rotations applied.
-inline size_t RotateBvh(std::vector<DevBvhNode>& nodes, int32_t root_ref, int max_passes = 4) {
-  if (root_ref < 0 || nodes.empty()) return 0;
-  std::vector<int32_t> order;                                   // nodes in pre-order; processed back to front = children before parents
-  order.reserve(nodes.size());
-  { std::vector<int32_t> st{root_ref}; while (!st.empty()) { const int32_t n = st.back(); st.pop_back(); order.push_back(n); if (nodes[n].left >= 0) st.push_back(nodes[n].left); if (nodes[n].right >= 0) st.push_back(nodes[n].right); } }
-  std::vector<uint8_t> height(nodes.size(), 1);
-  auto child_height = [&](int32_t ref) -> int { return ref >= 0 ? height[ref] : 0; };
-  auto refresh = [&](int32_t n) { height[n] = static_cast<uint8_t>(1 + std::max(child_height(nodes[n].left), child_height(nodes[n].right))); };
-  for (size_t k = order.size(); k-- > 0;) refresh(order[k]);
-  size_t total = 0;
-  for (int pass = 0; pass < max_passes; pass++) {
-    size_t applied = 0;
-    for (size_t k = order.size(); k-- > 0;) {
-      const int32_t n = order[k];
-      double best_gain = 0; int best_side = -1, best_grand = -1;
-      for (int side = 0; side < 2; side++) {                    // `side` = the inner child A whose box changes; the other child B moves down
-        const int32_t a = side ? nodes[n].right : nodes[n].left;
-        if (a < 0) continue;
-        const int32_t b_ref = side ? nodes[n].left : nodes[n].right;
-        const Box b_box = ChildBox(nodes[n], 1 - side), a_box = ChildBox(nodes[n], side);
-        for (int g = 0; g < 2; g++) {                           // the grandchild that moves UP (exchanged with B); the other one stays with B
-          const int32_t up = g ? nodes[a].right : nodes[a].left, stay = g ? nodes[a].left : nodes[a].right;
-          Box merged = ChildBox(nodes[a], 1 - g); merged.grow(b_box);
-          const double gain = a_box.area() - merged.area();
-          if (!(gain > best_gain * 1.0000001 + 1e-300)) continue;
-          const int new_a_height = 1 + std::max(child_height(stay), child_height(b_ref));
-          if (1 + std::max(new_a_height, child_height(up)) > height[n]) continue;       // would deepen the subtree
-          best_gain = gain; best_side = side; best_grand = g;
-        }
-      }
-      if (best_side < 0) continue;
-      DevBvhNode& N = nodes[n];
-      const int32_t a = best_side ? N.right : N.left;
-      DevBvhNode& A = nodes[a];
-      const int32_t b_ref = best_side ? N.left : N.right;
-      const Box b_box = ChildBox(N, 1 - best_side);
-      const int32_t up = best_grand ? A.right : A.left;
-      const Box up_box = ChildBox(A, best_grand);
-      // A's slot `best_grand` takes B; N's other slot takes the grandchild
-      (best_grand ? A.right : A.left) = b_ref; SetChildBox(A, best_grand, b_box);
-      (best_side ? N.left : N.right) = up; SetChildBox(N, 1 - best_side, up_box);
-      Box merged = ChildBox(A, 0); merged.grow(ChildBox(A, 1));
-      SetChildBox(N, best_side, merged);
-      refresh(a); refresh(n);
-      applied++;
-    }
-    total += applied;
-    if (applied == 0) break;
-    // the pre-order changed; rebuild it and the heights for the next pass
-    order.clear();
-    { std::vector<int32_t> st{root_ref}; while (!st.empty()) { const int32_t n = st.back(); st.pop_back(); order.push_back(n); if (nodes[n].left >= 0) st.push_back(nodes[n].left); if (nodes[n].right >= 0) st.push_back(nodes[n].right); } }
-    for (size_t k = order.size(); k-- > 0;) refresh(order[k]);
-  }
-  return total;
-}
-inline uint32_t BvhDepth(const std::vector<DevBvhNode>& nodes, int32_t root_ref) {       // levels of inner nodes + the leaf level, as Builder::max_depth_seen counts them
-  if (root_ref < 0) return 0;
-  uint32_t depth = 0;
-  std::vector<std::pair<int32_t, uint32_t>> st{{root_ref, 1u}};
-  while (!st.empty()) { const auto it = st.back(); st.pop_back(); depth = std::max(depth, it.second); if (nodes[it.first].left >= 0) st.push_back({nodes[it.first].left, it.second + 1}); if (nodes[it.first].right >= 0) st.push_back({nodes[it.first].right, it.second + 1}); }
-  return depth;
-}
+// (Tree rotations after the build -- Kensler 2008, exchanging a node's child with a grandchild where that shrinks the inner box -- were
+//  built and measured in round 5: 8 524 rotations on the 1M-sphere tree lower the inner-node term from 230.415 to 230.274 and the kernel time
+//  not at all; removed.  EXPERIMENTS.md, profiles/r05_config3_treelet_rotations_ab.txt.)
 
 // The tree the device traverses (DevBvhNodeQ): child boxes on a 16-bit grid over the bounds of all node boxes, min planes
 // rounded down and max planes up (checked in exact arithmetic: gmin and step are binary32, q * step and the sum are exact

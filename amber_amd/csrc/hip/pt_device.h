@@ -139,13 +139,6 @@ struct alignas(16) DevBvhNodeQ4 {  // 64 B
 #ifndef AMBER_BVH_WIDE
 #define AMBER_BVH_WIDE 0
 #endif
-// AMBER_BVH_FAT builds (measurement, round 5: the "lazily tested depth-2 treelet" of VERDICT r04 item 2a): every inner node's record is
-// followed by COPIES of its two children's records -- 96 bytes, six 16-byte loads issued together.  A visit tests the node's two child
-// boxes as before and, when it enters an inner child, tests that child's two boxes from the copy it already holds: two levels of the
-// near path per memory round trip, the same box tests per level (unlike the 4-wide tree, which tests all four grandchildren always).
-#ifndef AMBER_BVH_FAT
-#define AMBER_BVH_FAT 0
-#endif
 // Light-tracing source record: one per DiffuseLight object, sorted by power (scene/light_set.h:61-82).
 struct alignas(16) DevLight {     // 96 B
   uint32_t kind; int32_t slot;      // primitive kind ; filter-program slot of a light triangle (-1 otherwise)
@@ -192,7 +185,6 @@ struct DevScene {
   const DevObject* __restrict__ prog_objects;   // objects in program order, kind |= scene index << 8 (staged to LDS)
   const DevBvhNodeQ* __restrict__ bvh_nodes;    // engine BVH: quantised 2-wide nodes
   const DevBvhNodeQ4* __restrict__ bvh_nodes4;  // AMBER_BVH_WIDE builds: the collapsed 4-wide nodes (else null)
-  const uint4* __restrict__ bvh_fat;            // AMBER_BVH_FAT builds: six uint4 per inner node, {own record, left child's, right child's} (else null)
   float bvh_gmin[3], bvh_step[3];               // plane = bvh_gmin + value * bvh_step (binary16 planes: scene centre, half extent)
   float bvh_reach[3];                           // max(|bounds_min - x|, |bounds_max - x|) over x in the bounds, per axis = extent (slab rounding slack)
   const float4* __restrict__ bvh_spheres;       // (centre, radius) of every object in leaf order (zeros for non-spheres): leaves of spheres only test from here
@@ -1137,40 +1129,6 @@ __device__ __forceinline__ void BvhDescend(const DevScene& sc, const Stack& stac
     } else {
       cur = AMBER_BVH_DONE;
     }
-#elif AMBER_BVH_FAT
-    const uint4* nd = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.bvh_fat) + static_cast<uint32_t>(cur) * 96u);
-    const uint4 p0 = nd[0], q0 = nd[1], lp = nd[2], lq = nd[3], rp = nd[4], rq = nd[5];          // one round trip: the node and both children's records
-#define AMBER_ROT(wd, c) __builtin_amdgcn_alignbit((wd), (wd), tr.rot[c])
-#define AMBER_QLO(wd) AMBER_PLANE_VALUE((wd) & 0xffffu)
-#define AMBER_QHI(wd) AMBER_PLANE_VALUE((wd) >> 16)
-    // one level: the two child boxes of record (p, q); sets `cur` to the child entered (near first, the far one pushed), or pops / finishes
-#define AMBER_FAT_LEVEL(p, q, entered_) { \
-    const int32_t left = static_cast<int32_t>(q.z), right = static_cast<int32_t>(q.w); \
-    const uint32_t wlx = AMBER_ROT(p.x, 0), wly = AMBER_ROT(p.y, 1), wlz = AMBER_ROT(p.z, 2), wrx = AMBER_ROT(p.w, 0), wry = AMBER_ROT(q.x, 1), wrz = AMBER_ROT(q.y, 2); \
-    const float lnx = __builtin_fmaf(AMBER_QLO(wlx), tr.A.x, tr.b_in.x), lny = __builtin_fmaf(AMBER_QLO(wly), tr.A.y, tr.b_in.y), lnz = __builtin_fmaf(AMBER_QLO(wlz), tr.A.z, tr.b_in.z); \
-    const float lfx = __builtin_fmaf(AMBER_QHI(wlx), tr.A.x, tr.b_out.x), lfy = __builtin_fmaf(AMBER_QHI(wly), tr.A.y, tr.b_out.y), lfz = __builtin_fmaf(AMBER_QHI(wlz), tr.A.z, tr.b_out.z); \
-    const float rnx = __builtin_fmaf(AMBER_QLO(wrx), tr.A.x, tr.b_in.x), rny = __builtin_fmaf(AMBER_QLO(wry), tr.A.y, tr.b_in.y), rnz = __builtin_fmaf(AMBER_QLO(wrz), tr.A.z, tr.b_in.z); \
-    const float rfx = __builtin_fmaf(AMBER_QHI(wrx), tr.A.x, tr.b_out.x), rfy = __builtin_fmaf(AMBER_QHI(wry), tr.A.y, tr.b_out.y), rfz = __builtin_fmaf(AMBER_QHI(wrz), tr.A.z, tr.b_out.z); \
-    bool hl, hr; float tl, tr_; \
-    SlabDecide(lnx, lny, lnz, lfx, lfy, lfz, tr.neg_slack, t_best, hl, tl); \
-    SlabDecide(rnx, rny, rnz, rfx, rfy, rfz, tr.neg_slack, t_best, hr, tr_); \
-    entered_ = hl ? (hr && tr_ < tl ? 2 : 1) : (hr ? 2 : 0);                       /* 1: left entered, 2: right entered, 0: neither */ \
-    if (hl && hr) { stack.push(sp, entered_ == 1 ? right : left, tr.overflow); } \
-    if (entered_ == 1) cur = left; else if (entered_ == 2) cur = right; else if (sp > 0) cur = stack.pop(sp); else cur = AMBER_BVH_DONE; }
-    int entered;
-    AMBER_FAT_LEVEL(p0, q0, entered);
-    if (entered != 0 && cur >= 0) {                          // an inner child entered: its record is already here
-      AMBER_COUNT(0);
-      const bool took_left = entered == 1;
-      const uint4 cp = took_left ? lp : rp, cq = took_left ? lq : rq;
-      int entered2;
-      AMBER_FAT_LEVEL(cp, cq, entered2);
-      (void)entered2;
-    }
-#undef AMBER_FAT_LEVEL
-#undef AMBER_ROT
-#undef AMBER_QLO
-#undef AMBER_QHI
 #else
     // uniform base + 32-bit byte offset (the tree is < 4 GB): global_load with an SGPR base, no 64-bit address arithmetic per visit
     const uint4* nd = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.bvh_nodes) + (static_cast<uint32_t>(cur) << 5));
@@ -1346,15 +1304,8 @@ __device__ __forceinline__ V3 Radiance(const DevMaterial& m, V3 normal, V3 dir_o
 __device__ __forceinline__ void SampleLight(const DevMaterial& m, V3 normal, V3 dir_out, uint64_t& rng, V3& dir_in, V3& weight) {
   const V3 rho = ld3(m.rho);
   const uint32_t kind = m.kind;
-#ifdef AMBER_HOIST_MIRROR   /* diagnostic only (EXPERIMENTS.md, "the diagnostic build that lost 5 % of its rays"): the common-subexpression form of commit 778d0a2 */
-  const float hoisted_cos_o = Dot(dir_out, normal);
-  const V3 hoisted_mirror = PerfectReflection(dir_out, normal, hoisted_cos_o);
-#define AMBER_COS_O() hoisted_cos_o
-#define AMBER_MIRROR(c_) hoisted_mirror
-#else
 #define AMBER_COS_O() Dot(dir_out, normal)
 #define AMBER_MIRROR(c_) PerfectReflection(dir_out, normal, c_)
-#endif
   if (kind == MAT_LAMBERTIAN || kind == MAT_PHONG) {
     // Lambertian (material_lambertian.cc:61-70, HemispherePSA sampling.h:234-265) and Phong (material_phong.cc:81-106,
     // CosinePower sampling.h:267-300) share the lobe construction -- orthonormal basis, two uniforms, sin/cos of phi,

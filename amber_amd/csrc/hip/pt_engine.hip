@@ -80,7 +80,6 @@ struct RenderArgs {
   uint32_t first_sample, n_samples;
   uint32_t n_chunks, n_items;   // pt_bvh_megakernel: items = (pixel, chunk); path-granular kernels: n_items = paths of the launch
   uint32_t path_offset;      // light tracing: index of the first light path of this launch's range (amber_hip_lt_trace_range)
-  uint32_t claim_shift;      // pt_megakernel: log2 of the grid's wave count rounded up to a power of two (tapered claims)
   uint32_t shade_batch;      // pt_bvh_megakernel: lanes that must have finished their traversal before the wave shades (the handle's choice, BvhShadeBatch)
 };
 
@@ -163,21 +162,6 @@ __device__ __forceinline__ void CloseRecords(const RenderArgs& a, uint32_t rec_n
 #ifndef AMBER_CLAIM_PATHS
 #define AMBER_CLAIM_PATHS 1024u
 #endif
-// Tapered claims (round 4).  The last claims of a launch decide when it ends: a wave that takes 1024 paths just before the queue runs dry
-// works on them for ~0.3 ms while the waves that found it empty drain and leave (tools/launch_tail_floor.py: even with paths capped at
-// TWO bounces a launch has 0.26 ms of fixed time).  A wave therefore sizes its claim from what was left when it LAST looked -- the value
-// its previous atomicAdd returned, no extra access to the hot word --: left / (waves of the grid, rounded up to a power of two), in
-// whole primary rounds, between AMBER_CLAIM_MIN and AMBER_CLAIM_PATHS.  Claims shrink over the last ~2 % of a config-2 launch (the
-// last ~9 % of one rank's share on 8 GPUs); a launch too small to feed every wave (the one-chunk probe, tests) starts with small claims.
-#ifndef AMBER_CLAIM_MIN
-#define AMBER_CLAIM_MIN 128u
-#endif
-// MEASURED NEUTRAL, hence off (profiles/r04_launch_tail.txt: fixed part of a launch 0.614 ms without, 0.600 ms with; 1024 spp 52.64 / 52.83 ms):
-// what a launch waits for at its end is not the last claim but the LONGEST PATH still in flight (total-internal-reflection chains of
-// 100+ bounces), whose bounces are sequential.  Kept as a build option next to its measurement.
-#ifndef AMBER_CLAIM_TAPER
-#define AMBER_CLAIM_TAPER 0
-#endif
 // Pool slot: the whole state of a path between two bounces in four 16-byte chunks {o.xyz d.x} {d.yz w.xy} {w.z rng q}
 // {casts | carried-flag, origin slot, signature hashes}.
 template <bool kLight> struct PoolLayout { static constexpr int kChunks = 4; };
@@ -206,7 +190,6 @@ __global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 5 : AMBER_MEGAKER
   uint4* pool = lds_pool[wave_in_block];
 
   uint32_t claim_next = 0, claim_end = 0;    // wave-uniform: paths claimed from the global queue, not yet generated
-  uint32_t claim_seen = 0;                   // wave-uniform: queue head after this wave's previous claim (a stale lower bound of the head)
   uint32_t pool_count = 0;                   // wave-uniform: rays in the pool (slots [0, pool_count))
   uint32_t rec_next = 0, rec_end = 0;        // wave-uniform: the wave's open block of record slots
   bool exhausted = false;                    // wave-uniform: the global queue is empty
@@ -274,20 +257,10 @@ __global__ void __launch_bounds__(256, kEngine == ENGINE_BVH ? 5 : AMBER_MEGAKER
         // (first hits, materials) at full width; the parked rays go to whichever lanes lose their path afterwards.
         AMBER_STAMP(0);
         if (claim_next == claim_end) {                        // claim the next block of paths from the global queue
-          uint32_t size = AMBER_CLAIM_PATHS;
-#if AMBER_CLAIM_TAPER
-          {
-            const uint32_t left = a.n_items > claim_seen ? a.n_items - claim_seen : 0u;
-            uint32_t want = (left >> a.claim_shift) & ~63u;                // per wave of the grid, whole primary rounds
-            if (want < AMBER_CLAIM_MIN) want = AMBER_CLAIM_MIN;
-            if (want < size) size = want;
-          }
-#endif
+          const uint32_t size = AMBER_CLAIM_PATHS;                         // (claims sized from what is left of the queue were measured neutral and removed: EXPERIMENTS.md, round 4)
           uint32_t base = 0;
           if (lane == 0) base = atomicAdd(a.next_item, size);
           base = __builtin_amdgcn_readfirstlane(base);
-          claim_seen = base + size;                                        // (wraps only past 2^32 paths: launches are capped at 2^30)
-          (void)claim_seen;
           if (base >= a.n_items) exhausted = true;
           else { claim_next = base; claim_end = a.n_items - base < size ? a.n_items : base + size; }
 #ifdef AMBER_STAMPS
@@ -542,15 +515,21 @@ __global__ void reduce_flagged_kernel(float* __restrict__ fb, uint32_t* __restri
 //    1e-5 of the model size for the difference between a binary32 eye ray and the ideal one; A is inflated by 1e-3 of its size, F by
 //    2 % of the pixel.  Aperture blades are NOT part of the mask: a ray's own blade and, on blade boundaries, its neighbours are added
 //    per ray where the path starts.
-// Double precision throughout; one thread per band pixel, once per handle (the mask depends on scene and sensor only).
+// Double precision throughout, once per handle (the mask depends on scene and sensor only).  Since round 5 one mask serves a BLOCK of 4 x 4 band
+// pixels (F = the image of the whole block): a pixel's beam is as wide as the aperture nearly everywhere, so sixteen neighbours share their
+// candidates -- config 2: 2.10 candidates per pixel instead of 1.97, the render kernel unchanged (tools/pixel_mask_blocks.py,
+// profiles/r05_pixel_mask_blocks.txt), and the kernel takes 0.07 ms instead of 1.0.
 struct PixelMaskArgs {
   double ap[4][3];                // corners of the aperture's bounding rectangle in the lens plane (inflated), RELATIVE TO THE FILTER CENTRE; pinhole: the origin
   double inv_w, inv_h;            // 1 / sensor width, height (pixels)
   double focal_scale;             // thin lens: -focus_distance / sensor_distance; pinhole: -(8 reach + 1) / sensor_distance (a point far along the ray)
   uint32_t planes_cut_a;          // bit i: plane i of the filter program passes within the slack of the aperture rectangle (the same for every pixel: tested on the host)
   uint32_t row_begin, stripe_rows, stripe_period, n_pixels;
+  uint32_t block;                 // a mask serves a block of block x block band pixels (4, or 1 when the stripes are not whole blocks): the beam of a pixel's eye rays is as
+  uint32_t blocks_x, n_blocks;    // wide as the APERTURE nearly everywhere, so 16 pixels share their candidates at a sixteenth of the work (round 5: 1.0 -> < 0.1 ms)
+  uint32_t local_rows;
 };
-// SIXTEEN LANES PER PIXEL, lane k = corner ray a_(k >> 2) -> f_(k & 3) (round 4).  Round 3's kernel ran one thread per pixel with the 16
+// SIXTEEN LANES PER BLOCK OF PIXELS, lane k = corner ray a_(k >> 2) -> f_(k & 3) (round 4: per pixel).  Round 3's kernel ran one thread per pixel with the 16
 // directions and the 16 plane points in per-thread arrays: 128 VGPRs, 1 728 B of scratch, 3.7 ms per config-2 handle -- more than the first
 // 64 samples per pixel of the render it prepares.  Here a lane keeps ITS ray (3 + 3 doubles); "on all 16 corner rays" is a vote
 // (__ballot, masked to the pixel's 16 lanes), the maxima a plane needs are butterfly reductions over the 16 lanes, the aperture
@@ -563,14 +542,15 @@ __device__ __forceinline__ double Max16(double x) {               // maximum ove
   return x;
 }
 __global__ void __launch_bounds__(256) pixel_mask_kernel(const DevScene sc, const PixelMaskArgs pm, uint32_t* __restrict__ out) {
-  const uint32_t p_raw = blockIdx.x * 16u + (threadIdx.x >> 4), k = threadIdx.x & 15u;     // 16 pixels per workgroup of 256
-  const bool live = p_raw < pm.n_pixels;
-  const uint32_t p = live ? p_raw : pm.n_pixels - 1u;              // whole groups of 16 lanes stay active (votes, shuffles); only `live` groups store
-  const uint32_t shift = threadIdx.x & 48u;                        // position of the pixel's 16 lanes in the wave's 64-bit votes
+  const uint32_t b_raw = blockIdx.x * 16u + (threadIdx.x >> 4), k = threadIdx.x & 15u;     // 16 pixel blocks per workgroup of 256
+  const bool live = b_raw < pm.n_blocks;
+  const uint32_t b = live ? b_raw : pm.n_blocks - 1u;              // whole groups of 16 lanes stay active (votes, shuffles); only `live` groups store
+  const uint32_t shift = threadIdx.x & 48u;                        // position of the block's 16 lanes in the wave's 64-bit votes
   auto all16 = [&](bool c) { return ((__ballot(c) >> shift) & 0xffffull) == 0xffffull; };
   auto any16 = [&](bool c) { return ((__ballot(c) >> shift) & 0xffffull) != 0ull; };
-  const uint32_t lrow = p / sc.sensor.w, px = p - lrow * sc.sensor.w;
-  const uint32_t py = pm.row_begin + (pm.stripe_rows ? (lrow / pm.stripe_rows) * pm.stripe_period + lrow % pm.stripe_rows : lrow);
+  const uint32_t brow = b / pm.blocks_x, lrow = brow * pm.block, px = (b - brow * pm.blocks_x) * pm.block;   // first band row and column of the block
+  const uint32_t py = pm.row_begin + (pm.stripe_rows ? (lrow / pm.stripe_rows) * pm.stripe_period + lrow % pm.stripe_rows : lrow);   // (a block never straddles two stripes)
+  const double span = static_cast<double>(pm.block);              // the block covers pixels [px, px + span) x [py, py + span)
   const DevLens& L = *sc.lens;
   const double cx = sc.fp_center[0], cy = sc.fp_center[1], cz = sc.fp_center[2];
   const double reach = sc.fp_reach;
@@ -586,8 +566,8 @@ __global__ void __launch_bounds__(256) pixel_mask_kernel(const DevScene sc, cons
   for (int c = 0; c < 3; c++) a_[c] = ki == 0u ? pm.ap[0][c] : (ki == 1u ? pm.ap[1][c] : (ki == 2u ? pm.ap[2][c] : pm.ap[3][c]));
   {
     // (an IEEE binary64 division is 64 SIMD cycles on gfx950: the wave-uniform quotients are kernel arguments)
-    const double ux = (static_cast<double>(px) + ((kj & 1u) ? 1.02 : -0.02)) * pm.inv_w;
-    const double uy = (static_cast<double>(py) + ((kj & 2u) ? 1.02 : -0.02)) * pm.inv_h;
+    const double ux = (static_cast<double>(px) + ((kj & 1u) ? span + 0.02 : -0.02)) * pm.inv_w;
+    const double uy = (static_cast<double>(py) + ((kj & 2u) ? span + 0.02 : -0.02)) * pm.inv_h;
     const double sx = (ux - 0.5) * sc.sensor.sw, sy = (uy - 0.5) * sc.sensor.sh, sz = L.sensor_distance;
     // thin lens: the point of the focal plane all rays of this sensor point pass through; pinhole: a point far along the ray
     const double kk = pm.focal_scale;
@@ -675,7 +655,9 @@ __global__ void __launch_bounds__(256) pixel_mask_kernel(const DevScene sc, cons
       mask |= miss ? 0u : bit;
     }
   }
-  if (live && k == 0u) out[p] = mask & ~sc.blade_mask;
+  // lane k stores the block's mask for its pixel (k % block, k / block) of the block, where the band has one
+  const uint32_t sx = px + k % pm.block, sr = lrow + k / pm.block;
+  if (live && k < pm.block * pm.block && sx < sc.sensor.w && sr < pm.local_rows) out[sr * sc.sensor.w + sx] = mask & ~sc.blade_mask;
 }
 
 // Engine BVH worker.  Same work queue, item walk and accumulation order as pt_megakernel, but the closest-hit query
@@ -686,9 +668,6 @@ __global__ void __launch_bounds__(256) pixel_mask_kernel(const DevScene sc, cons
 // hit resolution, material sampling, Russian roulette, regeneration -- starts their next rays and resumes.  Lanes
 // never wait for more than a batch to fill; results do not depend on the schedule (paths are independent and a
 // lane's samples are still summed in order).
-#ifndef AMBER_BVH_SUM_IN_LDS
-#define AMBER_BVH_SUM_IN_LDS 1
-#endif
 #ifndef AMBER_BVH_SHADE_BATCH
 #define AMBER_BVH_SHADE_BATCH 52   // config 3 at 128 spp, one process (descent budget 5): 24 -> 173 ms, 32 -> 172, 40 -> 166, 48 -> 162, 52 -> 160, 56 -> 160.5, 60 -> 164, 64 (wait for all lanes) -> 181
 #endif
@@ -704,21 +683,16 @@ __global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4
   const DevScene& sc = a.scene;
   const uint32_t lane = threadIdx.x & 63u;
   __shared__ int32_t lds_stack[kStack * 256];
-#if AMBER_BVH_SUM_IN_LDS
   // the item's running sum is touched once per PATH (2.6 rays): it lives in LDS ([component][thread]: conflict-free), not in three of
   // the 96 registers the traversal loop is short of -- the compiler used to keep it in scratch
   __shared__ float lds_sum[6 * 256];                       // rows 0-2: the item's sum; rows 3-5: the measurement of the path in flight.  (Two more rows for y, z of the
                                                            // throughput -- what the compiler spills next -- make 32 KB per workgroup: five no longer fit a CU, 113 ms instead of 101 at 128 spp)
   float* const my_sum = lds_sum + threadIdx.x;
-#endif
 
   uint32_t pool_next = 0, pool_end = 0;
   bool exhausted = false;
   bool lane_done = false, have_item = false, alive = false, traversing = false;
   uint32_t s = 0, s_end = 0, pixel = 0, slot = 0;          // the pixel's x, y are recomputed where a path starts: two registers less
-#if !AMBER_BVH_SUM_IN_LDS
-  V3 sum = v3(0.f, 0.f, 0.f), meas = v3(0.f, 0.f, 0.f);
-#endif
   V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), w = v3(0.f, 0.f, 0.f);
   uint64_t rng = 1;
   uint32_t casts = 0;
@@ -741,11 +715,7 @@ __global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4
     if (need && have_item) {                                // item finished: publish its sum
       if (!kLight) {
         float* p = a.partial + static_cast<size_t>(slot) * 3u;
-#if AMBER_BVH_SUM_IN_LDS
         p[0] = my_sum[0]; p[1] = my_sum[256]; p[2] = my_sum[512];
-#else
-        p[0] = sum.x; p[1] = sum.y; p[2] = sum.z;
-#endif
       }
       have_item = false;
     }
@@ -775,11 +745,7 @@ __global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4
         s = a.first_sample + chunk * AMBER_ACCUM_CHUNK;
         const uint32_t left = a.first_sample + a.n_samples - s;
         s_end = s + (left < AMBER_ACCUM_CHUNK ? left : AMBER_ACCUM_CHUNK);
-#if AMBER_BVH_SUM_IN_LDS
         my_sum[0] = 0.f; my_sum[256] = 0.f; my_sum[512] = 0.f;
-#else
-        sum = v3(0.f, 0.f, 0.f);
-#endif
         have_item = true;
         need = false;
       }
@@ -802,11 +768,7 @@ __global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4
         GenerateEyeRay(sc, pixel - py * sc.sensor.w, py, rng, o, d, ew, origin_slot);
         w = v3(ew, ew, ew);
       }
-#if AMBER_BVH_SUM_IN_LDS
       my_sum[768] = 0.f; my_sum[1024] = 0.f; my_sum[1280] = 0.f;
-#else
-      meas = v3(0.f, 0.f, 0.f);
-#endif
       casts = 0;
       alive = true;
       ++s;
@@ -830,9 +792,7 @@ __global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4
     AMBER_CLK(6);
     rays_wave += static_cast<uint32_t>(__popcll(__ballot(alive && !traversing)));
     if (alive && !traversing) {                             // shade the lanes whose closest hit is known
-#if AMBER_BVH_SUM_IN_LDS
       V3 meas = v3(my_sum[768], my_sum[1024], my_sum[1280]);  // the measurement is read and written once per bounce: LDS, not registers held across the traversal
-#endif
       if (kLight) {
         const SplatSink sink{a.splats, a.splat_count, a.splat_capacity, pixel, s - 1u, sc.sensor.size_f};
         alive = PathShade<false, ENGINE_BVH, true>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_SHADE_STAMP_ARG, &sink);
@@ -849,15 +809,9 @@ __global__ void __launch_bounds__(256, kStack <= 24 && !kSig ? AMBER_BVH_WGS : 4
       } else {
         alive = PathShade<false, ENGINE_BVH, false>(sc, nullptr, hit, o, d, w, meas, rng, casts, origin_slot, nullptr AMBER_SHADE_STAMP_ARG, nullptr);
       }
-#if AMBER_BVH_SUM_IN_LDS
       if (alive) { my_sum[768] = meas.x; my_sum[1024] = meas.y; my_sum[1280] = meas.z; }
-#endif
       if (alive) { BvhBegin(sc, o, d, tr, hit); traversing = true; }
-#if AMBER_BVH_SUM_IN_LDS
       else { my_sum[0] = my_sum[0] + meas.x; my_sum[256] = my_sum[256] + meas.y; my_sum[512] = my_sum[512] + meas.z; }   // sequential sum over the item's samples
-#else
-      else sum = sum + meas;                                // sequential sum over the item's samples
-#endif
     }
     AMBER_CLK(5);
   }
@@ -1044,7 +998,6 @@ struct amber_hip_pt {
   DevObject* d_prog_objects = nullptr;
   DevBvhNodeQ* d_bvh_nodes = nullptr;
   DevBvhNodeQ4* d_bvh_nodes4 = nullptr;      // AMBER_BVH_WIDE builds only
-  uint4* d_bvh_fat = nullptr;                // AMBER_BVH_FAT builds only
   float4* d_bvh_spheres = nullptr;
   float4* d_bvh_tris = nullptr;
   uint32_t* d_bvh_prims = nullptr;
@@ -1084,10 +1037,12 @@ struct amber_hip_pt {
   int32_t* d_bvh_stack = nullptr;  size_t bvh_stack_ints = 0;     // pt_bvh_pool_kernel: deep traversal-stack levels
   float* d_carried = nullptr;      size_t carried_floats = 0;     // ... and carried measurements
   unsigned long long* d_sig = nullptr;  uint64_t sig_paths = 0;   // amber_hip_pt_signatures
-  uint32_t* d_pixel_mask = nullptr;  bool pixel_mask_ready = false, pixel_mask_on = true;   // two-phase engine: primary-ray candidates per band pixel
+  uint32_t* d_pixel_mask = nullptr;  bool pixel_mask_on = true;   // two-phase engine: primary-ray candidates per band pixel
+  // pixel_mask_kernel is enqueued on the render stream by create (0.07 ms since the masks are per 4 x 4 block of pixels: it no longer pays to
+  // overlap it -- a second stream costs a millisecond of host time to create, more than the kernel it would hide)
+  bool pixel_mask_ready = false;            // the kernel has been enqueued in front of everything that reads d_pixel_mask
   std::vector<uint32_t> prog_order;         // two-phase engine: scene index of the object in filter-program slot k (the bit positions of the masks)
   std::vector<DevPlane> host_planes;        // ... and its plane records (pixel_mask_kernel's wave-uniform tests are made on the host)
-  float pixel_mask_ms = 0;                  // duration of pixel_mask_kernel (amber_hip_kat_pixel_masks)
   uint32_t lens_kind = 0; float lens_sensor_distance = 0, lens_focus_distance = 0, lens_origin[3] = {0, 0, 0};   // host copies of the lens constants pixel_mask_kernel's arguments derive from
   float aperture_rect[4][3] = {};           // world corners of the blades' bounding rectangle in the lens plane (pixel_mask_kernel)
   int n_cus = 256;
@@ -1118,6 +1073,8 @@ struct DevBuf {
   ~DevBuf() { if (p) (void)hipFree(p); }
   hipError_t alloc(size_t n) { return hipMalloc(&p, (n ? n : 1) * sizeof(T)); }
 };
+
+int StartPixelMasks(amber_hip_pt* h, float* timing);      // defined with the launch code below
 
 int ValidateScene(const AmberFlatScene* s, const AmberSensor* sensor) {
   if (!s || !sensor) return Fail(AMBER_EINVAL, "null scene or sensor");
@@ -1256,16 +1213,6 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
                    what, q.inner_area, q.leaf_area, q.leaf_object_area, q.leaf_volume, q.inner, q.leaves, q.depth);
     };
     if (debug_bvh) report("as built");
-    if (const char* ev = std::getenv("AMBER_BVH_ROTATE")) {                   // measurement hook (EXPERIMENTS.md, round 5): tree rotations after the build
-      const int passes = std::atoi(ev);
-      if (passes > 0) {
-        const size_t n_rot = amber_bvh::RotateBvh(bvh.nodes, bvh.root_ref, passes);
-        if (debug_bvh) { std::fprintf(stderr, "amber_hip: BVH: %zu rotations in <= %d passes\n", n_rot, passes); report("after rotations"); }
-      }
-    }
-    if (bvh.depth > static_cast<uint32_t>(amber_bvh::kMaxDepth)) { amber_hip_pt_destroy(h); return Fail(AMBER_EINVAL, "BVH deeper than the device stack"); }
-    h->bvh_depth = bvh.depth;
-    h->bvh_paths = !h->bvh_pool && !(params->reserved & AMBER_PT_FLAG_BVH_ITEMS) && h->engine != AMBER_ENGINE_WAVEFRONT && bvh.depth <= static_cast<uint32_t>(AMBER_PATH_BVH_STACK);
     // The shading batch of pt_bvh_megakernel.  While a wave collects finished lanes they idle through the rounds of the others, and a round
     // over triangle leaves costs about twice a round over sphere leaves (45 against 20 vector instructions per leaf object before any
     // root / quotient), so idle lanes are dearer in a mesh: tools/shade_batch_sweep.py (profiles/r05_shade_batch_sweep.txt) -- 1M spheres
@@ -1344,21 +1291,6 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMalloc(&h->d_bvh_nodes, (qbvh.nodes.size() + 1) * sizeof(DevBvhNodeQ)));
   HIP_TRY_H(hipMalloc(&h->d_bvh_prims, (bvh.prim_index.size() + 1) * sizeof(uint32_t)));
   if (!qbvh.nodes.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_nodes, qbvh.nodes.data(), qbvh.nodes.size() * sizeof(DevBvhNodeQ), hipMemcpyHostToDevice));
-#if AMBER_BVH_FAT
-  {
-    // every inner node followed by copies of its children's records (zeros for a leaf child: never read)
-    std::vector<DevBvhNodeQ> fat(3 * qbvh.nodes.size());
-    for (size_t i = 0; i < qbvh.nodes.size(); i++) {
-      const DevBvhNodeQ& nd = qbvh.nodes[i];
-      fat[3 * i] = nd;
-      std::memset(&fat[3 * i + 1], 0, 2 * sizeof(DevBvhNodeQ));
-      if (nd.left >= 0) fat[3 * i + 1] = qbvh.nodes[nd.left];
-      if (nd.right >= 0) fat[3 * i + 2] = qbvh.nodes[nd.right];
-    }
-    HIP_TRY_H(hipMalloc(&h->d_bvh_fat, (fat.size() + 3) * sizeof(DevBvhNodeQ)));
-    if (!fat.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_fat, fat.data(), fat.size() * sizeof(DevBvhNodeQ), hipMemcpyHostToDevice));
-  }
-#endif
 #if AMBER_BVH_WIDE
   {
     amber_bvh::QuantizedBvh4 q4 = amber_bvh::CollapseBvh4(bvh.nodes, bvh.root_ref, qbvh, [&](uint32_t slot) { return objs[bvh.prim_index[slot]].kind & 0xffu; });
@@ -1415,7 +1347,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades;
   sc.planes = h->d_planes; sc.tri_filters = h->d_tri_filters; sc.sphere_filters = h->d_sphere_filters;
   sc.n_planes = static_cast<uint32_t>(fprog.planes.size()); sc.n_simple_planes = fprog.n_simple_planes; sc.n_sphere_filters = static_cast<uint32_t>(fprog.spheres.size());
-  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_nodes4 = h->d_bvh_nodes4; sc.bvh_fat = h->d_bvh_fat; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_spheres = h->d_bvh_spheres; sc.bvh_tris = h->d_bvh_tris; sc.bvh_root = qbvh.root_ref;
+  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_nodes4 = h->d_bvh_nodes4; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_spheres = h->d_bvh_spheres; sc.bvh_tris = h->d_bvh_tris; sc.bvh_root = qbvh.root_ref;
   for (int c = 0; c < 3; c++) { sc.bvh_gmin[c] = qbvh.gmin[c]; sc.bvh_step[c] = qbvh.step[c]; sc.bvh_reach[c] = qbvh.reach[c]; }
   {
     // per-ray box margin of engine BVH (BvhBegin): centre and half diagonal of the scene bounds, 1 / smallest sphere radius
@@ -1502,6 +1434,10 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMalloc(&h->d_lens, sizeof(DevLens)));
   HIP_TRY_H(hipMemcpy(h->d_lens, &lens, sizeof(DevLens), hipMemcpyHostToDevice));
   sc.lens = h->d_lens;
+  {
+    const int rc_masks = StartPixelMasks(h, nullptr);          // asynchronous, on the render stream: in front of the handle's first launch
+    if (rc_masks != AMBER_OK) { const std::string msg = g_last_error; amber_hip_pt_destroy(h); return Fail(rc_masks, msg); }
+  }
   *out = h;
   return AMBER_OK;
 }
@@ -1625,9 +1561,6 @@ namespace {
 constexpr uint64_t kMaxPathsPerLaunch = 1ull << 30;       // q and its bitmap index stay 32-bit; bitmap 128 MiB
 constexpr uint64_t kMaxRecordSlots = 48ull << 20;         // 28 B per slot (record + sorted measurement): 1.3 GiB at most
 
-// log2 of (waves of a grid of n_blocks workgroups of 4) rounded up to a power of two: RenderArgs.claim_shift
-uint32_t ClaimShift(uint32_t n_blocks) { uint32_t sh = 0; while ((1ull << sh) < static_cast<uint64_t>(n_blocks) * 4u) ++sh; return sh; }
-
 uint32_t PathBlocks(const amber_hip_pt* h, uint64_t n_paths) {
   const bool bvh = h->hit_engine == AMBER_ENGINE_BVH && !h->bvh_paths;
   uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * (bvh ? static_cast<uint32_t>(AMBER_BVH_POOL_WGS) : ResidentBlocksPerCu(h->hit_engine, h->bvh_depth));
@@ -1663,17 +1596,24 @@ int EnsureLaunchCtl(amber_hip_pt* h) {                                       // 
   return AMBER_OK;
 }
 
-// Two-phase engine, once per handle: the candidate mask of every band pixel's eye rays (pixel_mask_kernel), enqueued on the render
-// stream in front of the handle's first launch.  timed: bracket the kernel with events and wait (amber_hip_kat_pixel_masks).
-int EnsurePixelMasks(amber_hip_pt* h, uint32_t n_pixels, bool timed) {
-  if (!(h->two_phase && h->pixel_mask_on) || h->pixel_mask_ready || n_pixels == 0) return AMBER_OK;
-  HIP_TRY(hipMalloc(&h->d_pixel_mask, static_cast<size_t>(n_pixels) * sizeof(uint32_t)));
+// Two-phase engine, once per handle: the candidate mask of every band pixel's eye rays (pixel_mask_kernel), enqueued on the render stream by
+// create -- in front of the handle's first launch.  The buffer is allocated once and owned by the handle (amber_hip_pt_destroy releases it
+// whatever step failed).  `timing` != null (amber_hip_kat_pixel_masks): run the kernel (again) between two events and report its duration.
+int StartPixelMasks(amber_hip_pt* h, float* timing) {
+  const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
+  if (!(h->two_phase && h->pixel_mask_on) || n_pixels == 0 || (h->pixel_mask_ready && !timing)) return AMBER_OK;
+  if (!h->d_pixel_mask) HIP_TRY(hipMalloc(&h->d_pixel_mask, static_cast<size_t>(n_pixels) * sizeof(uint32_t)));
   PixelMaskArgs pm{};
   for (int i = 0; i < 4; i++) for (int c = 0; c < 3; c++) pm.ap[i][c] = static_cast<double>(h->aperture_rect[i][c]) - static_cast<double>(h->scene.fp_center[c]);
   pm.inv_w = 1.0 / static_cast<double>(h->scene.sensor.wf); pm.inv_h = 1.0 / static_cast<double>(h->scene.sensor.hf);
   pm.focal_scale = h->lens_kind == 1u ? -(8.0 * static_cast<double>(h->scene.fp_reach) + 1.0) / static_cast<double>(h->lens_sensor_distance)
                                       : static_cast<double>(h->lens_focus_distance) / -static_cast<double>(h->lens_sensor_distance);
   pm.row_begin = h->row_begin; pm.stripe_rows = h->stripe_rows; pm.stripe_period = h->stripe_period; pm.n_pixels = n_pixels;
+  pm.block = (h->stripe_rows == 0u || h->stripe_rows % 4u == 0u) ? 4u : 1u;
+  { const char* ev = std::getenv("AMBER_PIXEL_MASK_BLOCK"); if (ev && (ev[0] == '1' || ev[0] == '2' || ev[0] == '4') && ev[1] == 0 && (h->stripe_rows == 0u || h->stripe_rows % static_cast<uint32_t>(ev[0] - '0') == 0u)) pm.block = static_cast<uint32_t>(ev[0] - '0'); }   // measurement hook
+  pm.local_rows = h->local_rows;
+  pm.blocks_x = (h->scene.sensor.w + pm.block - 1u) / pm.block;
+  pm.n_blocks = pm.blocks_x * ((h->local_rows + pm.block - 1u) / pm.block);
   {
     // "does plane i cut the aperture rectangle?" -- the kernel's own expressions (binary64, the slack of its first lines), evaluated once
     const DevScene& sc = h->scene;
@@ -1693,10 +1633,10 @@ int EnsurePixelMasks(amber_hip_pt* h, uint32_t n_pixels, bool timed) {
     }
   }
   struct Events { hipEvent_t a = nullptr, b = nullptr; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evs;
-  if (timed) { HIP_TRY(hipEventCreate(&evs.a)); HIP_TRY(hipEventCreate(&evs.b)); HIP_TRY(hipEventRecord(evs.a, h->stream)); }
-  hipLaunchKernelGGL(pixel_mask_kernel, dim3((n_pixels + 15u) / 16u), dim3(256), 0, h->stream, h->scene, pm, h->d_pixel_mask);   // 16 lanes per pixel
+  if (timing) { HIP_TRY(hipEventCreate(&evs.a)); HIP_TRY(hipEventCreate(&evs.b)); HIP_TRY(hipEventRecord(evs.a, h->stream)); }
+  hipLaunchKernelGGL(pixel_mask_kernel, dim3((pm.n_blocks + 15u) / 16u), dim3(256), 0, h->stream, h->scene, pm, h->d_pixel_mask);   // 16 lanes per block of pixels
   HIP_TRY(hipGetLastError());
-  if (timed) { HIP_TRY(hipEventRecord(evs.b, h->stream)); HIP_TRY(hipEventSynchronize(evs.b)); HIP_TRY(hipEventElapsedTime(&h->pixel_mask_ms, evs.a, evs.b)); }
+  if (timing) { HIP_TRY(hipEventRecord(evs.b, h->stream)); HIP_TRY(hipEventSynchronize(evs.b)); HIP_TRY(hipEventElapsedTime(timing, evs.a, evs.b)); }
   h->pixel_mask_ready = true;
   return AMBER_OK;
 }
@@ -1756,7 +1696,6 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
       h->bvh_stack_ints = stack_ints;
     }
   }
-  { const int rc = EnsurePixelMasks(h, n_pixels, false); if (rc != AMBER_OK) return rc; }
   RenderArgs a{};
   a.pixel_mask = h->pixel_mask_ready ? h->d_pixel_mask : nullptr;
   a.scene = h->scene; a.flags = h->d_flags; a.touched = h->d_touched; a.records = h->d_records; a.rec_count = h->d_rec_count; a.rec_capacity = h->rec_capacity;
@@ -1764,7 +1703,6 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
   a.bvh_stack = h->d_bvh_stack; a.carried = h->d_carried; a.sig = sig;
   a.row_begin = h->row_begin; a.stripe_rows = h->stripe_rows; a.stripe_period = h->stripe_period; a.n_pixels = n_pixels; a.first_sample = first; a.n_samples = n;
   a.n_chunks = (n + AMBER_ACCUM_CHUNK - 1) / AMBER_ACCUM_CHUNK; a.n_items = static_cast<uint32_t>(n_paths);
-  a.claim_shift = ClaimShift(n_blocks);
   HIP_TRY(hipMemsetAsync(h->d_launch_ctl, 0, 4 * sizeof(unsigned int), h->stream));
   // The bitmap is cleared by the reduction itself where it can be (whole words per pixel); the host clears all of it only when a
   // launch left it dirty: the first use, sample counts that are not multiples of 32, signature launches, a launch that ran out of slots.
@@ -1988,8 +1926,7 @@ int amber_hip_lt_trace_range(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
     uint32_t n_blocks = static_cast<uint32_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, h->bvh_depth);
     const uint32_t by_work = (a.n_items + 255u) / 256u;
     if (by_work < n_blocks) n_blocks = by_work;
-    a.claim_shift = ClaimShift(n_blocks);
-    if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+      if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (bvh) {
       if (h->bvh_depth <= 24) hipLaunchKernelGGL((pt_bvh_megakernel<true, 24>), dim3(n_blocks), dim3(256), 0, h->stream, a);
       else hipLaunchKernelGGL((pt_bvh_megakernel<true, AMBER_BVH_STACK>), dim3(n_blocks), dim3(256), 0, h->stream, a);
@@ -2127,7 +2064,6 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_prog_objects) (void)hipFree(h->d_prog_objects);
   if (h->d_bvh_nodes) (void)hipFree(h->d_bvh_nodes);
   if (h->d_bvh_nodes4) (void)hipFree(h->d_bvh_nodes4);
-  if (h->d_bvh_fat) (void)hipFree(h->d_bvh_fat);
   if (h->d_bvh_spheres) (void)hipFree(h->d_bvh_spheres);
   if (h->d_bvh_tris) (void)hipFree(h->d_bvh_tris);
   if (h->d_bvh_prims) (void)hipFree(h->d_bvh_prims);
@@ -2326,17 +2262,19 @@ int amber_hip_kat_pixel_masks(amber_hip_pt* h, uint32_t* out_mask, uint32_t* out
   HIP_TRY(hipSetDevice(h->device));
   { const int rc = ResolvePending(h); if (rc != AMBER_OK) return rc; }
   const uint32_t n_pixels = h->local_rows * h->scene.sensor.w;
-  const bool was_ready = h->pixel_mask_ready;
-  { const int rc = EnsurePixelMasks(h, n_pixels, true); if (rc != AMBER_OK) return rc; }
-  if (!h->pixel_mask_ready) return Fail(AMBER_EINVAL, "pixel masks are switched off (AMBER_PIXEL_MASK=0) or the band is empty");
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  if (out_mask) HIP_TRY(hipMemcpy(out_mask, h->d_pixel_mask, static_cast<size_t>(n_pixels) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (out_mask || kernel_ms) {                                 // the slot table and the always-mask below do not need the kernel
+    float ms = 0;
+    { const int rc = StartPixelMasks(h, kernel_ms ? &ms : nullptr); if (rc != AMBER_OK) return rc; }
+    if (!h->pixel_mask_ready) return Fail(AMBER_EINVAL, "pixel masks are switched off (AMBER_PIXEL_MASK=0) or the band is empty");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (out_mask) HIP_TRY(hipMemcpy(out_mask, h->d_pixel_mask, static_cast<size_t>(n_pixels) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (kernel_ms) *kernel_ms = static_cast<double>(ms);
+  }
   if (out_slot_of_object) {
     for (uint32_t i = 0; i < h->scene.n_objects; i++) out_slot_of_object[i] = 0xffffffffu;
     for (size_t k = 0; k < h->prog_order.size(); k++) if (h->prog_order[k] < h->scene.n_objects) out_slot_of_object[h->prog_order[k]] = static_cast<uint32_t>(k);
   }
   if (out_always_mask) *out_always_mask = h->scene.always_mask | h->scene.blade_mask;
-  if (kernel_ms) *kernel_ms = was_ready ? -1.0 : static_cast<double>(h->pixel_mask_ms);
   return AMBER_OK;
 }
 

@@ -48,7 +48,7 @@ def _first_hits(pt, W, pixels, samples):
 def _check_masks(amber, hs, n_objects, W, H, seed, rows=None, stripe=None, n=60_000):
     pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=seed, rows=rows, stripe=stripe)
     masks, ms = pt.pixel_masks()
-    slots = pt.object_slots(n_objects)
+    slots, always_mask = pt.object_slots(n_objects)
     rng = np.random.default_rng(seed)
     local = rng.integers(0, masks.size, n)
     lrow, x = local // W, local % W
@@ -58,7 +58,7 @@ def _check_masks(amber, hs, n_objects, W, H, seed, rows=None, stripe=None, n=60_
     obj = _first_hits(pt, W, pix, sm)
     hit = obj >= 0
     slot = slots[obj[hit]]
-    m = masks.reshape(-1)[local[hit]] | np.uint32(pt.always_mask)                     # blades (added per ray) and objects without a filter record
+    m = masks.reshape(-1)[local[hit]] | np.uint32(always_mask)                     # blades (added per ray) and objects without a filter record
     covered = ((m >> np.minimum(slot, 31).astype(np.uint32)) & 1).astype(bool) & (slot < 32)
     bad = ~covered
     assert not bad.any(), (int(bad.sum()), obj[hit][bad][:5], pix[hit][bad][:5])
