@@ -1,7 +1,8 @@
 """amber_amd -- MI355X-native path-tracing integrator for amber (etheriqa/amber's `pt` hot path).
 
 The product is the shared library ``amber_amd/lib/libamber_hip.so`` (gfx950 kernels, the C ABI of
-``include/amber_hip.h`` and the C++ host object model of ``amber_amd/csrc/amber``).  This Python
+``include/amber_hip.h`` and the C++ host object model of ``amber_amd/csrc/amber``); the tests load
+``libamber_hip_lab.so``, the same sources plus the known-answer entry points (``include/amber_hip_lab.h``).  This Python
 package is a thin ctypes binding used by the tests, ``bench.py`` and the multi-GPU driver; it
 contains no rendering code of its own and has no CPU fallback.
 """
@@ -12,6 +13,7 @@ from .api import (  # noqa: F401
     ENGINE_LIST,
     ENGINE_TWO_PHASE,
     ENGINE_WAVEFRONT,
+    PT_FLAG_BVH_ITEMS,
     PT_FLAG_BVH_POOL,
     AmberError,
     FlatMaterial,
@@ -23,6 +25,7 @@ from .api import (  # noqa: F401
     Sensor,
     build_library,
     device_count,
+    is_lab,
     export,
     MATH_GLIBC,
     MATH_PORTABLE,

@@ -9,7 +9,8 @@ from pathlib import Path
 import numpy as np
 
 _ROOT = Path(__file__).resolve().parent
-# AMBER_AMD_LIB selects a measurement build next to the product library (tools/: stamps, portable math); default = the product
+# AMBER_AMD_LIB selects another build next to the product library: libamber_hip_lab.so (tests/ and the tools that use the known-answer entry
+# points, signatures or the measured-and-kept schedulers) or a measurement build (stamps, portable math); default = the product
 _LIB_PATH = _ROOT / "lib" / os.environ.get("AMBER_AMD_LIB", "libamber_hip.so")
 _lib = None
 
@@ -73,15 +74,20 @@ MAT_LAMBERTIAN, MAT_PHONG, MAT_SPECULAR, MAT_REFRACTION, MAT_DIFFUSE_LIGHT, MAT_
 ENGINE_AUTO, ENGINE_LIST, ENGINE_TWO_PHASE, ENGINE_BVH, ENGINE_WAVEFRONT = 0, 1, 2, 3, 4
 PT_FLAG_NULL_STREAM, PT_FLAG_BVH_POOL, PT_FLAG_BVH_ITEMS = 1, 2, 4
 
-# every symbol include/amber_hip.h and include/amber_host.h declare
+# every symbol include/amber_hip.h and include/amber_host.h declare: what libamber_hip.so (the product) exports
 ABI_SYMBOLS = [
     "amber_hip_pt_create", "amber_hip_pt_render_pass", "amber_hip_pt_clear", "amber_hip_pt_sync",
     "amber_hip_pt_download", "amber_hip_pt_device_framebuffer", "amber_hip_pt_stream", "amber_hip_pt_local_rows", "amber_hip_pt_kernel_time", "amber_hip_pt_destroy",
     "amber_hip_last_error", "amber_hip_abi_version", "amber_hip_math_mode", "amber_hip_device_count", "amber_hip_lt_trace", "amber_hip_lt_trace_range",
-    "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math", "amber_hip_kat_signatures", "amber_hip_pt_signatures", "amber_hip_kat_traversal_rate", "amber_hip_kat_pixel_masks",
     "amber_host_cornell_box", "amber_host_scene_import", "amber_host_scene_create", "amber_host_scene_destroy", "amber_host_scene_flatten",
     "amber_host_pt_create", "amber_host_render", "amber_host_render_devices", "amber_host_last_error", "amber_host_tonemap", "amber_host_export",
 ]
+# what include/amber_hip_lab.h declares: libamber_hip_lab.so (the same sources with -DAMBER_LAB) exports these as well
+LAB_SYMBOLS = [
+    "amber_hip_kat_cast", "amber_hip_kat_sample", "amber_hip_kat_eye", "amber_hip_kat_trace", "amber_hip_kat_math", "amber_hip_kat_signatures", "amber_hip_pt_signatures",
+    "amber_hip_kat_traversal_rate", "amber_hip_kat_pixel_masks",
+]
+PRODUCT_LIB, LAB_LIB = "libamber_hip.so", "libamber_hip_lab.so"
 
 
 def library_path() -> Path:
@@ -98,8 +104,13 @@ def build_library(force: bool = False) -> Path:
     return _LIB_PATH
 
 
+def is_lab() -> bool:
+    """True when the loaded library is a lab build (it has the entry points of include/amber_hip_lab.h)."""
+    return hasattr(load_library(), "amber_hip_kat_cast")
+
+
 def load_library() -> C.CDLL:
-    """Load libamber_hip.so.  Fails loudly: there is no CPU implementation to fall back to."""
+    """Load libamber_hip.so (or the build AMBER_AMD_LIB names).  Fails loudly: there is no CPU implementation to fall back to."""
     global _lib
     if _lib is not None:
         return _lib
@@ -125,16 +136,15 @@ def load_library() -> C.CDLL:
         lib.amber_hip_lt_trace.argtypes = [vp, u32, u32, vp, u32, C.POINTER(u32), C.POINTER(u64)]
     if hasattr(lib, "amber_hip_lt_trace_range"):
         lib.amber_hip_lt_trace_range.argtypes = [vp, u32, u32, u32, u32, vp, u32, C.POINTER(u32), C.POINTER(u64)]
-    lib.amber_hip_kat_cast.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
-    lib.amber_hip_kat_sample.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
-    lib.amber_hip_kat_eye.argtypes = [vp, u32, vp, vp, vp]
-    lib.amber_hip_kat_trace.argtypes = [vp, u32, vp, vp, u32, vp, vp]
-    lib.amber_hip_kat_math.argtypes = [i32, i32, u32, vp, vp]
-    lib.amber_hip_kat_signatures.argtypes = [vp, u32, u32, vp]
-    lib.amber_hip_kat_pixel_masks.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
-    if hasattr(lib, "amber_hip_kat_traversal_rate"):
+    if hasattr(lib, "amber_hip_kat_cast"):         # the lab build (include/amber_hip_lab.h); the product exports none of these
+        lib.amber_hip_kat_cast.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
+        lib.amber_hip_kat_sample.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
+        lib.amber_hip_kat_eye.argtypes = [vp, u32, vp, vp, vp]
+        lib.amber_hip_kat_trace.argtypes = [vp, u32, vp, vp, u32, vp, vp]
+        lib.amber_hip_kat_math.argtypes = [i32, i32, u32, vp, vp]
+        lib.amber_hip_kat_signatures.argtypes = [vp, u32, u32, vp]
+        lib.amber_hip_kat_pixel_masks.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         lib.amber_hip_kat_traversal_rate.argtypes = [vp, u32, vp, vp, u32, u32, u32, vp, vp, C.POINTER(C.c_double), vp]
-    if hasattr(lib, "amber_hip_pt_signatures"):    # absent only in older builds loaded by tools/ab_lib.py
         lib.amber_hip_pt_signatures.argtypes = [vp, u32, u32, vp]
     lib.amber_host_cornell_box.restype = vp
     lib.amber_host_cornell_box.argtypes = [C.c_float, C.c_float, u32]

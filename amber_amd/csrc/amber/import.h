@@ -29,6 +29,7 @@
 
 #include "scene.h"
 
+#pragma GCC visibility push(default)   // the C++ interface of the host object model is exported (bin/amber links against it)
 namespace amber {
 namespace cli {
 
@@ -44,3 +45,4 @@ scene::RGBScene ImportSceneBVH(const std::string& filename);
 
 }  // namespace cli
 }  // namespace amber
+#pragma GCC visibility pop

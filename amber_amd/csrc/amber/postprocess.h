@@ -9,6 +9,7 @@
 
 #include "prelude.h"
 
+#pragma GCC visibility push(default)   // the C++ interface of the host object model is exported (bin/amber links against it)
 namespace amber {
 namespace postprocess {
 
@@ -37,3 +38,4 @@ void ExportPNG(const postprocess::LDRImage& image, const std::string& filename);
 void ExportEXR(const postprocess::HDRImage& image, const std::string& filename);
 }  // namespace cli
 }  // namespace amber
+#pragma GCC visibility pop

@@ -19,6 +19,7 @@
 #include <valarray>
 #include <vector>
 
+#pragma GCC visibility push(default)   // the C++ interface of the host object model is exported (bin/amber links against it)
 namespace amber {
 
 // constants.h:25-28
@@ -143,3 +144,4 @@ class Image {
 
 }  // namespace prelude
 }  // namespace amber
+#pragma GCC visibility pop

@@ -20,6 +20,7 @@
 #include "prelude.h"
 #include "scene.h"
 
+#pragma GCC visibility push(default)   // the C++ interface of the host object model is exported (bin/amber links against it)
 namespace amber {
 namespace rendering {
 
@@ -149,3 +150,4 @@ std::unique_ptr<rendering::Algorithm<rendering::RGB>> MakeAlgorithm(const std::s
                                                                    const rendering::HipPathTracingOptions& options);
 }  // namespace cli
 }  // namespace amber
+#pragma GCC visibility pop

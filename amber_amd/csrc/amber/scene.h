@@ -21,6 +21,7 @@
 #include "../../../include/amber_hip.h"
 #include "prelude.h"
 
+#pragma GCC visibility push(default)   // the C++ interface of the host object model is exported (bin/amber links against it)
 namespace amber {
 
 namespace rendering {
@@ -165,3 +166,4 @@ scene::RGBScene CornelBox(scene::real_type focal_length, scene::real_type apertu
 }  // namespace etude
 
 }  // namespace amber
+#pragma GCC visibility pop

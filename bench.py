@@ -122,7 +122,20 @@ def cpu_baseline(amber_amd, width: int, spp_job: int, seed: int, many_s: float =
         c1, d1 = timed(1, spp1, 1, rows=rows1)
         out["single_thread_value"] = round(c1 / d1 / 1e6, 3)
         out["sample"] += f"; 1 thread: full frame @ {spp1} spp ({c1} rays in {d1:.2f} s)"
-    parity = compare_rows(amber_amd, width, spp_job, seed, threads=cores, math=O.MATH_LIBM, accel=O.ACCEL_BVH)
+    # images and ray counts: the PRODUCT library, in this process.  Per-path signatures come from the signature instantiation of the same kernels,
+    # which only the lab build has (include/amber_hip_lab.h): a child process on libamber_hip_lab.so adds them.
+    parity = compare_rows(amber_amd, width, spp_job, seed, threads=cores, math=O.MATH_LIBM, accel=O.ACCEL_BVH, signatures=amber_amd.is_lab())
+    parity["library"] = amber_amd.library_path().name
+    if not amber_amd.is_lab():
+        code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r); import amber_amd, oracle_binding as O; from parity_rows import compare_rows; "
+                "r = compare_rows(amber_amd, %d, %d, %d, threads=%d, math=O.MATH_LIBM, accel=O.ACCEL_BVH); r['library'] = amber_amd.library_path().name; print('PARITY ' + json.dumps(r))"
+                % (str(ROOT), str(ROOT / "tests"), width, spp_job, seed, cores))
+        try:
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, AMBER_AMD_LIB="libamber_hip_lab.so"))
+            line = [l for l in r.stdout.splitlines() if l.startswith("PARITY ")]
+            parity["signatures_lab_build"] = json.loads(line[0][7:]) if line else {"error": (r.stderr or "no result")[-200:]}
+        except Exception as e:
+            parity["signatures_lab_build"] = {"error": str(e)[:200]}
     return out, parity
 
 

@@ -25,8 +25,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the libraries are built with -fvisibility=hidden: what these headers declare is what they export */
 
-#define AMBER_HIP_ABI_VERSION 2   /* 2 (round 4): entry points added since 1 (signatures, traversal rate, lt ranges, stream); a stream-ordered read of
+#define AMBER_HIP_ABI_VERSION 3   /* 3 (round 5): the known-answer / signature entry points, engine WAVEFRONT and AMBER_PT_FLAG_BVH_POOL moved to the lab library
+                                    (amber_hip_lab.h); AMBER_PT_FLAG_BVH_ITEMS added.  2 (round 4): lt ranges, stream; a stream-ordered read of
                                     amber_hip_pt_device_framebuffer() needs amber_hip_pt_sync() first when a launch may have run out of record slots */
 
 /* Accumulation granule: within a render pass the samples of a pixel are summed sequentially in chunks of
@@ -136,8 +138,8 @@ typedef struct {
 } AmberPtParams;
 enum {
   AMBER_PT_FLAG_NULL_STREAM = 1u,
-  AMBER_PT_FLAG_BVH_POOL = 2u,    /* engine BVH: schedule with the per-wave ray pool (pt_bvh_pool_kernel) instead of the default
-                                     (pt_bvh_megakernel).  Same results bit for bit; measured slower on the 1M-sphere scene. */
+  AMBER_PT_FLAG_BVH_POOL = 2u,    /* LAB BUILD ONLY (the product answers AMBER_EINVAL): engine BVH scheduled with the per-wave ray pool
+                                     (pt_bvh_pool_kernel).  Same results bit for bit; measured slower on the 1M-sphere scene. */
   AMBER_PT_FLAG_BVH_ITEMS = 4u    /* engine BVH: always pt_bvh_megakernel.  By default a tree of depth <= 12 (scenes of a few hundred
                                      objects) renders with the path-granular kernel and a one-shot per-lane traversal
                                      (pt_megakernel<ENGINE_BVH>): same results bit for bit, faster on shallow trees. */
@@ -150,11 +152,13 @@ enum {
   AMBER_ENGINE_LIST = 1,       /* exact test of every object, wave-uniform scan (object data in SGPRs) */
   AMBER_ENGINE_TWO_PHASE = 2,  /* conservative wave-uniform candidate filter, then exact tests of the candidates only */
   AMBER_ENGINE_BVH = 3,        /* host-built flattened 2-wide BVH, per-lane traversal with an LDS stack, exact leaf tests */
-  AMBER_ENGINE_WAVEFRONT = 4   /* streaming formulation: SoA ray queues in HBM, one launch per bounce, ballot/prefix-sum
-                                  compaction; closest hit as AUTO.  Same results; kept to measure that design. */
+  AMBER_ENGINE_WAVEFRONT = 4   /* LAB BUILD ONLY (the product answers AMBER_EINVAL): streaming formulation -- SoA ray queues in HBM, one launch
+                                  per bounce, ballot/prefix-sum compaction; closest hit as AUTO.  Same results; kept to measure that design. */
 };
 
+#pragma GCC visibility push(hidden)            /* the handle is opaque: its members (and their constructors) are not part of the ABI */
 typedef struct amber_hip_pt amber_hip_pt;
+#pragma GCC visibility pop
 
 /* Uploads the flattened scene to HBM and allocates the band framebuffer (zeroed). */
 int  amber_hip_pt_create(const AmberFlatScene* scene, const AmberSensor* sensor,
@@ -204,48 +208,11 @@ enum { AMBER_MATH_PORTABLE = 1, AMBER_MATH_GLIBC = 2 };
 int         amber_hip_math_mode(void);
 int         amber_hip_device_count(void);
 
-/* ---- known-answer entry points (same device functions as the render kernels) --------------
- * Used by tests/ to compare individual stages against the oracle.  All buffers are HOST
- * pointers; n items; synchronous. */
-/* closest hit: out_object = object index or -1 */
-int amber_hip_kat_cast(amber_hip_pt*, uint32_t n, const float* origins /*n*3*/, const float* dirs /*n*3*/,
-                       int32_t* out_object, float* out_t, float* out_pos /*n*3*/, float* out_normal /*n*3*/);
-/* material sampling with a per-item XorShift state; returns dir_in, weight and the advanced state */
-int amber_hip_kat_sample(amber_hip_pt*, uint32_t n, const uint32_t* material /*n*/, const float* normals,
-                         const float* dirs_out, uint64_t* rng_state /*n, in/out*/, float* out_dir_in, float* out_weight);
-/* eye rays for (pixel index, sample) pairs: out = origin[3] dir[3] weight */
-int amber_hip_kat_eye(amber_hip_pt*, uint32_t n, const uint32_t* pixel, const uint32_t* sample, float* out7);
-/* full per-path trace: for item i writes up to max_bounces records of
- * {object(int32 as float bits), t, pos[3], weight[3], measurement[3]} (11 x 4 bytes) and the cast count */
-int amber_hip_kat_trace(amber_hip_pt*, uint32_t n, const uint32_t* pixel, const uint32_t* sample,
-                        uint32_t max_bounces, uint32_t* out_records /*n*max_bounces*11*/, uint32_t* out_casts /*n*/);
-/* Path signatures of the handle's rows for samples [first_sample, first_sample + n_samples): out[(band pixel * n_samples) + k]
- * = FNV-1a-32 over the object index of every cast of that path (0xffffffff = miss) in the low word -- two paths have
- * DIVERGED iff these differ -- and FNV-1a-32 over the bits of every hit distance in the high word.  out: host pointer,
- * local_rows * width * n_samples entries. */
-int amber_hip_kat_signatures(amber_hip_pt*, uint32_t first_sample, uint32_t n_samples, uint64_t* out);
-/* The same signatures from the PRODUCT render kernel (pt_megakernel / pt_bvh_megakernel / pt_bvh_pool_kernel instantiated with the hashing
- * switched on: identical scheduling, work queue, ray pool and device functions), so that the kernel that renders -- not
- * only the per-thread known-answer kernel above -- is compared with the oracle path by path
- * (algorithm_pt.cc:125-160).  Same layout as amber_hip_kat_signatures.  Leaves the framebuffer and the ray count untouched. */
-int amber_hip_pt_signatures(amber_hip_pt*, uint32_t first_sample, uint32_t n_samples, uint64_t* out);
-/* Engine BVH's traversal in a kernel of its own (no shading, no path state): closest hits of n rays, `waves` resident waves per SIMD
- * (4, 5, 6 or 8), idle lanes refilled once `refill_min` of a wave's 64 lanes are idle; out_t = NaN for a miss; best_ms = the fastest of
- * `repeats` launches; out_rounds (may be NULL): per ray, the number of wave rounds it was in flight for.  A measurement (DESIGN.md
- * section 5) that doubles as a known-answer test of the traversal. */
-int amber_hip_kat_traversal_rate(amber_hip_pt*, uint32_t n, const float* origins, const float* dirs, uint32_t waves, uint32_t refill_min,
-                                 uint32_t repeats, float* out_t, int32_t* out_object, double* best_ms, uint32_t* out_rounds);
-/* Two-phase engine: the per-pixel candidate masks of the primary rays (pixel_mask_kernel; computed now if the handle has not rendered yet).
- * out_mask: one word per band pixel, bit k = the object in filter-program slot k can be hit by SOME eye ray of the pixel (aperture blades
- * excluded: they are added per ray).  out_slot_of_object: n_objects entries, the slot of every scene object (0xffffffff: none).
- * out_always_mask: the slots that are candidates of EVERY ray whatever the pixel (objects the filter program has no record for, and the
- * aperture blades, which a primary ray adds itself).  kernel_ms: duration of the mask kernel if this call ran it, else -1.
- * Any pointer may be NULL. */
-int amber_hip_kat_pixel_masks(amber_hip_pt*, uint32_t* out_mask, uint32_t* out_slot_of_object, uint32_t* out_always_mask, double* kernel_ms);
-/* the engine's sin/cos/pow on device: mode 0 = sincos(x[i]) -> out[2i], out[2i+1] ; mode 1 = pow(x[2i], x[2i+1]) -> out[i] ;
- * mode 2 / 3 = x[i]^4 / x[i]^5 in binary64 -> out[2i], out[2i+1] = low, high word of the double */
-int amber_hip_kat_math(int device, int mode, uint32_t n, const float* x, float* out);
+/* The known-answer entry points of the tests (amber_hip_kat_*), amber_hip_pt_signatures, engine WAVEFRONT and AMBER_PT_FLAG_BVH_POOL belong to
+ * the LAB build, libamber_hip_lab.so: include/amber_hip_lab.h.  libamber_hip.so exports exactly what this header declares (plus the C shim of
+ * the host object model, include/amber_host.h, and that model's C++ classes, amber_amd/csrc/amber/). */
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

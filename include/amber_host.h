@@ -16,6 +16,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the libraries are built with -fvisibility=hidden: what these headers declare is what they export */
 
 typedef struct amber_host_scene amber_host_scene;
 
@@ -66,6 +67,7 @@ int amber_host_export(const float* rgb, uint32_t width, uint32_t height, const c
 
 const char* amber_host_last_error(void);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,10 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
+# The suite runs on the LAB build: the product's sources compiled with -DAMBER_LAB, i.e. the same kernels plus the known-answer entry points,
+# the signature instantiations and the measured-and-kept schedulers (include/amber_hip_lab.h).  tests/test_product_library.py checks that the
+# product library exports only the documented ABI and renders the same bits.  (A measurement build may be selected from outside.)
+os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 

@@ -11,19 +11,25 @@ import oracle_binding as O
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def test_library_exports_every_declared_symbol(amber):
-    lib = amber.load_library()
-    declared = set()
-    for header in ("amber_hip.h", "amber_host.h"):
+def _declared(*headers):
+    out = set()
+    for header in headers:
         text = (ROOT / "include" / header).read_text()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        declared |= set(re.findall(r"\b(amber_(?:hip|host)_[a-z0-9_]+)\s*\(", text))
-    assert len(declared) >= 20
-    from amber_amd.api import ABI_SYMBOLS
-    assert declared == set(ABI_SYMBOLS)
-    for name in declared:
+        out |= set(re.findall(r"\b(amber_(?:hip|host)_[a-z0-9_]+)\s*\(", text))
+    return out
+
+
+def test_library_exports_every_declared_symbol(amber):
+    """The loaded library (the lab build under pytest) has every entry point of the three headers; the binding's lists are the headers'."""
+    lib = amber.load_library()
+    from amber_amd.api import ABI_SYMBOLS, LAB_SYMBOLS
+    product, lab = _declared("amber_hip.h", "amber_host.h"), _declared("amber_hip_lab.h")
+    assert len(product) >= 20 and product == set(ABI_SYMBOLS)
+    assert lab == set(LAB_SYMBOLS) and not (lab & product)
+    for name in product | (lab if amber.is_lab() else set()):
         assert hasattr(lib, name), name
-    assert lib.amber_hip_abi_version() == 2
+    assert lib.amber_hip_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header(amber):

@@ -8,12 +8,17 @@ materials, lens).  GPU: a band of each workload at its bench frame against the o
   (ii)  Cornell-like room + 1 304-triangle mesh,
   (iii) 1.04 M-triangle displaced terrain with needle triangles at the seams.
 """
+import os
+from pathlib import Path
+
 import numpy as np
 import pytest
 
 import oracle_binding as O
 from amber_amd import workloads as WL
 from bvh_parity import bits, check_band
+
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def _import(amber, wl, tmp_path):
@@ -84,3 +89,20 @@ def test_terrain_band_against_both_oracles(amber, oracle, tmp_path):
     pt = amber.PathTracer(hs, amber.Sensor.default(1920, 1080), seed=3, rows=(700, 704))
     assert np.array_equal(pt.render_signatures(0, 8), so)
     pt.close()
+
+
+@pytest.mark.gpu
+def test_engine_bvh_picks_its_scheduler_from_the_tree_depth(amber):
+    """Shallow trees (depth <= 12) render with the path-granular kernel, deeper ones and AMBER_PT_FLAG_BVH_ITEMS with pt_bvh_megakernel; scenes with
+    triangles shade in batches of 40, sphere scenes of 52 (AMBER_DEBUG_BVH prints the choice at create)."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import amber_amd as A; from amber_amd import scenes; sn = A.Sensor.default(32, 32); c = A.HostScene.cornell_box();"
+            "A.PathTracer(c, sn, engine=A.ENGINE_BVH).close(); A.PathTracer(c, sn, engine=A.ENGINE_BVH, flags=A.PT_FLAG_BVH_ITEMS).close();"
+            "A.PathTracer(A.HostScene.create_arrays(**scenes.random_spheres(50_000, 7)), sn).close()") % str(ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, AMBER_DEBUG_BVH="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stderr.splitlines() if "scheduler" in l]
+    assert len(lines) == 3, p.stderr
+    assert "depth 6; scheduler pt_megakernel<ENGINE_BVH>, shading batch 40" in lines[0]
+    assert "scheduler pt_bvh_megakernel, shading batch 40" in lines[1]
+    assert "scheduler pt_bvh_megakernel, shading batch 52" in lines[2]

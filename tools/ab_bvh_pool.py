@@ -4,6 +4,7 @@ against pt_bvh_pool_kernel (AMBER_BVH_POOL=1 at create), in ONE process, interle
 import os, sys, statistics
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 import amber_amd as A
 from amber_amd import scenes
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64

@@ -1,6 +1,7 @@
 """Engine BVH vs engine LIST (exhaustive exact scan) on the 1M-sphere scene: per-ray equality on random and path-like rays."""
 import sys, os, time; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R)
 import numpy as np, amber_amd as A
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 from amber_amd import scenes
 n_obj=int(sys.argv[1]) if len(sys.argv)>1 else 1_000_000
 n=int(sys.argv[2]) if len(sys.argv)>2 else 20000

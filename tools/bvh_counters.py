@@ -2,6 +2,7 @@
 node visits, leaf sphere tests, traversal rounds, shading calls -- how many lanes are busy each time a wave runs them."""
 import ctypes as C, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 import amber_amd.api as api
 CLOCKS = "--clocks" in sys.argv
 if CLOCKS: sys.argv.remove("--clocks")

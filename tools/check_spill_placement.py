@@ -15,7 +15,7 @@ copy happens to precede the exec restore, the allocator puts the spill code in f
         ...
         scratch_load_dword v64, off, off offset:56 ; 4-byte Folded Reload      <- all lanes: Phong lanes read stale values
 
-This script compiles hip/pt_engine.hip to assembly (hipcc cross-compiles without a GPU) with the product's flags plus any
+This script compiles hip/pt_host.hip to assembly (hipcc cross-compiles without a GPU) with the product's flags plus any
 given on the command line, and reports every block in which a `Folded Spill` / `Folded Reload` precedes the block's
 `s_or_b64 exec, exec, ...`.      python tools/check_spill_placement.py [extra hipcc flags]      exit status 1 = found."""
 import re
@@ -29,8 +29,8 @@ FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC"
 
 
 def compile_to_asm(extra):
-    out = Path(tempfile.mkdtemp()) / "pt_engine.s"
-    subprocess.run(["hipcc", "--offload-arch=gfx950", *FLAGS, *extra, "--cuda-device-only", "-S", "hip/pt_engine.hip", "-o", str(out)],
+    out = Path(tempfile.mkdtemp()) / "pt_host.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", *FLAGS, *extra, "--cuda-device-only", "-S", "hip/pt_host.hip", "-o", str(out)],
                    cwd=ROOT / "amber_amd" / "csrc", check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return out.read_text()
 

@@ -1,5 +1,6 @@
 import sys; sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, time
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 import amber_amd as A, oracle_binding as O
 from amber_amd import scenes
 kw = scenes.random_spheres(1_000_000, 7)

@@ -1,5 +1,6 @@
 """Times every engine on BASELINE config 2 (Cornell 1024x1024) at a given spp: kernel ms (hipEvents) and Mrays/s."""
 import sys, os, time; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R)
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 import amber_amd as A
 spp=int(sys.argv[1]) if len(sys.argv)>1 else 256
 sc=A.HostScene.cornell_box(); sn=A.Sensor.default(1024,1024)

@@ -5,6 +5,7 @@ subset against the CPU oracle.     python tools/fuzz_engines.py [n_scenes] [firs
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 import amber_amd as A
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]

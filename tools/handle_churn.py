@@ -1,6 +1,7 @@
 """Creates, uses and destroys many handles (both engines, signatures, light tracing) and checks that device memory comes back."""
 import sys, os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, torch
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 import amber_amd as A
 from amber_amd import scenes
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150

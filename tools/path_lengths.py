@@ -1,6 +1,7 @@
 """Distribution of path lengths (casts per path) of config 2: how long can the last paths of a launch keep a wave busy?"""
 import sys, os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 import amber_amd as A
 pt = A.PathTracer(A.HostScene.cornell_box(), A.Sensor.default(1024, 1024), seed=12345)
 rng = np.random.default_rng(1)

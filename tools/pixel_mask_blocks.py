@@ -3,6 +3,7 @@ candidates per pixel, and what the coarser masks cost the render (config 2 at 25
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 import amber_amd as A
 hs = A.HostScene.cornell_box(); sn = A.Sensor.default(1024, 1024)
 for block in ("1", "2", "4"):

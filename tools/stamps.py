@@ -1,6 +1,7 @@
 """Section shares of one megakernel loop iteration from the diagnostic -DAMBER_STAMPS build (not the product)."""
 import ctypes as C, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 import amber_amd.api as api
 api._LIB_PATH = api._ROOT / "lib" / "libamber_hip_stamps.so"
 if not api._LIB_PATH.exists():                      # measurement builds are not kept in the tree: build on demand (30 s)

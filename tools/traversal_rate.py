@@ -6,6 +6,7 @@ and runs them through bvh_trace_rate_kernel: the render kernels' resumable trave
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 import amber_amd as A
 from amber_amd import scenes
 n_paths = int(sys.argv[1]) if len(sys.argv) > 1 else 400_000

@@ -5,6 +5,7 @@ tail of slow rays).   python tools/traversal_rate_primary.py [pixels] [spp]"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 import amber_amd as A
 from amber_amd import scenes
 n_pix = int(sys.argv[1]) if len(sys.argv) > 1 else 20000

@@ -2,6 +2,7 @@
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 import amber_amd as A
 from amber_amd import scenes
 n_pix, spp, W, H = 8000, 32, 1920, 1080

@@ -3,6 +3,7 @@ build (make stamps).  Looks for the fixed 0.5 ms of a launch (tools/launch_fixed
 import ctypes as C, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
+import os; os.environ.setdefault("AMBER_AMD_LIB", "libamber_hip_lab.so")   # known-answer entry points / lab schedulers: the lab build (include/amber_hip_lab.h)
 import amber_amd.api as api
 api._LIB_PATH = api._ROOT / "lib" / "libamber_hip_stamps.so"
 import amber_amd as A
