@@ -1,6 +1,7 @@
 """Large random soups (tens of thousands of triangles, spheres, disks, cylinders): engine BVH (parallel build, deep tree)
-against engine LIST, bit for bit.   python tools/fuzz_big.py [n_scenes] [n_objects] [sphere share]
-(a sphere share near 1 makes most leaves all-sphere leaves: the wave-cooperative leaf phase)"""
+against engine LIST, bit for bit.   python tools/fuzz_big.py [n_scenes] [n_objects] [sphere share] [triangle share]
+(a sphere share near 1 makes most leaves all-sphere leaves: the two-stage sphere leaf; a triangle share near 1 all-triangle leaves: the
+two-stage triangle leaf -- a fifth of those triangles are NEEDLES, one edge 1e-3 .. 1e-5 of the others, and a tenth lie in a common plane)"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
@@ -8,11 +9,13 @@ import amber_amd as A
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n_obj = int(sys.argv[2]) if len(sys.argv) > 2 else 80000
 p_sphere = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0 / 6.0
+p_tri = float(sys.argv[4]) if len(sys.argv) > 4 else None
 W, H, spp = 64, 48, 4
 for seed in range(n_scenes):
     rng = np.random.default_rng(1000 + seed)
     q = (1.0 - p_sphere) / 5.0
-    kinds = rng.choice([0, 1, 2, 3], n_obj, p=[3 * q, p_sphere, q, q]).astype(np.uint32)
+    if p_tri is None: kinds = rng.choice([0, 1, 2, 3], n_obj, p=[3 * q, p_sphere, q, q]).astype(np.uint32)
+    else: kinds = rng.choice([0, 1, 2, 3], n_obj, p=[p_tri, (1 - p_tri) / 3, (1 - p_tri) / 3, (1 - p_tri) / 3]).astype(np.uint32)
     params = np.zeros((n_obj, 12), np.float32)
     c = rng.uniform(-1, 1, (n_obj, 3)) * rng.choice([1.0, 1.0, 30.0], (n_obj, 1))          # a third of the objects far out: deep, unbalanced tree
     size = (10.0 ** rng.uniform(-3, -0.5, n_obj))
@@ -20,6 +23,11 @@ for seed in range(n_scenes):
     params[:, 0:3] = c
     params[tri, 3:6] = (c + rng.normal(size=(n_obj, 3)) * size[:, None])[tri]
     params[tri, 6:9] = (c + rng.normal(size=(n_obj, 3)) * size[:, None])[tri]
+    if p_tri is not None:
+        needle = tri & (rng.random(n_obj) < 0.2)                                                  # second vertex a hair from the first
+        params[needle, 3:6] = (c + rng.normal(size=(n_obj, 3)) * (size * 10.0 ** rng.uniform(-5, -3, n_obj))[:, None])[needle]
+        flat = tri & (rng.random(n_obj) < 0.1)                                                    # coplanar clutter in the plane y = 0.25: exact ties and grazing rays
+        for k in (1, 4, 7): params[flat, k] = 0.25
     params[kinds == 1, 3] = size[kinds == 1]
     nrm = rng.normal(size=(n_obj, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
     dc = kinds >= 2
