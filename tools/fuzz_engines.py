@@ -65,8 +65,8 @@ for seed in range(first_seed, first_seed + n_scenes):
     if use_lt:
         lref = None
         lt_depth = int(rng.integers(0, 2)) * 5
-        for e in [x for x in engines if x != A.ENGINE_WAVEFRONT]:
-            pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=seed, engine=e, max_depth=lt_depth)
+        for e, fl in [x for x in engines if x[0] != A.ENGINE_WAVEFRONT]:
+            pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=seed, engine=e, flags=fl, max_depth=lt_depth)
             rec, lrays = pt.lt_trace(0, 3, capacity=1 << 14); pt.close()
             if lref is None:
                 lref = (rec.tobytes(), lrays)
