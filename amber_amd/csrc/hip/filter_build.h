@@ -38,7 +38,9 @@ struct FilterProgram {
 // affine maps see magnitudes of the order of the scene size however far the scene lies from the world origin; in
 // absolute coordinates u = A.P + a0 cancels two large terms and loses the precision the tolerances assume
 // (found by fuzzing with scenes offset by 1e4 of their size).
-inline void BuildFilterProgram(const std::vector<DevObject>& objs, const float center[3], FilterProgram& fp) {
+// `subset` (engine TWO_PHASE_N): the scene indices of the group the program is for, at most 32; null = the scene's first 32 objects.  Tolerances
+// always derive from the bounds of ALL objects.
+inline void BuildFilterProgram(const std::vector<DevObject>& objs, const float center[3], FilterProgram& fp, const std::vector<uint32_t>* subset = nullptr) {
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, e_max = 0;
   auto grow = [&](double x, double y, double z) {
     const double p[3] = {x, y, z};
@@ -65,9 +67,10 @@ inline void BuildFilterProgram(const std::vector<DevObject>& objs, const float c
   struct Group { double n[3], d0, kt, ktol; std::vector<Tri> tris; bool flip = false, same_normal = false; };
   std::vector<Group> groups;
   std::vector<uint32_t> sphere_index, always_index;
-  for (size_t i = 0; i < objs.size() && i < 32; i++) {
-    const DevObject& o = objs[i];
-    const uint32_t idx = static_cast<uint32_t>(i);
+  const size_t n_members = subset ? std::min<size_t>(subset->size(), 32) : std::min<size_t>(objs.size(), 32);
+  for (size_t member = 0; member < n_members; member++) {
+    const uint32_t idx = subset ? (*subset)[member] : static_cast<uint32_t>(member);
+    const DevObject& o = objs[idx];
     if (o.kind == AMBER_PRIM_TRIANGLE) {
       const double v0[3] = {double(o.a[0]) - center[0], double(o.a[1]) - center[1], double(o.a[2]) - center[2]};   // centred
       const double E1[3] = {o.e1[0], o.e1[1], o.e1[2]}, E2[3] = {o.e2[0], o.e2[1], o.e2[2]};

@@ -108,6 +108,14 @@ struct alignas(16) DevSphereFilter { // 32 B
   float c[3]; float r2;
   float ktol; uint32_t pad[3];
 };
+// Two-phase engine on 33 .. 128 objects (round 5): the objects are dealt into GROUPS of <= 32, each with a Phase-A program of its own over the
+// shared record arrays; the closest hit runs group after group (the (t, index) rule makes the order irrelevant).  Group g's objects occupy the
+// LDS slots [32 g, 32 g + n_objects).  Group 0 is described by DevScene's own fields as well (pixel_mask_kernel and the 32-object engine read those).
+struct alignas(16) DevFilterGroup {  // 48 B, scalar-loaded
+  uint32_t plane_first, n_planes, n_simple_planes, tri_first;      // offsets into DevScene.planes / tri_filters (records)
+  uint32_t sphere_first, n_sphere_filters, always_mask, n_prog_tris;
+  uint32_t n_objects, pad[3];
+};
 // Flattened 2-wide BVH node (engine BVH, bvh_build.h): both children's (padded) boxes live in the parent.
 // Child reference: >= 0 inner node index; < 0 leaf: -(ref+1) = first*8 + count into prim_index (count <= 7).
 // The planes are grouped so that the slab test runs on packed FMAs (v_pk_fma_f32): (x, y) pairs of every corner
@@ -182,7 +190,10 @@ struct DevScene {
   uint32_t always_mask;        // program slots that are always candidates (disks, cylinders, degenerate triangles)
   uint32_t blade_mask;         // program slots of the aperture blades (primary rays: decided per ray, not per pixel)
   uint32_t n_prog_tris;        // program slots [0, n_prog_tris) are filtered triangles, then spheres, then the rest
-  const DevObject* __restrict__ prog_objects;   // objects in program order, kind |= scene index << 8 (staged to LDS)
+  const DevObject* __restrict__ prog_objects;   // objects in program order, kind |= scene index << 8 (| 0x80: a filtered triangle) (staged to LDS)
+  const DevFilterGroup* __restrict__ groups;    // engine TWO_PHASE_N: n_groups records (null otherwise)
+  uint32_t n_groups;                            // 1 for the 32-object engine
+  uint32_t n_lds_objects;                       // records of prog_objects (n_objects, or 32 * n_groups)
   const DevBvhNodeQ* __restrict__ bvh_nodes;    // engine BVH: quantised 2-wide nodes
   const DevBvhNodeQ4* __restrict__ bvh_nodes4;  // AMBER_BVH_WIDE builds: the collapsed 4-wide nodes (else null)
   float bvh_gmin[3], bvh_step[3];               // plane = bvh_gmin + value * bvh_step (binary16 planes: scene centre, half extent)
@@ -623,10 +634,44 @@ __device__ __forceinline__ void ClosestHitList(const DevScene& sc, V3 o, V3 d, H
 #ifndef AMBER_SHARED_WEIGHT_QUOTIENT
 #define AMBER_SHARED_WEIGHT_QUOTIENT 1
 #endif
+// The Phase-A program one call works through: the whole scene's (the 32-object engine: DevScene's own fields, compile-time `first`) or one group's.
+struct FilterView {
+  ConstWords planes, tris, spheres;
+  int n_planes, n_simple_planes, n_sphere_filters;
+  uint32_t always_mask, n_prog_tris, n_objects;
+  int slot_base;                                             // LDS slot of the view's first object
+};
+__device__ __forceinline__ FilterView SceneView(const DevScene& sc) {
+  return FilterView{(ConstWords)(sc.planes), (ConstWords)(sc.tri_filters), (ConstWords)(sc.sphere_filters), static_cast<int>(sc.n_planes), static_cast<int>(sc.n_simple_planes),
+                    static_cast<int>(sc.n_sphere_filters), sc.always_mask, sc.n_prog_tris, sc.n_objects, 0};
+}
+template <bool kFirst>
+__device__ __forceinline__ void ClosestHitTwoPhaseView(const DevScene& sc, const FilterView fv, const DevObject* lds_objects, V3 o_world, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM,
+                                                       const bool use_premask, const uint32_t premask);
 __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const DevObject* lds_objects, V3 o_world, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM,
                                                    const bool use_premask = false, const uint32_t premask = 0u) {
-  best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;
-  uint32_t cand = sc.always_mask;
+  ClosestHitTwoPhaseView<true>(sc, SceneView(sc), lds_objects, o_world, d, origin_slot, best AMBER_STAMP_ARG, use_premask, premask);
+}
+// Engine TWO_PHASE_N: every group in turn; the primary rounds' pixel masks describe group 0 only (the other groups run Phase A for eye rays too).
+__device__ __forceinline__ void ClosestHitTwoPhaseGroups(const DevScene& sc, const DevObject* lds_objects, V3 o_world, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM,
+                                                         const bool use_premask = false, const uint32_t premask = 0u) {
+  ClosestHitTwoPhaseView<true>(sc, SceneView(sc), lds_objects, o_world, d, origin_slot < 32 ? origin_slot : -1, best AMBER_STAMP_ARG, use_premask, premask);
+  const int n_groups = static_cast<int>(sc.n_groups);
+  ConstWords gw = (ConstWords)(sc.groups);
+  for (int g = 1; g < n_groups; ++g) {
+    ConstWords w = gw + g * 12;                               // DevFilterGroup = 12 dwords
+    const FilterView fv{(ConstWords)(sc.planes) + w[0] * 8u, (ConstWords)(sc.tri_filters) + w[3] * 8u, (ConstWords)(sc.sphere_filters) + w[4] * 8u,
+                        static_cast<int>(w[1]), static_cast<int>(w[2]), static_cast<int>(w[5]), w[6], w[7], w[8], g * 32};
+    ClosestHitTwoPhaseView<false>(sc, fv, lds_objects, o_world, d, origin_slot, best AMBER_STAMP_ARG, false, 0u);
+  }
+}
+template <bool kFirst>
+__device__ __forceinline__ void ClosestHitTwoPhaseView(const DevScene& sc, const FilterView fv, const DevObject* lds_objects_all, V3 o_world, V3 d, int origin_slot_all, HitRec& best AMBER_STAMP_PARAM,
+                                                       const bool use_premask, const uint32_t premask) {
+  if (kFirst) { best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1; }
+  const DevObject* lds_objects = lds_objects_all + fv.slot_base;
+  const int origin_slot = kFirst ? origin_slot_all : ((origin_slot_all >= fv.slot_base && origin_slot_all < fv.slot_base + 32) ? origin_slot_all - fv.slot_base : -1);
+  uint32_t cand = fv.always_mask;
   // use_premask (WAVE-UNIFORM): the candidates are already known -- a primary round of pt_megakernel, whose 64 eye rays take them
   // from their pixel's mask (pixel_mask_kernel: every object some ray of the pixel's beam can hit, computed once per handle) --
   // so Phase A, a third of the kernel, is skipped for the ray that every path starts with.
@@ -645,9 +690,9 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
     // Every comparison is false on NaN: nothing is pruned and nothing is certain.
     float t_upper = sc.fp_tmax * __builtin_amdgcn_rsqf(d.x * d.x + d.y * d.y + d.z * d.z);
     if (!(t_upper == t_upper)) t_upper = 3.402823466e+38f;
-    ConstWords pl = (ConstWords)(sc.planes);
-    ConstWords tr = (ConstWords)(sc.tri_filters);
-    const int n_planes = static_cast<int>(sc.n_planes);
+    ConstWords pl = fv.planes;
+    ConstWords tr = fv.tris;
+    const int n_planes = fv.n_planes;
     uint32_t bit = 1u;                                       // candidate bit of the next program triangle (SALU)
     float nd = 0.f, no = 0.f, rc = 0.f;
 #define AMBER_PLANE_NORMAL() \
@@ -685,7 +730,7 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
         cand |= keep1 ? bit : 0u; \
         cand |= keep2 ? (bit << 1) : 0u; \
         AMBER_PLANE_HIT(__builtin_fmaxf(m1, m2)); }
-    const int n_simple = static_cast<int>(sc.n_simple_planes);
+    const int n_simple = fv.n_simple_planes;
     int p = 0;
     for (; p < n_simple; p += 2) {                          // slabs (filter_build.h): two parallel planes of one parallelogram pair each
       AMBER_PLANE_NORMAL();
@@ -716,8 +761,8 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
 #undef AMBER_PLANE_NORMAL
 #undef AMBER_PAIR_RECORD
 #undef AMBER_PLANE_HIT
-    ConstWords sp = (ConstWords)(sc.sphere_filters);
-    const int ns = static_cast<int>(sc.n_sphere_filters);
+    ConstWords sp = fv.spheres;
+    const int ns = fv.n_sphere_filters;
     for (int k = 0; k < ns; ++k, sp += 8, bit <<= 1) {      // DevSphereFilter = 8 dwords
       const float cx = cw_f(sp, 0) - o.x, cy = cw_f(sp, 1) - o.y, cz = cw_f(sp, 2) - o.z;
       const float bb = __builtin_fmaf(cx, d.x, __builtin_fmaf(cy, d.y, cz * d.z));       // co.d
@@ -735,7 +780,7 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
   if (!use_premask) {
     const float ex = Abs(o_world.x - sc.fp_center[0]), ey = Abs(o_world.y - sc.fp_center[1]), ez = Abs(o_world.z - sc.fp_center[2]);
     const bool in_model = __builtin_fmaxf(__builtin_fmaxf(ex, ey), ez) <= sc.fp_reach && (d.x * d.x + d.y * d.y + d.z * d.z) <= 4.0f;   // NaN -> false
-    if (!in_model) cand = sc.n_objects >= 32u ? 0xffffffffu : ((1u << sc.n_objects) - 1u);
+    if (!in_model) cand = fv.n_objects >= 32u ? 0xffffffffu : ((1u << fv.n_objects) - 1u);
   }
   AMBER_STAMP(2);
   // Self trip.  A ray that leaves a triangle always re-selects that triangle in Phase A (t' ~ 0), and the exact test
@@ -754,7 +799,7 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
     }
   }
   // Phase B: filtered triangles first, then everything else (keeps the per-lane kind branch out of the hot loop)
-  const uint32_t tri_bits = sc.n_prog_tris >= 32u ? 0xffffffffu : ((1u << sc.n_prog_tris) - 1u);
+  const uint32_t tri_bits = fv.n_prog_tris >= 32u ? 0xffffffffu : ((1u << fv.n_prog_tris) - 1u);
   uint32_t mt = cand & tri_bits;
 #ifdef AMBER_STAMPS
   while (__any(mt != 0u)) {                                  // diagnostic build: all lanes stay in the loop so that lane 0 can count
@@ -767,7 +812,7 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
       const int slot = __builtin_ctz(mt);
       mt &= mt - 1u;
       const DevObject& ob = lds_objects[slot];
-      IntersectTriangle<true>(ld3(ob.a), ld3(ob.e1), ld3(ob.e2), static_cast<int>(ob.kind >> 8), slot, o_world, d, best);
+      IntersectTriangle<true>(ld3(ob.a), ld3(ob.e1), ld3(ob.e2), static_cast<int>(ob.kind >> 8), fv.slot_base + slot, o_world, d, best);
     }
   }
   uint32_t mo = cand & ~tri_bits;
@@ -775,7 +820,7 @@ __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const Dev
     const int slot = __builtin_ctz(mo);
     mo &= mo - 1u;
     const DevObject& ob = lds_objects[slot];
-    IntersectObject<true>(ob, ob.kind & 0xffu, static_cast<int>(ob.kind >> 8), slot, o_world, d, best);
+    IntersectObject<true>(ob, ob.kind & 0x7fu, static_cast<int>(ob.kind >> 8), fv.slot_base + slot, o_world, d, best);
   }
 }
 
@@ -1223,12 +1268,13 @@ __device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_s
   BvhResolveIndex(sc, best);                                       // callers of this form report the object
 }
 
-enum { ENGINE_LIST = 1, ENGINE_TWO_PHASE = 2, ENGINE_BVH = 3 };
+enum { ENGINE_LIST = 1, ENGINE_TWO_PHASE = 2, ENGINE_BVH = 3, ENGINE_TWO_PHASE_N = 5 };   // (4 is the public WAVEFRONT; 5 = two-phase over groups of 32 objects)
 
 template <int kEngine>
 __device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3 o, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM,
                                            const bool use_premask = false, const uint32_t premask = 0u, const int bvh_stack_cap = AMBER_BVH_STACK) {
   if (kEngine == ENGINE_TWO_PHASE) ClosestHitTwoPhase(sc, lds_objects, o, d, origin_slot, best AMBER_STAMP_ARG, use_premask, premask);
+  else if (kEngine == ENGINE_TWO_PHASE_N) ClosestHitTwoPhaseGroups(sc, lds_objects, o, d, origin_slot, best AMBER_STAMP_ARG, use_premask, premask);
   else if (kEngine == ENGINE_BVH) ClosestHitBvh(sc, lds_stack, o, d, best, bvh_stack_cap);
   else ClosestHitList(sc, o, d, best);
   AMBER_STAMP(3);
@@ -1237,7 +1283,7 @@ __device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* 
 // position / normal of the winning hit, evaluated exactly as the reference's Intersect() does
 __device__ __forceinline__ void ResolveHit(const DevObject* objects, const HitRec& h, V3 o, V3 d, V3& pos, V3& normal, uint32_t& material) {
   const DevObject* ob = objects + h.slot;
-  const uint32_t kind = ob->kind & 0xffu;             // the LDS image of the two-phase engine tags kind with index << 8
+  const uint32_t kind = ob->kind & 0x7fu;             // the LDS image of the two-phase engine tags kind with index << 8 and bit 7 (a filtered triangle)
   material = ob->material;
   const V3 A = ld3(ob->a);
   if (kind == PRIM_TRIANGLE) {
@@ -1258,8 +1304,9 @@ __device__ __forceinline__ void ResolveHit(const DevObject* objects, const HitRe
 
 // Copies the object records into the workgroup's LDS image (two-phase engine only; n_objects <= 32).
 #define AMBER_MAX_LDS_OBJECTS 32
+#define AMBER_MAX_GROUP_OBJECTS 128          /* engine TWO_PHASE_N: four groups of 32 */
 __device__ __forceinline__ void StageObjects(const DevScene& sc, DevObject* lds_objects) {
-  const uint32_t n_dwords = sc.n_objects * (sizeof(DevObject) / 4u);
+  const uint32_t n_dwords = sc.n_lds_objects * (sizeof(DevObject) / 4u);
   const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.prog_objects);
   uint32_t* dst = reinterpret_cast<uint32_t*>(lds_objects);
   for (uint32_t k = threadIdx.x; k < n_dwords; k += blockDim.x) dst[k] = src[k];
@@ -1562,7 +1609,7 @@ __device__ __forceinline__ bool PathShade(const DevScene& sc, const DevObject* l
     return false;
   }
   V3 pos, normal; uint32_t mat;
-  ResolveHit(kEngine == ENGINE_TWO_PHASE ? lds_objects : (kEngine == ENGINE_BVH ? sc.bvh_objects : sc.objects), h, o, d, pos, normal, mat);
+  ResolveHit((kEngine == ENGINE_TWO_PHASE || kEngine == ENGINE_TWO_PHASE_N) ? lds_objects : (kEngine == ENGINE_BVH ? sc.bvh_objects : sc.objects), h, o, d, pos, normal, mat);
   const DevMaterial m = sc.materials[mat];
   const V3 dir_out = -d;
   if (kTrace) { trace->object = h.idx; trace->t = h.t; trace->pos = pos; trace->weight_before = weight; }
@@ -1594,7 +1641,8 @@ __device__ __forceinline__ bool PathShade(const DevScene& sc, const DevObject* l
   if (Uniform(rng) >= p_rr) return false;                                    // :151-153
   if (sc.max_depth && casts >= sc.max_depth) return false;                   // build-side extension (BASELINE config 5)
   o = pos; d = dir_in;                                                       // :155 Ray(pos, UnitVector3) -- no renormalisation
-  origin_slot = (kEngine == ENGINE_TWO_PHASE && static_cast<uint32_t>(h.slot) < sc.n_prog_tris) ? h.slot : -1;
+  if (kEngine == ENGINE_TWO_PHASE_N) origin_slot = (lds_objects[h.slot].kind & 0x80u) ? h.slot : -1;      // a filtered triangle of its group (bit 7 of the LDS record)
+  else origin_slot = (kEngine == ENGINE_TWO_PHASE && static_cast<uint32_t>(h.slot) < sc.n_prog_tris) ? h.slot : -1;
 #if AMBER_SHARED_WEIGHT_QUOTIENT
   {
     // :156  weight *= scatter.Weight() / p -- three binary32 divisions by the same p.  A component of the scatter weight that has the

@@ -79,6 +79,7 @@ struct amber_hip_pt {
   DevTriFilter* d_tri_filters = nullptr;
   DevSphereFilter* d_sphere_filters = nullptr;
   DevObject* d_prog_objects = nullptr;
+  DevFilterGroup* d_groups = nullptr;       // engine TWO_PHASE_N: one record per group of 32 objects
   DevBvhNodeQ* d_bvh_nodes = nullptr;
   DevBvhNodeQ4* d_bvh_nodes4 = nullptr;      // AMBER_BVH_WIDE builds only
   float4* d_bvh_spheres = nullptr;
@@ -159,6 +160,11 @@ struct DevBuf {
 
 int StartPixelMasks(amber_hip_pt* h, float* timing);      // defined with the launch code below
 
+constexpr uint32_t kHitTwoPhaseN = 5;                // amber_hip_pt.hit_engine: the two-phase engine over groups of 32 objects (device: ENGINE_TWO_PHASE_N); not a public engine id
+constexpr uint32_t kTwoPhaseAutoObjects = 80;        // AUTO picks the grouped two-phase engine up to this many objects: the Cornell box plus small quads, 1024^2 @ 128 spp
+                                                     // (tools/object_count_curve.py, profiles/r05_object_count_curve.txt): 33 objects 8.5 ms against 16.5 for engine BVH, 64: 13.7 / 16.9,
+                                                     // 73: 15.1 / 16.9, 89: 17.6 / 15.5 -- the curves cross near 80
+
 int ValidateScene(const AmberFlatScene* s, const AmberSensor* sensor) {
   if (!s || !sensor) return Fail(AMBER_EINVAL, "null scene or sensor");
   if (!s->objects || s->n_objects == 0) return Fail(AMBER_EINVAL, "scene has no objects");
@@ -222,8 +228,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   if (params->engine == AMBER_ENGINE_WAVEFRONT) return Fail(AMBER_EINVAL, "engine WAVEFRONT (the streaming formulation, kept for measurement) is part of the lab build, libamber_hip_lab.so");
   if (params->reserved & AMBER_PT_FLAG_BVH_POOL) return Fail(AMBER_EINVAL, "AMBER_PT_FLAG_BVH_POOL (pt_bvh_pool_kernel, kept for measurement) is part of the lab build, libamber_hip_lab.so");
 #endif
-  if (params->engine == AMBER_ENGINE_TWO_PHASE && s->n_objects > AMBER_MAX_LDS_OBJECTS)
-    return Fail(AMBER_EINVAL, "AMBER_ENGINE_TWO_PHASE supports at most 32 objects");
+  if (params->engine == AMBER_ENGINE_TWO_PHASE && s->n_objects > AMBER_MAX_GROUP_OBJECTS)
+    return Fail(AMBER_EINVAL, "AMBER_ENGINE_TWO_PHASE supports at most 128 objects");
 
   HIP_TRY(hipSetDevice(params->device));
   auto* h = new amber_hip_pt();
@@ -282,10 +288,15 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     blades[i].slot = -1; blades[i].pad[0] = blades[i].pad[1] = blades[i].pad[2] = 0;
   }
 
-  const uint32_t auto_hit = s->n_objects <= AMBER_MAX_LDS_OBJECTS ? AMBER_ENGINE_TWO_PHASE : AMBER_ENGINE_BVH;
-  h->engine = params->engine != AMBER_ENGINE_AUTO ? params->engine : auto_hit;
-  h->hit_engine = h->engine == AMBER_ENGINE_WAVEFRONT ? auto_hit : h->engine;
-  h->two_phase = h->hit_engine == AMBER_ENGINE_TWO_PHASE;
+  // AUTO: <= 32 objects the two-phase engine; up to kTwoPhaseAutoObjects its grouped form (one Phase-A program per 32 objects: cheaper than a per-lane
+  // tree traversal while the groups are few -- tools/object_count_curve.py); beyond that engine BVH.  Asked for explicitly, two-phase takes up to 128 objects.
+  uint32_t two_phase_auto = kTwoPhaseAutoObjects;
+  { const char* ev = std::getenv("AMBER_TWO_PHASE_MAX_OBJECTS"); if (ev && std::atoi(ev) >= 0) two_phase_auto = std::min<uint32_t>(AMBER_MAX_GROUP_OBJECTS, static_cast<uint32_t>(std::atoi(ev))); }   // measurement hook
+  const uint32_t auto_hit = s->n_objects <= AMBER_MAX_LDS_OBJECTS ? AMBER_ENGINE_TWO_PHASE : (s->n_objects <= two_phase_auto ? kHitTwoPhaseN : AMBER_ENGINE_BVH);
+  h->engine = params->engine != AMBER_ENGINE_AUTO ? params->engine : (auto_hit == kHitTwoPhaseN ? static_cast<uint32_t>(AMBER_ENGINE_TWO_PHASE) : auto_hit);
+  h->hit_engine = h->engine == AMBER_ENGINE_WAVEFRONT ? (s->n_objects <= AMBER_MAX_LDS_OBJECTS ? AMBER_ENGINE_TWO_PHASE : AMBER_ENGINE_BVH) : h->engine;
+  if (h->hit_engine == AMBER_ENGINE_TWO_PHASE && s->n_objects > AMBER_MAX_LDS_OBJECTS) h->hit_engine = kHitTwoPhaseN;
+  h->two_phase = h->hit_engine == AMBER_ENGINE_TWO_PHASE || h->hit_engine == kHitTwoPhaseN;
   // engine BVH has two schedulers with identical results: the default is the faster one on the 1M-sphere
   // scene (pt_bvh_megakernel, 74 ms at 64 spp against 79); the environment overrides the flag either way (A/B tools)
 #ifdef AMBER_LAB
@@ -331,13 +342,24 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     for (int c = 0; c < 3; c++) { fp_center[c] = static_cast<float>(0.5 * (lo[c] + hi[c])); reach = std::max(reach, 0.5 * (hi[c] - lo[c])); }
     fp_reach = static_cast<float>(std::min(3.0e38, 2.0 * reach + 1e-3));
   }
-  if (h->two_phase) amber_filter::BuildFilterProgram(objs, fp_center, fprog);
+  std::vector<amber_filter::FilterProgram> more_progs;          // engine TWO_PHASE_N: the programs of groups 1, 2, ... (fprog is group 0's)
+  if (h->hit_engine == kHitTwoPhaseN) {
+    // groups of 32 in scene order, the aperture blades first (the primary rounds' masks and the blades' own slots live in group 0)
+    std::vector<uint32_t> order;
+    for (uint32_t i = 0; i < L.n_blades; i++) order.push_back(L.first_blade_object + i);
+    for (uint32_t i = 0; i < s->n_objects; i++) if (i < L.first_blade_object || i >= L.first_blade_object + L.n_blades) order.push_back(i);
+    for (size_t first = 0; first < order.size(); first += 32) {
+      const std::vector<uint32_t> members(order.begin() + first, order.begin() + std::min(order.size(), first + 32));
+      if (first == 0) amber_filter::BuildFilterProgram(objs, fp_center, fprog, &members);
+      else { more_progs.emplace_back(); amber_filter::BuildFilterProgram(objs, fp_center, more_progs.back(), &members); }
+    }
+  } else if (h->two_phase) amber_filter::BuildFilterProgram(objs, fp_center, fprog);
   if (h->two_phase && std::getenv("AMBER_DEBUG_FILTER")) {     // diagnostic: shape of the Phase-A program
     uint32_t pairs = 0, singles = 0;
     uint32_t shared = 0;
     for (const DevPlane& pl : fprog.planes) { pairs += pl.n_pairs; singles += pl.n_tris & 0x7fffffffu; shared += pl.n_tris >> 31; }
-    std::fprintf(stderr, "amber_hip: filter program: %zu planes (%u share the previous plane's normal), %u pair records, %u single records, %zu spheres, always mask %#x\n",
-                 fprog.planes.size(), shared, pairs, singles, fprog.spheres.size(), fprog.always_mask);
+    std::fprintf(stderr, "amber_hip: filter program%s: %zu planes (%u share the previous plane's normal), %u pair records, %u single records, %zu spheres, always mask %#x; %zu group(s) of <= 32 objects\n",
+                 more_progs.empty() ? "" : " of group 0", fprog.planes.size(), shared, pairs, singles, fprog.spheres.size(), fprog.always_mask, more_progs.size() + 1);
   }
   h->prog_order = fprog.order;
   h->host_planes = fprog.planes;
@@ -355,6 +377,38 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     for (int c = 0; c < 12; c++) dl.p[c] = fo.p[c];
     for (uint32_t k = 0; k < fprog.n_prog_tris; k++)
       if (fprog.order[k] == fl.object) dl.slot = static_cast<int32_t>(k);
+    for (size_t g = 0; g < more_progs.size(); g++)              // LDS slots of group g + 1 start at 32 (g + 1)
+      for (uint32_t k = 0; k < more_progs[g].n_prog_tris; k++)
+        if (more_progs[g].order[k] == fl.object) dl.slot = static_cast<int32_t>(32u * (g + 1) + k);
+  }
+  // every group's records behind each other; the LDS image: 32 slots per group, kind |= scene index << 8 | 0x80 for a filtered triangle
+  std::vector<DevPlane> all_planes = fprog.planes;
+  std::vector<DevTriFilter> all_tris = fprog.tris;
+  std::vector<DevSphereFilter> all_spheres = fprog.spheres;
+  std::vector<DevFilterGroup> groups;
+  std::vector<DevObject> prog(more_progs.empty() ? fprog.order.size() : 32u * (more_progs.size() + 1));
+  if (!prog.empty()) std::memset(prog.data(), 0, prog.size() * sizeof(DevObject));
+  auto place = [&](const amber_filter::FilterProgram& fp, size_t base) {
+    for (size_t k = 0; k < fp.order.size(); k++) { prog[base + k] = objs[fp.order[k]]; prog[base + k].kind |= fp.order[k] << 8 | (k < fp.n_prog_tris ? 0x80u : 0u); }
+  };
+  place(fprog, 0);
+  if (!more_progs.empty()) {
+    auto record = [&](const amber_filter::FilterProgram& fp, size_t plane_first, size_t tri_first, size_t sphere_first) {
+      DevFilterGroup g{};
+      g.plane_first = static_cast<uint32_t>(plane_first); g.n_planes = static_cast<uint32_t>(fp.planes.size()); g.n_simple_planes = fp.n_simple_planes;
+      g.tri_first = static_cast<uint32_t>(tri_first); g.sphere_first = static_cast<uint32_t>(sphere_first); g.n_sphere_filters = static_cast<uint32_t>(fp.spheres.size());
+      g.always_mask = fp.always_mask; g.n_prog_tris = fp.n_prog_tris; g.n_objects = static_cast<uint32_t>(fp.order.size());
+      groups.push_back(g);
+    };
+    record(fprog, 0, 0, 0);
+    for (size_t g = 0; g < more_progs.size(); g++) {
+      const amber_filter::FilterProgram& fp = more_progs[g];
+      record(fp, all_planes.size(), all_tris.size(), all_spheres.size());
+      all_planes.insert(all_planes.end(), fp.planes.begin(), fp.planes.end());
+      all_tris.insert(all_tris.end(), fp.tris.begin(), fp.tris.end());
+      all_spheres.insert(all_spheres.end(), fp.spheres.begin(), fp.spheres.end());
+      place(fp, 32u * (g + 1));
+    }
   }
 
   auto cleanup = [&](int code, const std::string& msg) { amber_hip_pt_destroy(h); return Fail(code, msg); };
@@ -364,16 +418,16 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMalloc(&h->d_objects, objs.size() * sizeof(DevObject)));
   HIP_TRY_H(hipMalloc(&h->d_materials, mats.size() * sizeof(DevMaterial)));
   HIP_TRY_H(hipMalloc(&h->d_blades, blades.size() * sizeof(DevBlade)));
-  HIP_TRY_H(hipMalloc(&h->d_planes, (fprog.planes.size() + 1) * sizeof(DevPlane)));
-  HIP_TRY_H(hipMalloc(&h->d_tri_filters, (fprog.tris.size() + 1) * sizeof(DevTriFilter)));
-  HIP_TRY_H(hipMalloc(&h->d_sphere_filters, (fprog.spheres.size() + 1) * sizeof(DevSphereFilter)));
-  if (!fprog.planes.empty()) HIP_TRY_H(hipMemcpy(h->d_planes, fprog.planes.data(), fprog.planes.size() * sizeof(DevPlane), hipMemcpyHostToDevice));
-  if (!fprog.tris.empty()) HIP_TRY_H(hipMemcpy(h->d_tri_filters, fprog.tris.data(), fprog.tris.size() * sizeof(DevTriFilter), hipMemcpyHostToDevice));
-  {
-    std::vector<DevObject> prog(fprog.order.size());
-    for (size_t k = 0; k < prog.size(); k++) { prog[k] = objs[fprog.order[k]]; prog[k].kind |= fprog.order[k] << 8; }
-    HIP_TRY_H(hipMalloc(&h->d_prog_objects, (prog.size() + 1) * sizeof(DevObject)));
-    if (!prog.empty()) HIP_TRY_H(hipMemcpy(h->d_prog_objects, prog.data(), prog.size() * sizeof(DevObject), hipMemcpyHostToDevice));
+  HIP_TRY_H(hipMalloc(&h->d_planes, (all_planes.size() + 1) * sizeof(DevPlane)));
+  HIP_TRY_H(hipMalloc(&h->d_tri_filters, (all_tris.size() + 1) * sizeof(DevTriFilter)));
+  HIP_TRY_H(hipMalloc(&h->d_sphere_filters, (all_spheres.size() + 1) * sizeof(DevSphereFilter)));
+  if (!all_planes.empty()) HIP_TRY_H(hipMemcpy(h->d_planes, all_planes.data(), all_planes.size() * sizeof(DevPlane), hipMemcpyHostToDevice));
+  if (!all_tris.empty()) HIP_TRY_H(hipMemcpy(h->d_tri_filters, all_tris.data(), all_tris.size() * sizeof(DevTriFilter), hipMemcpyHostToDevice));
+  HIP_TRY_H(hipMalloc(&h->d_prog_objects, (prog.size() + 1) * sizeof(DevObject)));
+  if (!prog.empty()) HIP_TRY_H(hipMemcpy(h->d_prog_objects, prog.data(), prog.size() * sizeof(DevObject), hipMemcpyHostToDevice));
+  if (!groups.empty()) {
+    HIP_TRY_H(hipMalloc(&h->d_groups, groups.size() * sizeof(DevFilterGroup)));
+    HIP_TRY_H(hipMemcpy(h->d_groups, groups.data(), groups.size() * sizeof(DevFilterGroup), hipMemcpyHostToDevice));
   }
   HIP_TRY_H(hipMalloc(&h->d_lights, (lights.size() + 1) * sizeof(DevLight)));
   if (!lights.empty()) HIP_TRY_H(hipMemcpy(h->d_lights, lights.data(), lights.size() * sizeof(DevLight), hipMemcpyHostToDevice));
@@ -418,7 +472,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     if (!leaf_order.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_objects, leaf_order.data(), leaf_order.size() * sizeof(DevObject), hipMemcpyHostToDevice));
     if (!leaf_spheres.empty()) HIP_TRY_H(hipMemcpy(h->d_bvh_spheres, leaf_spheres.data(), leaf_spheres.size() * sizeof(float4), hipMemcpyHostToDevice));
   }
-  if (!fprog.spheres.empty()) HIP_TRY_H(hipMemcpy(h->d_sphere_filters, fprog.spheres.data(), fprog.spheres.size() * sizeof(DevSphereFilter), hipMemcpyHostToDevice));
+  if (!all_spheres.empty()) HIP_TRY_H(hipMemcpy(h->d_sphere_filters, all_spheres.data(), all_spheres.size() * sizeof(DevSphereFilter), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_objects, objs.data(), objs.size() * sizeof(DevObject), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMemcpy(h->d_blades, blades.data(), blades.size() * sizeof(DevBlade), hipMemcpyHostToDevice));
@@ -457,6 +511,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   sc.fp_tmax = static_cast<float>(std::min(3.0e38, 1.7320508 * 1.5 * 1.01 * static_cast<double>(fp_reach)));
   sc.lights = h->d_lights; sc.n_lights = s->n_lights; sc.total_power = s->n_lights ? s->lights[s->n_lights - 1].cum_power : 0.0f;
   sc.n_prog_tris = fprog.n_prog_tris; sc.always_mask = fprog.always_mask; sc.prog_objects = h->d_prog_objects;
+  sc.groups = h->d_groups; sc.n_groups = static_cast<uint32_t>(groups.empty() ? 1 : groups.size()); sc.n_lds_objects = static_cast<uint32_t>(prog.size());
   sc.blade_mask = 0u;
   for (const DevBlade& bl : blades) if (bl.slot >= 0 && bl.slot < 32) sc.blade_mask |= 1u << bl.slot;
   {
@@ -745,6 +800,7 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
     if (bvh) hipLaunchKernelGGL((pt_bvh_pool_kernel<true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (h->bvh_paths) hipLaunchKernelGGL((pt_megakernel<ENGINE_BVH, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else if (h->hit_engine == kHitTwoPhaseN) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE_N, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL((pt_megakernel<ENGINE_LIST, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
   } else if (bvh) {
     hipLaunchKernelGGL((pt_bvh_pool_kernel<false>), dim3(n_blocks), dim3(256), 0, h->stream, a);
@@ -753,6 +809,7 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
   {
     if (h->bvh_paths) hipLaunchKernelGGL((pt_megakernel<ENGINE_BVH>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else if (h->hit_engine == kHitTwoPhaseN) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE_N>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL((pt_megakernel<ENGINE_LIST>), dim3(n_blocks), dim3(256), 0, h->stream, a);
   }
   HIP_TRY(hipGetLastError());
@@ -967,6 +1024,7 @@ int amber_hip_lt_trace_range(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
     const uint32_t by_work = (a.n_items + 255u) / 256u;
     if (by_work < n_blocks) n_blocks = by_work;
       if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+      else if (h->hit_engine == kHitTwoPhaseN) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE_N, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (bvh) {
       if (h->bvh_depth <= 24) hipLaunchKernelGGL((pt_bvh_megakernel<true, 24>), dim3(n_blocks), dim3(256), 0, h->stream, a);
       else hipLaunchKernelGGL((pt_bvh_megakernel<true, AMBER_BVH_STACK>), dim3(n_blocks), dim3(256), 0, h->stream, a);
@@ -1102,6 +1160,7 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_tri_filters) (void)hipFree(h->d_tri_filters);
   if (h->d_sphere_filters) (void)hipFree(h->d_sphere_filters);
   if (h->d_prog_objects) (void)hipFree(h->d_prog_objects);
+  if (h->d_groups) (void)hipFree(h->d_groups);
   if (h->d_bvh_nodes) (void)hipFree(h->d_bvh_nodes);
   if (h->d_bvh_nodes4) (void)hipFree(h->d_bvh_nodes4);
   if (h->d_bvh_spheres) (void)hipFree(h->d_bvh_spheres);

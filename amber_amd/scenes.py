@@ -70,3 +70,29 @@ def mesh_room(subdivisions: int = 8, seed: int = 3):
                  (api.MAT_LAMBERTIAN, (0.25, 0.75, 0.25), 0.0), (api.MAT_PHONG, (0.8, 0.8, 0.8), 40.0)]
     return dict(kinds=np.full(len(params), api.PRIM_TRIANGLE, np.uint32), material_index=material, params=params, materials=materials,
                 transform=[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 4, 0, 0, 0, 1], focal_length=0.05, focus_distance=4.0, radius=0.01, n_blades=6)
+
+
+def cornell_plus(k: int, seed: int = 5):
+    """The Cornell box (etude::CornelBox(0.050, 0.050, 6), read back from the host model) plus k extra objects -- small diffuse quads of two triangles
+    scattered through the room, and one small sphere when k is odd: scenes on both sides of the engine switches (32 / 80 objects).
+    Returns the keyword arguments of HostScene.create_arrays / oracle_binding.Scene.create_arrays (the aperture blades are inserted by create)."""
+    objs, mats, lens = api.HostScene.cornell_box().flatten()
+    arr = np.frombuffer(objs, dtype=np.dtype([("kind", np.uint32), ("material", np.uint32), ("p", np.float32, (12,))])).copy()
+    n_blades = int(lens.n_blades)
+    body = arr[n_blades:]
+    materials = [(int(m.kind), tuple(float(x) for x in m.rho[:]), float(m.param)) for m in mats]
+    diffuse = next(i for i, m in enumerate(materials) if m[0] == api.MAT_LAMBERTIAN)
+    rng = np.random.default_rng(seed)
+    extra = np.zeros(k, arr.dtype)
+    for i in range(0, k - 1, 2):
+        c = rng.uniform([-0.85, -0.95, -0.85], [0.85, 0.2, 0.85]); a = rng.normal(size=3) * 0.06; b = rng.normal(size=3) * 0.06
+        q = [c, c + a, c + a + b, c + b]
+        extra[i]["p"][:9] = np.concatenate([q[0], q[1], q[2]]); extra[i + 1]["p"][:9] = np.concatenate([q[2], q[3], q[0]])
+        extra[i]["material"] = extra[i + 1]["material"] = diffuse
+    if k % 2:
+        extra[k - 1]["kind"] = api.PRIM_SPHERE; extra[k - 1]["p"][:4] = [*rng.uniform(-0.8, 0.8, 3), 0.05]; extra[k - 1]["material"] = diffuse
+    allo = np.concatenate([body, extra])
+    g = np.array(lens.global_[:], np.float32).reshape(3, 3); o = np.array(lens.origin[:], np.float32)
+    transform = [g[0, 0], g[0, 1], g[0, 2], o[0], g[1, 0], g[1, 1], g[1, 2], o[1], g[2, 0], g[2, 1], g[2, 2], o[2], 0, 0, 0, 1]
+    return dict(kinds=allo["kind"].copy(), material_index=allo["material"].copy(), params=allo["p"].copy(), materials=materials, transform=[float(x) for x in transform],
+                focal_length=0.050, focus_distance=float(lens.focus_distance), radius=0.050, n_blades=n_blades)

@@ -210,6 +210,15 @@ def secondary_workloads(amber_amd, np, seed: int, device: int):
     e["kernel_ms_over_two_phase"] = round(e["kernel_ms"] / two["kernel_ms"], 3) if two["kernel_ms"] > 0 else None
     out.append(e)
     cornell.close()
+    from amber_amd import scenes as _scenes
+    for extra in (8, 24):                                                    # 33 and 49 objects: just past the 32-object two-phase engine
+        kw = _scenes.cornell_plus(extra)
+        hs = amber_amd.HostScene.create_arrays(**kw)
+        e = run(f"mesh (i''): the Cornell box + {extra} small triangles = {len(kw['kinds']) + kw['n_blades']} objects, engine auto, config 2's frame (1024x1024 @ 1024 spp)",
+                hs, 1024, 1024, 1024, "path-granular megakernel, two-phase closest hit over two groups of <= 32 objects")
+        e["kernel_ms_over_two_phase"] = round(e["kernel_ms"] / two["kernel_ms"], 3) if two["kernel_ms"] > 0 else None
+        out.append(e)
+        hs.close()
     with tempfile.TemporaryDirectory() as tmp:
         for wl, W, H, spp, what in ((workloads.room_mesh(3), 1024, 1024, 256, "mesh (ii): Cornell-like room + bumpy icosphere, imported OBJ"),
                                     (workloads.terrain_mesh(16, 56), 1920, 1080, 64, "mesh (iii): displaced terrain with needle triangles at the tile seams, imported OBJ")):

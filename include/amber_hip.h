@@ -148,9 +148,10 @@ enum {
 /* All engines are the same persistent work-queue kernel; they differ in how a lane finds its closest hit.
  * Every engine returns the List-semantics answer (closest finite hit, ties to the lower object index). */
 enum {
-  AMBER_ENGINE_AUTO = 0,       /* TWO_PHASE when the scene has <= 32 objects, BVH otherwise */
+  AMBER_ENGINE_AUTO = 0,       /* TWO_PHASE when the scene has <= 80 objects, BVH otherwise */
   AMBER_ENGINE_LIST = 1,       /* exact test of every object, wave-uniform scan (object data in SGPRs) */
-  AMBER_ENGINE_TWO_PHASE = 2,  /* conservative wave-uniform candidate filter, then exact tests of the candidates only */
+  AMBER_ENGINE_TWO_PHASE = 2,  /* conservative wave-uniform candidate filter, then exact tests of the candidates only; <= 128 objects
+                                  (beyond 32 the objects are dealt into groups of 32, one filter program each) */
   AMBER_ENGINE_BVH = 3,        /* host-built flattened 2-wide BVH, per-lane traversal with an LDS stack, exact leaf tests */
   AMBER_ENGINE_WAVEFRONT = 4   /* LAB BUILD ONLY (the product answers AMBER_EINVAL): streaming formulation -- SoA ray queues in HBM, one launch
                                   per bounce, ballot/prefix-sum compaction; closest hit as AUTO.  Same results; kept to measure that design. */

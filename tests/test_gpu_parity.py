@@ -726,7 +726,7 @@ def test_fuzz_regressions(amber):
         sc, _ = scene_for_seed(seed, scaled=bool(scaled), extreme=bool(extreme))
         hs = amber.HostScene.create(**sc)
         n_obj = len(sc["objects"]) + max(1, sc["n_blades"])
-        engines = [amber.ENGINE_LIST, amber.ENGINE_BVH, amber.ENGINE_WAVEFRONT] + ([amber.ENGINE_TWO_PHASE] if n_obj <= 32 else [])
+        engines = [amber.ENGINE_LIST, amber.ENGINE_BVH, amber.ENGINE_WAVEFRONT] + ([amber.ENGINE_TWO_PHASE] if n_obj <= 128 else [])
         ref = None
         for e in engines:
             pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=seed, engine=e)

@@ -106,3 +106,43 @@ def test_engine_bvh_picks_its_scheduler_from_the_tree_depth(amber):
     assert "depth 6; scheduler pt_megakernel<ENGINE_BVH>, shading batch 40" in lines[0]
     assert "scheduler pt_bvh_megakernel, shading batch 40" in lines[1]
     assert "scheduler pt_bvh_megakernel, shading batch 52" in lines[2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [8, 20, 55, 103])
+def test_two_phase_over_groups_of_32_objects(amber, oracle, extra):
+    """Between 33 and 128 objects the two-phase engine runs one Phase-A program per group of 32 (AUTO up to 80 objects): the Cornell box plus `extra`
+    small quads -- 33, 45, 80 and 128 objects -- a band against both oracles like every other workload, the product kernel's paths one by one, and every
+    other engine bit for bit.  (8 extra: exactly 33 objects, the second group holds ONE object.)"""
+    from amber_amd import scenes
+    kw = scenes.cornell_plus(extra)
+    n = len(kw["kinds"]) + kw["n_blades"]
+    hs, osc = amber.HostScene.create_arrays(**kw), O.Scene.create_arrays(**kw, accel=O.ACCEL_BVH_CONS)
+    W = H = 512
+    check_band(amber, hs, osc, W, H, 12345, 32, (300, 332), max_ref_pixels=16, max_ref_ray_delta=128, engine=amber.ENGINE_TWO_PHASE, label=f"two-phase, {n} objects")
+    rows = (336, 340)
+    so = osc.set_accel(O.ACCEL_BVH_CONS).path_signatures(W, H, 12345, 0, 16, rows, threads=16)
+    ref = None
+    for engine, flags in ((amber.ENGINE_TWO_PHASE, 0), (amber.ENGINE_AUTO, 0), (amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, amber.PT_FLAG_BVH_ITEMS)):
+        pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=12345, rows=rows, engine=engine, flags=flags)
+        assert np.array_equal(pt.render_signatures(0, 16), so), (engine, flags)
+        pt.render_pass(0, 16)
+        img, rays = pt.download()
+        pt.close()
+        if ref is None:
+            ref = (bits(img).copy(), rays)
+        assert rays == ref[1] and np.array_equal(bits(img), ref[0]), (engine, flags)
+    # light tracing through the grouped engine (origin slots of light triangles beyond group 0)
+    a = amber.PathTracer(hs, amber.Sensor.default(64, 48), seed=3, engine=amber.ENGINE_TWO_PHASE).lt_trace(0, 2)
+    b = amber.PathTracer(hs, amber.Sensor.default(64, 48), seed=3, engine=amber.ENGINE_LIST).lt_trace(0, 2)
+    assert a[1] == b[1] and a[0].tobytes() == b[0].tobytes()
+
+
+@pytest.mark.gpu
+def test_two_phase_refuses_more_than_128_objects(amber):
+    from amber_amd import scenes
+    from amber_amd.api import AmberError
+    hs = amber.HostScene.create_arrays(**scenes.cornell_plus(104))
+    with pytest.raises(AmberError, match="at most 128 objects"):
+        amber.PathTracer(hs, amber.Sensor.default(32, 32), engine=amber.ENGINE_TWO_PHASE)
+    amber.PathTracer(hs, amber.Sensor.default(32, 32)).close()               # AUTO: engine BVH

@@ -319,7 +319,7 @@ def test_fresh_fuzz_scenes(amber):
         sc, rng = scene_for_seed(seed, scaled=scaled, extreme=extreme)
         n_obj = len(sc["objects"]) + max(1, sc["n_blades"])
         hs = amber.HostScene.create(**sc)
-        engines = [(amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_ITEMS), (amber.ENGINE_BVH, POOL), (amber.ENGINE_WAVEFRONT, 0)] + ([(amber.ENGINE_TWO_PHASE, 0)] if n_obj <= 32 else [])
+        engines = [(amber.ENGINE_LIST, 0), (amber.ENGINE_BVH, 0), (amber.ENGINE_BVH, amber.api.PT_FLAG_BVH_ITEMS), (amber.ENGINE_BVH, POOL), (amber.ENGINE_WAVEFRONT, 0)] + ([(amber.ENGINE_TWO_PHASE, 0)] if n_obj <= 128 else [])
         ref = None
         for e, fl in engines:
             pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=seed, engine=e, flags=fl)

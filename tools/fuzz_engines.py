@@ -35,7 +35,7 @@ for seed in range(first_seed, first_seed + n_scenes):
     n_obj = len(sc["objects"]) + max(1, sc["n_blades"])
     hs = A.HostScene.create(**sc)
     # engine BVH twice: its default scheduler (pt_megakernel<ENGINE_BVH> on these shallow trees) and pt_bvh_megakernel (PT_FLAG_BVH_ITEMS)
-    engines = [(A.ENGINE_LIST, 0), (A.ENGINE_BVH, 0), (A.ENGINE_BVH, A.api.PT_FLAG_BVH_ITEMS), (A.ENGINE_WAVEFRONT, 0)] + ([(A.ENGINE_TWO_PHASE, 0)] if n_obj <= 32 else [])
+    engines = [(A.ENGINE_LIST, 0), (A.ENGINE_BVH, 0), (A.ENGINE_BVH, A.api.PT_FLAG_BVH_ITEMS), (A.ENGINE_WAVEFRONT, 0)] + ([(A.ENGINE_TWO_PHASE, 0)] if n_obj <= 128 else [])
     ref = None
     for e, fl in engines:
         pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=seed, engine=e, flags=fl)
