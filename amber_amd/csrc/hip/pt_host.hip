@@ -3,7 +3,7 @@
 //   pt_args.h              RenderArgs; record emission (accumulation without owners)
 //   pt_megakernel.inc      pt_megakernel: persistent waves, work unit = ONE PATH (q = band pixel * n_samples + sample), a wave claims 1024 paths with
 //                          one atomicAdd; lanes are decoupled from pixels through the wave's LDS pool; 64 fresh paths of one pixel start together
-//                          (primary round, candidates from the per-pixel masks).  Engines LIST / TWO_PHASE, engine BVH on trees of depth <= 12
+//                          (primary round, candidates from the per-pixel masks).  Engines LIST / TWO_PHASE (<= 32 objects; groups of 32 up to 128), engine BVH on trees of depth <= 12
 //                          (one-shot per-lane traversal, stack in LDS), light tracing.
 //   pt_bvh_megakernel.inc  pt_bvh_megakernel: engine BVH on deep trees -- lanes own (pixel, chunk of 8 samples) items, the closest hit is a RESUMABLE
 //                          per-lane traversal of the 2-wide binary16-plane tree advanced in wave rounds until a batch of lanes has finished; per-item
