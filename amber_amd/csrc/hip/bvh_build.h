@@ -361,7 +361,7 @@ inline uint32_t EmptyPlaneWord() {                            // min above max: 
 #ifndef AMBER_BVH_TRI_LEAVES
 #define AMBER_BVH_TRI_LEAVES 1
 #endif
-// Device leaf reference: -(ref + 1) = first * 16 + all_triangles * 8 + all_spheres * 4 + count (count <= 3; first < 2^27).
+// Device leaf reference: -(ref + 1) = first * 16 + all_triangles * 8 + all_spheres * 4 + count (count <= 3; first < 2^26: ValidateScene).
 // `kind_of_slot(slot)` = primitive kind of the object in leaf-order slot `slot` (0 triangle, 1 sphere, ...).
 template <typename KindOfSlot>
 inline int32_t QuantizedLeafRef(int32_t ref, KindOfSlot kind_of_slot) {

@@ -168,7 +168,7 @@ constexpr uint32_t kTwoPhaseAutoObjects = 80;        // AUTO picks the grouped t
 int ValidateScene(const AmberFlatScene* s, const AmberSensor* sensor) {
   if (!s || !sensor) return Fail(AMBER_EINVAL, "null scene or sensor");
   if (!s->objects || s->n_objects == 0) return Fail(AMBER_EINVAL, "scene has no objects");
-  if (s->n_objects >= (1u << 27)) return Fail(AMBER_EINVAL, "too many objects (BVH leaf references hold 27-bit offsets)");
+  if (s->n_objects >= (1u << 26)) return Fail(AMBER_EINVAL, "too many objects (engine BVH addresses its 48-byte leaf records with 32-bit byte offsets: fewer than 2^26 objects)");
   if (!s->materials || s->n_materials == 0) return Fail(AMBER_EINVAL, "scene has no materials");
   if (sensor->width == 0 || sensor->height == 0) return Fail(AMBER_EINVAL, "empty sensor");
   if (static_cast<uint64_t>(sensor->width) * sensor->height >= (1ull << 32)) return Fail(AMBER_EINVAL, "sensor too large");
