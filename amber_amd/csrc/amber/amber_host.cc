@@ -426,7 +426,7 @@ const Image<RGB> HipPathTracing::Render(const Scene<RGB>& scene, const Sensor& s
   // Context contract (context.cc:48-60): each successful Iterate() is one whole-image sample.
   // Claim a batch of passes, render them on every handle (launches are asynchronous: the devices run concurrently), wait
   // for all, repeat until Iterate() fails.  samples_per_launch = 0 (default): the batch adapts to TIME -- it starts at one
-  // accumulation chunk and doubles while a batch takes less than kBatchTargetMs, so that expiry (--time, SIGINT) and the
+  // accumulation chunk and grows (at least doubling, at most to what the measured rate says fills the target) while a batch takes less than kBatchTargetMs, so that expiry (--time, SIGINT) and the
   // progress line stay responsive whatever the scene costs, and a long render does not synchronise with the host every 64
   // samples (round 2: `--spp 1024` was 16 launches + 16 host synchronisations per device).  Batches are multiples of the
   // chunk, so the summation order -- and every bit of the image -- is that of one launch.
@@ -446,7 +446,16 @@ const Image<RGB> HipPathTracing::Render(const Scene<RGB>& scene, const Sensor& s
     first += n;
     stats_.passes += n;
     if (n < batch) break;
-    if (adaptive && ms < kBatchTargetMs && batch < kBatchMax) batch *= 2;
+    if (adaptive && ms < kBatchTargetMs && batch < kBatchMax) {
+      // at least double; and straight to the batch the measured rate says fills the target (a launch has a fixed cost -- 0.6 ms on the Cornell box,
+      // several ms of long traversals on a large mesh -- so four doublings where one step would do cost the CLI more than half of a short render:
+      // the 1M-triangle terrain at 960 x 540 @ 64 spp took 38.6 ms of kernel time in launches of 8 + 16 + 32 + 8 samples).  The first batch's time
+      // includes the handle's one-time costs, which only makes the estimate cautious.
+      const double per_sample = ms / static_cast<double>(n);
+      uint64_t want = per_sample > 0 ? static_cast<uint64_t>(kBatchTargetMs / per_sample) : kBatchMax;
+      want = want / AMBER_ACCUM_CHUNK * AMBER_ACCUM_CHUNK;
+      batch = static_cast<uint32_t>(std::min<uint64_t>(kBatchMax, std::max<uint64_t>(2ull * batch, want)));
+    }
   }
 
   auto image = sensor.CreateImage<RGB>();

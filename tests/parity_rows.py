@@ -93,10 +93,8 @@ def compare_image_rows(image: np.ndarray, width: int, spp: int, seed: int, bands
                against=f"oracle(XorShift, {'BVH' if accel == O.ACCEL_BVH else 'List'}, live libm) on rows of the gathered image")
     for y0, y1 in bands:
         full = np.zeros((width, width, 3), np.float32)
-        for first, n in (launches or [(0, spp)]):
-            part = np.zeros((width, width, 3), np.float32)
-            _, cnt = osc.render_xorshift(width, width, seed, first, n, math=math, threads=threads, rows=(y0, y1), out=part)
-            full[y0:y1] = full[y0:y1] + part[y0:y1]                     # launches add onto the framebuffer in order
+        for first, n in (launches or [(0, spp)]):                      # the oracle adds every chunk sum onto the running pixel value, launch after launch, as the engine does
+            _, cnt = osc.render_xorshift(width, width, seed, first, n, math=math, threads=threads, rows=(y0, y1), out=full)
             out["rays_oracle"] += int(cnt.casts)
         g, o = np.ascontiguousarray(image[y0:y1], np.float32), full[y0:y1]
         out["rows"] += y1 - y0
