@@ -1079,6 +1079,10 @@ __device__ __forceinline__ void IntersectTriangleLeaf(const DevScene& sc, uint32
 #ifndef AMBER_BVH_DESCENT_BUDGET
 #define AMBER_BVH_DESCENT_BUDGET 5
 #endif
+// The same for the one-shot traversal (ClosestHitBvh: pt_megakernel<ENGINE_BVH>, the known-answer kernels), where nothing is resumed
+#ifndef AMBER_ONE_SHOT_BVH_BUDGET
+#define AMBER_ONE_SHOT_BVH_BUDGET AMBER_BVH_DESCENT_BUDGET
+#endif
 // Where a lane keeps the far children it has not visited yet.
 //  BvhStackLds     the whole stack in LDS, [level][thread of the workgroup] (conflict-free ds_read/write_b32); a push beyond
 //                  `cap` sets the overflow flag (the caller then falls back to the list scan; cannot happen with the
@@ -1128,7 +1132,7 @@ struct BvhStackHybrid {
 #else
 #define AMBER_PLANE_VALUE(bits16) static_cast<float>(bits16)
 #endif
-template <class Stack>
+template <class Stack, int kBudget = AMBER_BVH_DESCENT_BUDGET>
 __device__ __forceinline__ void BvhDescend(const DevScene& sc, const Stack& stack, BvhTrav& tr, const float t_best AMBER_STAMP_PARAM_OPT) {
   int32_t cur = tr.cur, pend = tr.pend;
   int sp = tr.sp;
@@ -1136,7 +1140,7 @@ __device__ __forceinline__ void BvhDescend(const DevScene& sc, const Stack& stac
 #define AMBER_BVH_PARK() \
   if (cur < 0 && pend == 0) { pend = cur; if (sp > 0) cur = stack.pop(sp); else cur = AMBER_BVH_DONE; }
   AMBER_BVH_PARK();
-  int budget = AMBER_BVH_DESCENT_BUDGET;
+  int budget = kBudget;
   while (cur >= 0 && cur != AMBER_BVH_DONE && budget-- > 0) {
     AMBER_COUNT(0);
 #if AMBER_BVH_WIDE
@@ -1249,9 +1253,9 @@ __device__ __forceinline__ void BvhLeafPhase(const DevScene& sc, V3 o, V3 d, Bvh
 }
 
 // One round for a lane on its own; returns false when the traversal is complete.
-template <class Stack>
+template <class Stack, int kBudget = AMBER_BVH_DESCENT_BUDGET>
 __device__ __forceinline__ bool BvhRoundOn(const DevScene& sc, const Stack& stack, V3 o, V3 d, BvhTrav& tr, HitRec& best AMBER_STAMP_PARAM_OPT) {
-  BvhDescend(sc, stack, tr, best.t AMBER_STAMP_ARG);
+  BvhDescend<Stack, kBudget>(sc, stack, tr, best.t AMBER_STAMP_ARG);
   BvhLeafPhase(sc, o, d, tr, best AMBER_STAMP_ARG);
   return tr.cur != AMBER_BVH_DONE || tr.pend != 0;
 }
@@ -1263,7 +1267,8 @@ __device__ __forceinline__ bool BvhRound(const DevScene& sc, int32_t* lds_stack,
 __device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_stack, V3 o, V3 d, HitRec& best, const int stack_cap = AMBER_BVH_STACK) {
   BvhTrav tr;
   BvhBegin(sc, o, d, tr, best);
-  while (BvhRound(sc, lds_stack, o, d, tr, best, stack_cap)) {}
+  const BvhStackLds stack{lds_stack + threadIdx.x, stack_cap};
+  while (BvhRoundOn<BvhStackLds, AMBER_ONE_SHOT_BVH_BUDGET>(sc, stack, o, d, tr, best)) {}
   if (__any(tr.overflow)) { if (tr.overflow) ClosestHitLeafList(sc, o, d, best); }
   BvhResolveIndex(sc, best);                                       // callers of this form report the object
 }
