@@ -17,7 +17,9 @@ After the timed steps, and outside `value`, the N = 1 run starts ONE child proce
 headline numbers are already on disk in gpurun_out/bench_headline.json by then, and a fault, hang or time-out of the child costs only
 its own fields) that measures on this one GPU:
   `secondary`         the other BASELINE configurations: config 3 at its full size, and ONE rank's share of configs 4 and 5 (its stripes
-                      of the real frame, one launch of the real samples-per-launch; config 5 with max depth 16);
+                      of the real frame, one launch of the real samples-per-launch; config 5 with max depth 16); and where a `--scene` user
+                      lands: the Cornell box through ENGINE_BVH (both schedulers) and just past the 32-object engine (33 / 49 objects), a room
+                      with a 1.3k-triangle OBJ mesh, a 1.04M-triangle terrain OBJ -- written and imported through cli::ImportScene here;
   `projected_scaling` every rank's COMPLETE step of the headline job at N = 1 / 2 / 4 / 8 (clear, launch, record kernels, sync, the RCCL
                       gather of its rows run as a one-rank collective), max over the ranks' shares -- a projection, labelled as such;
   `cold_start`        create -> first downloaded frame of the headline job on a new handle (`cold_wall_ms`).

@@ -48,11 +48,12 @@ int amber_hip_pt_signatures(amber_hip_pt*, uint32_t first_sample, uint32_t n_sam
  * section 5) that doubles as a known-answer test of the traversal. */
 int amber_hip_kat_traversal_rate(amber_hip_pt*, uint32_t n, const float* origins, const float* dirs, uint32_t waves, uint32_t refill_min,
                                  uint32_t repeats, float* out_t, int32_t* out_object, double* best_ms, uint32_t* out_rounds);
-/* Two-phase engine: the per-pixel candidate masks of the primary rays (pixel_mask_kernel; computed now if the handle has not rendered yet).
+/* Two-phase engine: the per-pixel candidate masks of the primary rays (pixel_mask_kernel, one mask per 4 x 4 block of pixels; for scenes of more than 32
+ * objects the masks describe group 0 -- the aperture blades and the first 26 objects).
  * out_mask: one word per band pixel, bit k = the object in filter-program slot k can be hit by SOME eye ray of the pixel (aperture blades
  * excluded: they are added per ray).  out_slot_of_object: n_objects entries, the slot of every scene object (0xffffffff: none).
  * out_always_mask: the slots that are candidates of EVERY ray whatever the pixel (objects the filter program has no record for, and the
- * aperture blades, which a primary ray adds itself).  kernel_ms: duration of the mask kernel if this call ran it, else -1.
+ * aperture blades, which a primary ray adds itself).  kernel_ms: duration of the mask kernel (create has run it once; asking for the duration runs it again between two events).
  * Any pointer may be NULL. */
 int amber_hip_kat_pixel_masks(amber_hip_pt*, uint32_t* out_mask, uint32_t* out_slot_of_object, uint32_t* out_always_mask, double* kernel_ms);
 /* the engine's sin/cos/pow on device: mode 0 = sincos(x[i]) -> out[2i], out[2i+1] ; mode 1 = pow(x[2i], x[2i+1]) -> out[i] ;
