@@ -123,6 +123,44 @@ int main() {
     for (auto& o : objs) { std::memset(&o, 0, sizeof o); o.kind = 1; o.a[0] = u(rng); o.a[1] = u(rng); o.a[2] = u(rng); o.radius = 0.004f; }
     CheckBvh(objs, "200k random spheres");
   }
+  // 3b. round 5: filter programs of SUBSETS (the two-phase engine's groups of 32), triangle-leaf references, SAH figures
+  {
+    std::mt19937 rng(5); std::uniform_real_distribution<float> u(-1.f, 1.f);
+    std::vector<DevObject> objs(100);
+    for (size_t i = 0; i < objs.size(); i++) {
+      DevObject& o = objs[i]; std::memset(&o, 0, sizeof o);
+      if (i % 7 == 3) { o.kind = 1; o.a[0] = u(rng); o.a[1] = u(rng); o.a[2] = u(rng); o.radius = 0.05f; continue; }
+      o.kind = 0; for (int c = 0; c < 3; c++) { o.a[c] = u(rng); o.e1[c] = 0.1f * u(rng); o.e2[c] = (i % 11 == 0) ? o.e1[c] : 0.1f * u(rng); }   // every 11th: zero area
+    }
+    const float center[3] = {0.1f, -0.2f, 0.3f};
+    size_t slots = 0;
+    for (size_t first = 0; first < objs.size(); first += 32) {
+      std::vector<uint32_t> members;
+      for (size_t k = first; k < std::min(objs.size(), first + 32); k++) members.push_back(static_cast<uint32_t>(objs.size() - 1 - k));   // any order, any subset
+      amber_filter::FilterProgram fp;
+      amber_filter::BuildFilterProgram(objs, center, fp, &members);
+      std::vector<uint32_t> sorted_order = fp.order, sorted_members = members;
+      std::sort(sorted_order.begin(), sorted_order.end()); std::sort(sorted_members.begin(), sorted_members.end());
+      if (sorted_order != sorted_members || fp.order.size() > 32) { std::printf("FAIL subset filter program: %zu slots for %zu members\n", fp.order.size(), members.size()); return 1; }
+      slots += fp.order.size();
+    }
+    std::printf("ok   filter programs of 4 subsets: %zu slots for %zu objects\n", slots, objs.size());
+    const auto b = amber_bvh::BuildBvh(objs);
+    const auto q = amber_bvh::QuantizeBvh(b.nodes, b.root_ref, [&](uint32_t slot) { return objs[b.prim_index[slot]].kind & 0xffu; });
+    size_t tri_leaves = 0, sphere_leaves = 0, mixed = 0;
+    for (const auto& nd : q.nodes)
+      for (int32_t ref : {nd.left, nd.right}) {
+        if (ref >= 0) continue;
+        const uint32_t r = static_cast<uint32_t>(-(ref + 1)), first = r >> 4, count = r & 3u;
+        bool tris = true, spheres = true;
+        for (uint32_t k = 0; k < count; k++) { const uint32_t kind = objs[b.prim_index[first + k]].kind; tris = tris && kind == 0; spheres = spheres && kind == 1; }
+        if (((r & 8u) != 0) != tris || ((r & 4u) != 0) != spheres || count == 0 || count > 3) { std::printf("FAIL leaf reference flags\n"); return 1; }
+        tri_leaves += tris; sphere_leaves += spheres; mixed += !tris && !spheres;
+      }
+    const amber_bvh::BvhQuality bq = amber_bvh::MeasureBvh(b.nodes, b.root_ref);
+    if (bq.leaves != tri_leaves + sphere_leaves + mixed || !(bq.inner_area >= 1.0) || bq.depth != b.depth) { std::printf("FAIL MeasureBvh: %u leaves, depth %u / %u\n", bq.leaves, bq.depth, b.depth); return 1; }
+    std::printf("ok   leaf references: %zu triangle leaves, %zu sphere leaves, %zu mixed; SAH inner term %.2f\n", tri_leaves, sphere_leaves, mixed, bq.inner_area);
+  }
   // 4. output stage writers
   {
     postprocess::HDRImage img(33, 17);
