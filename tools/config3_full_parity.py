@@ -4,21 +4,35 @@ the whole frame.
   (ii)  the pixels on which the GPU differs from oracle(REFERENCE BVH) == the pixels on which the oracle's two accelerations differ;
   (iii) every such pixel attributed to a path whose first differing cast is either a hit the reference's BVH loses because the ray misses
         the sphere's geometric box (its List, like the engine, keeps it) or an exact distance tie.
-python tools/config3_full_parity.py [spp]     (about two minutes of oracle time on 16 host threads)"""
+python tools/config3_full_parity.py [spp] [threads] [config3 | terrain | room_mesh]     (config 3: about two minutes of oracle time on 16 host threads;
+terrain / room_mesh, round 5: the imported-mesh workloads of bench.py at their full frames, read back through cli::ImportScene)"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 import amber_amd as A
 import oracle_binding as O
-from amber_amd import scenes
-spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-W, H, seed = 1920, 1080, 1
-threads = min(16, os.cpu_count() or 1)
-kw = scenes.random_spheres(1_000_000, 7)
-pt = A.PathTracer(A.HostScene.create_arrays(**kw), A.Sensor.default(W, H), seed=seed)
-pt.render_pass(0, spp); img, rays = pt.download()
+from amber_amd import scenes, workloads
+# usage: config3_full_parity.py [spp] [threads] [workload]     workload: config3 (default) | terrain | room_mesh   (round 5: the imported-mesh workloads at full size)
+args = [a for a in sys.argv[1:]]
+workload = next((a for a in args if not a.isdigit()), "config3")
+nums = [int(a) for a in args if a.isdigit()]
+W, H, seed = (1024, 1024, 7) if workload == "room_mesh" else (1920, 1080, 3 if workload == "terrain" else 1)
+spp = nums[0] if nums else {"config3": 256, "terrain": 64, "room_mesh": 256}[workload]
+threads = nums[1] if len(nums) > 1 else 16
+if workload == "config3":
+    kw = scenes.random_spheres(1_000_000, 7); blades_last = 0
+    hs = A.HostScene.create_arrays(**kw)
+else:
+    import tempfile
+    wl = workloads.terrain_mesh(16, 56) if workload == "terrain" else workloads.room_mesh(3)
+    kw = wl.arrays(); blades_last = O.BLADES_LAST
+    hs = A.HostScene.import_file(wl.write(tempfile.mkdtemp()))
+pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=seed)
+t = time.time(); pt.render_pass(0, spp); img, rays = pt.download(); tg = time.time() - t
+pt.close()
+print("%s, %dx%d @ %d spp, seed %d" % (workload, W, H, spp, seed))
 print("GPU (engine BVH, List semantics): %d rays" % rays, flush=True)
-t = time.time(); osc = O.Scene.create_arrays(**kw, accel=O.ACCEL_BVH_CONS); tb = time.time() - t
+t = time.time(); osc = O.Scene.create_arrays(**kw, accel=O.ACCEL_BVH_CONS | blades_last); tb = time.time() - t
 bits = lambda a: a.view(np.uint32)
 res = {}
 for name, accel in (("List via the conservative BVH", O.ACCEL_BVH_CONS), ("reference BVH", O.ACCEL_BVH)):
