@@ -146,3 +146,26 @@ def test_two_phase_refuses_more_than_128_objects(amber):
     with pytest.raises(AmberError, match="at most 128 objects"):
         amber.PathTracer(hs, amber.Sensor.default(32, 32), engine=amber.ENGINE_TWO_PHASE)
     amber.PathTracer(hs, amber.Sensor.default(32, 32)).close()               # AUTO: engine BVH
+
+
+@pytest.mark.gpu
+def test_small_imported_mesh_runs_the_grouped_two_phase_engine_with_the_blades_last(amber, oracle, tmp_path):
+    """cli::ImportScene puts the aperture blades LAST (import.cc:155-157); the grouped two-phase engine deals them into group 0 all the same (their slots,
+    the primary rounds' masks).  A 44-triangle imported room (50 objects): AUTO against the oracle and every other engine, light tracing included."""
+    wl = WL.room_mesh(0)
+    assert wl.n_triangles == 44
+    hs, osc = _import(amber, wl, tmp_path), O.Scene.create_arrays(**wl.arrays(), accel=O.ACCEL_BVH_CONS | O.BLADES_LAST)
+    _, _, lens = hs.flatten()
+    assert lens.first_blade_object == 44
+    W = H = 384
+    check_band(amber, hs, osc, W, H, 5, 48, (200, 232), max_ref_pixels=16, max_ref_ray_delta=128, label="imported room, 50 objects, engine auto (two groups)")
+    rows = (180, 184)
+    so = osc.set_accel(O.ACCEL_BVH_CONS).path_signatures(W, H, 5, 0, 24, rows, threads=16)
+    for engine in (amber.ENGINE_AUTO, amber.ENGINE_TWO_PHASE, amber.ENGINE_LIST, amber.ENGINE_BVH):
+        pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=5, rows=rows, engine=engine)
+        assert np.array_equal(pt.render_signatures(0, 24), so), engine
+        pt.close()
+    a = amber.PathTracer(hs, amber.Sensor.default(64, 48), seed=3).lt_trace(0, 16)
+    b = amber.PathTracer(hs, amber.Sensor.default(64, 48), seed=3, engine=amber.ENGINE_LIST).lt_trace(0, 16)
+    assert a[1] == b[1] and a[0].tobytes() == b[0].tobytes(), (a[1], b[1], len(a[0]), len(b[0]))
+    assert a[1] > 2 * 64 * 48 * 16                                       # light paths bounce (the aperture is a 1-cm target: splats are rare)
