@@ -289,14 +289,14 @@ def test_light_tracing_shards_by_path_index_and_splits_long_ranges(amber, cornel
 
 
 def test_render_batches_adapt_to_time(amber, cornell):
-    """HipPathTracingOptions.samples_per_launch = 0 (the default): Algorithm::Render grows its batches while they are short.
+    """HipPathTracingOptions.samples_per_launch = 0 (the default): Algorithm::Render grows its batches while they are short (at least doubling, at most to the measured 100-ms batch).
     All batches are multiples of the accumulation chunk, so the image is that of one launch -- bit for bit -- and of the oracle."""
     hs, osc = cornell
     W, H, spp = 96, 64, 200
     auto, st = hs.render(amber.Sensor.default(W, H), spp, seed=9)                          # samples_per_launch = 0: adaptive
     one, st1 = hs.render(amber.Sensor.default(W, H), spp, seed=9, samples_per_launch=spp)
     assert st["passes"] == st1["passes"] == spp and st["rays"] == st1["rays"]
-    assert 3 <= st["launches"] < 20                                                          # 8, 16, 32, 64, 80: not 25 launches of 8
+    assert 2 <= st["launches"] < 20                                                          # 8, then what the measured rate says fills 100 ms (here: the rest): not 25 launches of 8
     assert np.array_equal(bits(auto), bits(one))
     ref, cnt = osc.render_xorshift(W, H, 9, 0, spp)
     assert st["rays"] == cnt.casts and np.array_equal(bits(auto), bits(ref / np.float32(spp)))
