@@ -4,6 +4,8 @@ set -u
 TAG=$1; KERNEL=$2; shift 2
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmcg_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+# bench.py starts a child process for its side measurements, which would inherit the profiler and run under counter collection: not when profiled
+case "$1" in *bench.py) case " $* " in *" --no-secondary "*) ;; *) set -- "$@" --no-secondary ;; esac ;; esac
 for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "TA_TA_BUSY_sum TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TA_TOTAL_WAVEFRONTS_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   timeout -k 10 200 rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$name" -- python3 "$@" > "$OUT/pmc_${name}.log" 2>&1 || echo "pmc $pass failed"
