@@ -645,33 +645,37 @@ __device__ __forceinline__ FilterView SceneView(const DevScene& sc) {
   return FilterView{(ConstWords)(sc.planes), (ConstWords)(sc.tri_filters), (ConstWords)(sc.sphere_filters), static_cast<int>(sc.n_planes), static_cast<int>(sc.n_simple_planes),
                     static_cast<int>(sc.n_sphere_filters), sc.always_mask, sc.n_prog_tris, sc.n_objects, 0};
 }
-template <bool kFirst>
+template <bool kMulti, bool kFirst>
 __device__ __forceinline__ void ClosestHitTwoPhaseView(const DevScene& sc, const FilterView fv, const DevObject* lds_objects, V3 o_world, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM,
                                                        const bool use_premask, const uint32_t premask);
 __device__ __forceinline__ void ClosestHitTwoPhase(const DevScene& sc, const DevObject* lds_objects, V3 o_world, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM,
                                                    const bool use_premask = false, const uint32_t premask = 0u) {
-  ClosestHitTwoPhaseView<true>(sc, SceneView(sc), lds_objects, o_world, d, origin_slot, best AMBER_STAMP_ARG, use_premask, premask);
+  ClosestHitTwoPhaseView<false, true>(sc, SceneView(sc), lds_objects, o_world, d, origin_slot, best AMBER_STAMP_ARG, use_premask, premask);
 }
 // Engine TWO_PHASE_N: every group in turn; the primary rounds' pixel masks describe group 0 only (the other groups run Phase A for eye rays too).
 __device__ __forceinline__ void ClosestHitTwoPhaseGroups(const DevScene& sc, const DevObject* lds_objects, V3 o_world, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM,
                                                          const bool use_premask = false, const uint32_t premask = 0u) {
-  ClosestHitTwoPhaseView<true>(sc, SceneView(sc), lds_objects, o_world, d, origin_slot < 32 ? origin_slot : -1, best AMBER_STAMP_ARG, use_premask, premask);
+  ClosestHitTwoPhaseView<true, true>(sc, SceneView(sc), lds_objects, o_world, d, origin_slot < 32 ? origin_slot : -1, best AMBER_STAMP_ARG, use_premask, premask);
   const int n_groups = static_cast<int>(sc.n_groups);
   ConstWords gw = (ConstWords)(sc.groups);
   for (int g = 1; g < n_groups; ++g) {
     ConstWords w = gw + g * 12;                               // DevFilterGroup = 12 dwords
     const FilterView fv{(ConstWords)(sc.planes) + w[0] * 8u, (ConstWords)(sc.tri_filters) + w[3] * 8u, (ConstWords)(sc.sphere_filters) + w[4] * 8u,
                         static_cast<int>(w[1]), static_cast<int>(w[2]), static_cast<int>(w[5]), w[6], w[7], w[8], g * 32};
-    ClosestHitTwoPhaseView<false>(sc, fv, lds_objects, o_world, d, origin_slot, best AMBER_STAMP_ARG, false, 0u);
+    ClosestHitTwoPhaseView<true, false>(sc, fv, lds_objects, o_world, d, origin_slot, best AMBER_STAMP_ARG, false, 0u);
   }
 }
-template <bool kFirst>
+// kMulti = false: the 32-object engine -- the code of rounds 2-4, operand for operand (slot base 0, the kind byte unmasked: a 1.2 % slower config-2 kernel was
+// the price of sharing ONE instantiation with the grouped engine, tools/ab_lib.py across the round's commits).
+template <bool kMulti, bool kFirst>
 __device__ __forceinline__ void ClosestHitTwoPhaseView(const DevScene& sc, const FilterView fv, const DevObject* lds_objects_all, V3 o_world, V3 d, int origin_slot_all, HitRec& best AMBER_STAMP_PARAM,
                                                        const bool use_premask, const uint32_t premask) {
   if (kFirst) { best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1; }
-  const DevObject* lds_objects = lds_objects_all + fv.slot_base;
-  const int origin_slot = kFirst ? origin_slot_all : ((origin_slot_all >= fv.slot_base && origin_slot_all < fv.slot_base + 32) ? origin_slot_all - fv.slot_base : -1);
-  uint32_t cand = fv.always_mask;
+  const int slot_base = kMulti ? fv.slot_base : 0;
+  const DevObject* lds_objects = kMulti ? lds_objects_all + slot_base : lds_objects_all;
+  const int origin_slot = kFirst ? origin_slot_all : ((origin_slot_all >= slot_base && origin_slot_all < slot_base + 32) ? origin_slot_all - slot_base : -1);
+  constexpr uint32_t kKindMask = kMulti ? 0x7fu : 0xffu;       // the grouped engine's LDS records flag filtered triangles in bit 7 of `kind`
+  uint32_t cand = kMulti ? fv.always_mask : sc.always_mask;      // (kMulti = false reads the scene record where rounds 2-4 read it: nothing of `fv` is live)
   // use_premask (WAVE-UNIFORM): the candidates are already known -- a primary round of pt_megakernel, whose 64 eye rays take them
   // from their pixel's mask (pixel_mask_kernel: every object some ray of the pixel's beam can hit, computed once per handle) --
   // so Phase A, a third of the kernel, is skipped for the ray that every path starts with.
@@ -690,9 +694,9 @@ __device__ __forceinline__ void ClosestHitTwoPhaseView(const DevScene& sc, const
     // Every comparison is false on NaN: nothing is pruned and nothing is certain.
     float t_upper = sc.fp_tmax * __builtin_amdgcn_rsqf(d.x * d.x + d.y * d.y + d.z * d.z);
     if (!(t_upper == t_upper)) t_upper = 3.402823466e+38f;
-    ConstWords pl = fv.planes;
-    ConstWords tr = fv.tris;
-    const int n_planes = fv.n_planes;
+    ConstWords pl = kMulti ? fv.planes : (ConstWords)(sc.planes);
+    ConstWords tr = kMulti ? fv.tris : (ConstWords)(sc.tri_filters);
+    const int n_planes = kMulti ? fv.n_planes : static_cast<int>(sc.n_planes);
     uint32_t bit = 1u;                                       // candidate bit of the next program triangle (SALU)
     float nd = 0.f, no = 0.f, rc = 0.f;
 #define AMBER_PLANE_NORMAL() \
@@ -730,7 +734,7 @@ __device__ __forceinline__ void ClosestHitTwoPhaseView(const DevScene& sc, const
         cand |= keep1 ? bit : 0u; \
         cand |= keep2 ? (bit << 1) : 0u; \
         AMBER_PLANE_HIT(__builtin_fmaxf(m1, m2)); }
-    const int n_simple = fv.n_simple_planes;
+    const int n_simple = kMulti ? fv.n_simple_planes : static_cast<int>(sc.n_simple_planes);
     int p = 0;
     for (; p < n_simple; p += 2) {                          // slabs (filter_build.h): two parallel planes of one parallelogram pair each
       AMBER_PLANE_NORMAL();
@@ -761,8 +765,8 @@ __device__ __forceinline__ void ClosestHitTwoPhaseView(const DevScene& sc, const
 #undef AMBER_PLANE_NORMAL
 #undef AMBER_PAIR_RECORD
 #undef AMBER_PLANE_HIT
-    ConstWords sp = fv.spheres;
-    const int ns = fv.n_sphere_filters;
+    ConstWords sp = kMulti ? fv.spheres : (ConstWords)(sc.sphere_filters);
+    const int ns = kMulti ? fv.n_sphere_filters : static_cast<int>(sc.n_sphere_filters);
     for (int k = 0; k < ns; ++k, sp += 8, bit <<= 1) {      // DevSphereFilter = 8 dwords
       const float cx = cw_f(sp, 0) - o.x, cy = cw_f(sp, 1) - o.y, cz = cw_f(sp, 2) - o.z;
       const float bb = __builtin_fmaf(cx, d.x, __builtin_fmaf(cy, d.y, cz * d.z));       // co.d
@@ -780,7 +784,7 @@ __device__ __forceinline__ void ClosestHitTwoPhaseView(const DevScene& sc, const
   if (!use_premask) {
     const float ex = Abs(o_world.x - sc.fp_center[0]), ey = Abs(o_world.y - sc.fp_center[1]), ez = Abs(o_world.z - sc.fp_center[2]);
     const bool in_model = __builtin_fmaxf(__builtin_fmaxf(ex, ey), ez) <= sc.fp_reach && (d.x * d.x + d.y * d.y + d.z * d.z) <= 4.0f;   // NaN -> false
-    if (!in_model) cand = fv.n_objects >= 32u ? 0xffffffffu : ((1u << fv.n_objects) - 1u);
+    if (!in_model) { const uint32_t n_here = kMulti ? fv.n_objects : sc.n_objects; cand = n_here >= 32u ? 0xffffffffu : ((1u << n_here) - 1u); }
   }
   AMBER_STAMP(2);
   // Self trip.  A ray that leaves a triangle always re-selects that triangle in Phase A (t' ~ 0), and the exact test
@@ -799,7 +803,8 @@ __device__ __forceinline__ void ClosestHitTwoPhaseView(const DevScene& sc, const
     }
   }
   // Phase B: filtered triangles first, then everything else (keeps the per-lane kind branch out of the hot loop)
-  const uint32_t tri_bits = fv.n_prog_tris >= 32u ? 0xffffffffu : ((1u << fv.n_prog_tris) - 1u);
+  const uint32_t n_tris_here = kMulti ? fv.n_prog_tris : sc.n_prog_tris;
+  const uint32_t tri_bits = n_tris_here >= 32u ? 0xffffffffu : ((1u << n_tris_here) - 1u);
   uint32_t mt = cand & tri_bits;
 #ifdef AMBER_STAMPS
   while (__any(mt != 0u)) {                                  // diagnostic build: all lanes stay in the loop so that lane 0 can count
@@ -812,7 +817,7 @@ __device__ __forceinline__ void ClosestHitTwoPhaseView(const DevScene& sc, const
       const int slot = __builtin_ctz(mt);
       mt &= mt - 1u;
       const DevObject& ob = lds_objects[slot];
-      IntersectTriangle<true>(ld3(ob.a), ld3(ob.e1), ld3(ob.e2), static_cast<int>(ob.kind >> 8), fv.slot_base + slot, o_world, d, best);
+      IntersectTriangle<true>(ld3(ob.a), ld3(ob.e1), ld3(ob.e2), static_cast<int>(ob.kind >> 8), slot_base + slot, o_world, d, best);
     }
   }
   uint32_t mo = cand & ~tri_bits;
@@ -820,7 +825,7 @@ __device__ __forceinline__ void ClosestHitTwoPhaseView(const DevScene& sc, const
     const int slot = __builtin_ctz(mo);
     mo &= mo - 1u;
     const DevObject& ob = lds_objects[slot];
-    IntersectObject<true>(ob, ob.kind & 0x7fu, static_cast<int>(ob.kind >> 8), fv.slot_base + slot, o_world, d, best);
+    IntersectObject<true>(ob, ob.kind & kKindMask, static_cast<int>(ob.kind >> 8), slot_base + slot, o_world, d, best);
   }
 }
 
@@ -1286,9 +1291,10 @@ __device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* 
 }
 
 // position / normal of the winning hit, evaluated exactly as the reference's Intersect() does
+template <uint32_t kKindMask = 0xffu>
 __device__ __forceinline__ void ResolveHit(const DevObject* objects, const HitRec& h, V3 o, V3 d, V3& pos, V3& normal, uint32_t& material) {
   const DevObject* ob = objects + h.slot;
-  const uint32_t kind = ob->kind & 0x7fu;             // the LDS image of the two-phase engine tags kind with index << 8 and bit 7 (a filtered triangle)
+  const uint32_t kind = ob->kind & kKindMask;         // the LDS image of the two-phase engine tags kind with index << 8; the grouped engine's also with bit 7 (a filtered triangle)
   material = ob->material;
   const V3 A = ld3(ob->a);
   if (kind == PRIM_TRIANGLE) {
@@ -1310,8 +1316,9 @@ __device__ __forceinline__ void ResolveHit(const DevObject* objects, const HitRe
 // Copies the object records into the workgroup's LDS image (two-phase engine only; n_objects <= 32).
 #define AMBER_MAX_LDS_OBJECTS 32
 #define AMBER_MAX_GROUP_OBJECTS 128          /* engine TWO_PHASE_N: four groups of 32 */
-__device__ __forceinline__ void StageObjects(const DevScene& sc, DevObject* lds_objects) {
-  const uint32_t n_dwords = sc.n_lds_objects * (sizeof(DevObject) / 4u);
+template <bool kGroups = false>                          // kGroups: the grouped engine's image, 32 slots per group (sc.n_lds_objects records); else the scene's n_objects -- the
+__device__ __forceinline__ void StageObjects(const DevScene& sc, DevObject* lds_objects) {   // 32-object kernel must not read one more field of the scene record: its SGPRs are spilled as it is
+  const uint32_t n_dwords = (kGroups ? sc.n_lds_objects : sc.n_objects) * (sizeof(DevObject) / 4u);
   const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.prog_objects);
   uint32_t* dst = reinterpret_cast<uint32_t*>(lds_objects);
   for (uint32_t k = threadIdx.x; k < n_dwords; k += blockDim.x) dst[k] = src[k];
@@ -1614,7 +1621,7 @@ __device__ __forceinline__ bool PathShade(const DevScene& sc, const DevObject* l
     return false;
   }
   V3 pos, normal; uint32_t mat;
-  ResolveHit((kEngine == ENGINE_TWO_PHASE || kEngine == ENGINE_TWO_PHASE_N) ? lds_objects : (kEngine == ENGINE_BVH ? sc.bvh_objects : sc.objects), h, o, d, pos, normal, mat);
+  ResolveHit<kEngine == ENGINE_TWO_PHASE_N ? 0x7fu : 0xffu>((kEngine == ENGINE_TWO_PHASE || kEngine == ENGINE_TWO_PHASE_N) ? lds_objects : (kEngine == ENGINE_BVH ? sc.bvh_objects : sc.objects), h, o, d, pos, normal, mat);
   const DevMaterial m = sc.materials[mat];
   const V3 dir_out = -d;
   if (kTrace) { trace->object = h.idx; trace->t = h.t; trace->pos = pos; trace->weight_before = weight; }

@@ -389,7 +389,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   std::vector<DevObject> prog(more_progs.empty() ? fprog.order.size() : 32u * (more_progs.size() + 1));
   if (!prog.empty()) std::memset(prog.data(), 0, prog.size() * sizeof(DevObject));
   auto place = [&](const amber_filter::FilterProgram& fp, size_t base) {
-    for (size_t k = 0; k < fp.order.size(); k++) { prog[base + k] = objs[fp.order[k]]; prog[base + k].kind |= fp.order[k] << 8 | (k < fp.n_prog_tris ? 0x80u : 0u); }
+    for (size_t k = 0; k < fp.order.size(); k++) { prog[base + k] = objs[fp.order[k]]; prog[base + k].kind |= fp.order[k] << 8 | (!more_progs.empty() && k < fp.n_prog_tris ? 0x80u : 0u); }   // (the flag only in the grouped engine's image)
   };
   place(fprog, 0);
   if (!more_progs.empty()) {
