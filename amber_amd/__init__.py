@@ -11,6 +11,7 @@ from .api import (  # noqa: F401
     ENGINE_AUTO,
     ENGINE_BVH,
     ENGINE_LIST,
+    ENGINE_REFERENCE_BVH,
     ENGINE_TWO_PHASE,
     ENGINE_WAVEFRONT,
     PT_FLAG_BVH_ITEMS,

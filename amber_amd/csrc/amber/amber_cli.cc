@@ -93,7 +93,7 @@ int main(int argc, char** argv) {
   if (!Parse(argc, argv, option) || option.help) {
     std::cerr << "amber: a global illumination renderer (MI355X path tracer)\n"
                  "  --algorithm pt  --spp N  --width W  --height H  --time S  --output NAME  [--threads N]  [--scene FILE.obj]\n"
-                 "  [--seed N] [--device N | --devices N | --device-list a,b,..] [--max-depth N] [--engine 0..4] [--samples-per-launch N]" << std::endl;
+                 "  [--seed N] [--device N | --devices N | --device-list a,b,..] [--max-depth N] [--engine 0..4|6] [--samples-per-launch N]" << std::endl;
     return option.help ? 0 : -1;
   }
   if (option.spp == 0 && option.time == 0) std::cerr << "note: --spp 0 without --time renders until SIGINT" << std::endl;

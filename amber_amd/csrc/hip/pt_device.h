@@ -173,6 +173,10 @@ struct DevLens {
   float edge_tol;             // barycentric distance from a blade's boundary below which an aperture sample may also lie in ANOTHER blade for the exact
                               // test: 1e-3, or more when the blades are small against the binary32 grid of their world coordinates (>= 0.34: always)
 };
+// Engine REFERENCE_BVH (ref_bvh_build.h): an inner node of the reference's own tree with BOTH children's boxes as the reference stores them
+// (binary32, unpadded); a child reference >= 0 is a node, < 0 is leaf -(reference + 1); a leaf is a run of the sorted object order.
+struct alignas(16) DevRefNode { float lmin[3], lmax[3], rmin[3], rmax[3]; int32_t left, right; uint32_t pad[2]; };   // 64 B
+struct DevRefLeaf { uint32_t first, count; };
 struct DevSensor {
   uint32_t w, h;
   float wf, hf, sw, sh;
@@ -216,6 +220,12 @@ struct DevScene {
   uint32_t max_depth;
   const DevLens* __restrict__ lens;              // device memory, read with LoadLens() where a path starts / ends
   DevSensor sensor;
+  // engine REFERENCE_BVH (the last fields: the other engines' kernels never read them).  It also uses bvh_objects / bvh_prims (the objects in the
+  // order the reference's build leaves them in) and bvh_root (a DevRefNode index, or a leaf)
+  const DevRefNode* __restrict__ ref_nodes;
+  const DevRefLeaf* __restrict__ ref_leaves;
+  uint2* ref_stack;                              // traversal stack, [level][thread of the grid]: {child reference, bits of the child's entry distance}
+  uint32_t ref_stack_stride;                     // threads of the grid the stack was allocated for
 };
 
 #define AMBER_PHONG_MAX_TRIES 1024
@@ -1278,7 +1288,83 @@ __device__ __forceinline__ void ClosestHitBvh(const DevScene& sc, int32_t* lds_s
   BvhResolveIndex(sc, best);                                       // callers of this form report the object
 }
 
-enum { ENGINE_LIST = 1, ENGINE_TWO_PHASE = 2, ENGINE_BVH = 3, ENGINE_TWO_PHASE_N = 5 };   // (4 is the public WAVEFRONT; 5 = two-phase over groups of 32 objects)
+// Engine REFERENCE_BVH: BVH::Node::Cast (acceleration_bvh.h:340-403) on the reference's own tree, without recursion.
+//
+// The recursion passes a bound `distance` down and hands hits up; every hit it accepts is strictly closer than the bound it was searched
+// under, and a far child is searched under the near child's hit distance (:393-396) -- so the bound in force at any moment is the closest
+// hit found so far in the whole cast, and one running `best` serves every level.  A node whose two children are both entered (:374-383)
+// visits the nearer one (left_in < right_in ? left : right) and comes back for the other: that one goes on the stack with its entry
+// distance max(left_in, right_in).  When it is popped the recursion's three cases are one comparison:
+//   near subtree found nothing  -> best is still the bound the far child's box was accepted under, t_in <= bound: visit (:384-386)
+//   near hit in front of the far box (best.t < t_in) -> return the near hit: skip (:387-389)
+//   otherwise -> search the far child under the near hit's distance (:391-400).
+// A leaf scans its objects in the order the build left them, a hit replacing the best iff it is strictly closer (:343-355): on equal
+// distances the FIRST object met wins -- not the lower scene index of the List rule the other engines implement.
+// The slab test is aabb.cc:28-62 operation for operation: reciprocal direction by IEEE division, (plane - origin) * reciprocal,
+// _mm_min_ps / _mm_max_ps (the SECOND operand when one is NaN), std::max / std::min over {0 | distance, x, y, z} left to right.
+__device__ __forceinline__ float SseMin(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float SseMax(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ bool ReferenceSlab(const float* mn, const float* mx, V3 o, V3 inv, float distance, float& t_in) {
+  const float t0x = (mn[0] - o.x) * inv.x, t0y = (mn[1] - o.y) * inv.y, t0z = (mn[2] - o.z) * inv.z;
+  const float t1x = (mx[0] - o.x) * inv.x, t1y = (mx[1] - o.y) * inv.y, t1z = (mx[2] - o.z) * inv.z;
+  const float nx = SseMin(t0x, t1x), ny = SseMin(t0y, t1y), nz = SseMin(t0z, t1z);
+  const float fx = SseMax(t0x, t1x), fy = SseMax(t0y, t1y), fz = SseMax(t0z, t1z);
+  float t_min = 0.0f;                                    // std::max({t_min, ..}): the running value is replaced iff it is < the next
+  if (t_min < nx) t_min = nx;
+  if (t_min < ny) t_min = ny;
+  if (t_min < nz) t_min = nz;
+  float t_max = distance;                                // std::min({t_max, ..}): replaced iff the next is < it
+  if (fx < t_max) t_max = fx;
+  if (fy < t_max) t_max = fy;
+  if (fz < t_max) t_max = fz;
+  t_in = t_min;
+  return t_min <= t_max;
+}
+__device__ __forceinline__ void ClosestHitReferenceBvh(const DevScene& sc, V3 o, V3 d, HitRec& best) {
+  best.t = 3.402823466e+38f; best.u = 0.f; best.v = 0.f; best.idx = -1; best.slot = -1;   // Acceleration::Cast(ray, max()), acceleration.h:46-51
+  const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  uint2* const stack = sc.ref_stack + (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x);
+  const size_t stride = sc.ref_stack_stride;
+  int sp = 0;
+  int32_t cur = sc.bvh_root;                             // the root is cast without a test of its own box (:152-156)
+  for (;;) {
+    if (cur >= 0) {
+      const uint4* nd = reinterpret_cast<const uint4*>(sc.ref_nodes + cur);
+      const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
+      const float lmin[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)}, lmax[3] = {__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y)};
+      const float rmin[3] = {__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x)}, rmax[3] = {__uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
+      const int32_t left = static_cast<int32_t>(w3.x), right = static_cast<int32_t>(w3.y);
+      float lin, rin;
+      const bool lh = ReferenceSlab(lmin, lmax, o, inv, best.t, lin);
+      const bool rh = ReferenceSlab(rmin, rmax, o, inv, best.t, rin);
+      if (lh && rh) {
+        const bool left_near = lin < rin;
+        const uint32_t far_ = static_cast<uint32_t>(left_near ? right : left);
+        stack[static_cast<size_t>(sp) * stride] = make_uint2(far_, __float_as_uint(left_near ? rin : lin));   // std::max(left_in, right_in)
+        ++sp;
+        cur = left_near ? left : right;
+        continue;
+      }
+      if (lh) { cur = left; continue; }
+      if (rh) { cur = right; continue; }
+    } else {
+      const DevRefLeaf lf = sc.ref_leaves[-(cur + 1)];
+      for (uint32_t k = lf.first; k < lf.first + lf.count; ++k) {
+        const DevObject& ob = sc.bvh_objects[k];
+        IntersectObject<false>(ob, ob.kind, static_cast<int>(sc.bvh_prims[k]), static_cast<int>(k), o, d, best);
+      }
+    }
+    bool more = false;
+    while (sp > 0) {
+      --sp;
+      const uint2 e = stack[static_cast<size_t>(sp) * stride];
+      if (!(best.t < __uint_as_float(e.y))) { cur = static_cast<int32_t>(e.x); more = true; break; }
+    }
+    if (!more) return;
+  }
+}
+
+enum { ENGINE_LIST = 1, ENGINE_TWO_PHASE = 2, ENGINE_BVH = 3, ENGINE_TWO_PHASE_N = 5, ENGINE_REF_BVH = 6 };   // (4 is the public WAVEFRONT; 5 = two-phase over groups of 32 objects)
 
 template <int kEngine>
 __device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* lds_objects, int32_t* lds_stack, V3 o, V3 d, int origin_slot, HitRec& best AMBER_STAMP_PARAM,
@@ -1286,6 +1372,7 @@ __device__ __forceinline__ void ClosestHit(const DevScene& sc, const DevObject* 
   if (kEngine == ENGINE_TWO_PHASE) ClosestHitTwoPhase(sc, lds_objects, o, d, origin_slot, best AMBER_STAMP_ARG, use_premask, premask);
   else if (kEngine == ENGINE_TWO_PHASE_N) ClosestHitTwoPhaseGroups(sc, lds_objects, o, d, origin_slot, best AMBER_STAMP_ARG, use_premask, premask);
   else if (kEngine == ENGINE_BVH) ClosestHitBvh(sc, lds_stack, o, d, best, bvh_stack_cap);
+  else if (kEngine == ENGINE_REF_BVH) ClosestHitReferenceBvh(sc, o, d, best);
   else ClosestHitList(sc, o, d, best);
   AMBER_STAMP(3);
 }
@@ -1621,7 +1708,7 @@ __device__ __forceinline__ bool PathShade(const DevScene& sc, const DevObject* l
     return false;
   }
   V3 pos, normal; uint32_t mat;
-  ResolveHit<kEngine == ENGINE_TWO_PHASE_N ? 0x7fu : 0xffu>((kEngine == ENGINE_TWO_PHASE || kEngine == ENGINE_TWO_PHASE_N) ? lds_objects : (kEngine == ENGINE_BVH ? sc.bvh_objects : sc.objects), h, o, d, pos, normal, mat);
+  ResolveHit<kEngine == ENGINE_TWO_PHASE_N ? 0x7fu : 0xffu>((kEngine == ENGINE_TWO_PHASE || kEngine == ENGINE_TWO_PHASE_N) ? lds_objects : ((kEngine == ENGINE_BVH || kEngine == ENGINE_REF_BVH) ? sc.bvh_objects : sc.objects), h, o, d, pos, normal, mat);
   const DevMaterial m = sc.materials[mat];
   const V3 dir_out = -d;
   if (kTrace) { trace->object = h.idx; trace->t = h.t; trace->pos = pos; trace->weight_before = weight; }

@@ -33,6 +33,7 @@
 #include "pt_device.h"
 #include "bvh_build.h"
 #include "filter_build.h"
+#include "ref_bvh_build.h"
 
 using namespace amber_dev;
 
@@ -86,6 +87,9 @@ struct amber_hip_pt {
   float4* d_bvh_tris = nullptr;
   uint32_t* d_bvh_prims = nullptr;
   DevObject* d_bvh_objects = nullptr;
+  DevRefNode* d_ref_nodes = nullptr;        // engine REFERENCE_BVH: the reference's own tree (ref_bvh_build.h) ...
+  DevRefLeaf* d_ref_leaves = nullptr;
+  uint2* d_ref_stack = nullptr;             // ... and its traversal stack, [level][thread of the largest grid]
   bool two_phase = false;
   uint32_t bvh_depth = 0;                   // depth of the flattened tree (selects the traversal-stack size)
   float* d_fb = nullptr;
@@ -159,6 +163,7 @@ struct DevBuf {
 };
 
 int StartPixelMasks(amber_hip_pt* h, float* timing);      // defined with the launch code below
+uint32_t ResidentBlocksPerCu(uint32_t hit_engine, uint32_t bvh_depth);
 
 constexpr uint32_t kHitTwoPhaseN = 5;                // amber_hip_pt.hit_engine: the two-phase engine over groups of 32 objects (device: ENGINE_TWO_PHASE_N); not a public engine id
 constexpr uint32_t kTwoPhaseAutoObjects = 80;        // AUTO picks the grouped two-phase engine up to this many objects: the Cornell box plus small quads, 1024^2 @ 128 spp
@@ -223,7 +228,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     const uint32_t q = (re - rb) / params->stripe_period, rem = (re - rb) % params->stripe_period;
     local_rows = q * params->stripe_rows + (rem < params->stripe_rows ? rem : params->stripe_rows);
   }
-  if (params->engine > AMBER_ENGINE_WAVEFRONT) return Fail(AMBER_EINVAL, "unknown engine");
+  if (params->engine > AMBER_ENGINE_REFERENCE_BVH || params->engine == 5u) return Fail(AMBER_EINVAL, "unknown engine");
 #ifndef AMBER_LAB
   if (params->engine == AMBER_ENGINE_WAVEFRONT) return Fail(AMBER_EINVAL, "engine WAVEFRONT (the streaming formulation, kept for measurement) is part of the lab build, libamber_hip_lab.so");
   if (params->reserved & AMBER_PT_FLAG_BVH_POOL) return Fail(AMBER_EINVAL, "AMBER_PT_FLAG_BVH_POOL (pt_bvh_pool_kernel, kept for measurement) is part of the lab build, libamber_hip_lab.so");
@@ -328,6 +333,16 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
     { const char* ev = std::getenv("AMBER_BVH_PATHS_MAX_DEPTH"); if (ev && static_cast<uint32_t>(std::atoi(ev)) < bvh.depth) h->bvh_paths = false; }   // measurement hook
     if (debug_bvh) std::fprintf(stderr, "amber_hip: BVH of %u objects: %zu nodes, depth %u; scheduler %s, shading batch %u\n", s->n_objects, bvh.nodes.size(), bvh.depth,
                                 h->bvh_pool ? "pt_bvh_pool_kernel" : (h->bvh_paths ? "pt_megakernel<ENGINE_BVH>" : "pt_bvh_megakernel"), h->bvh_shade_batch);
+  }
+  amber_refbvh::FlatTree ref_tree;
+  uint32_t ref_depth = 0;
+  if (h->hit_engine == AMBER_ENGINE_REFERENCE_BVH) {
+    const amber_refbvh::Tree tree = amber_refbvh::Build(s->objects, s->n_objects);
+    ref_tree = amber_refbvh::Flatten(tree);
+    ref_depth = tree.depth;
+    bvh.prim_index = tree.order;                               // the object arrays of engine BVH, in the reference's order
+    if (std::getenv("AMBER_DEBUG_BVH"))
+      std::fprintf(stderr, "amber_hip: reference BVH of %u objects: %u inner nodes, %u leaves (largest %u objects), depth %u\n", s->n_objects, tree.n_inner, tree.n_leaves, tree.largest_leaf, tree.depth);
   }
   amber_filter::FilterProgram fprog;
   float fp_center[3] = {0, 0, 0}, fp_reach = 0;
@@ -488,11 +503,24 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   HIP_TRY_H(hipMemsetAsync(h->d_fb, 0, fb_floats * sizeof(float), h->stream));
   HIP_TRY_H(hipMemsetAsync(h->d_rays, 0, sizeof(unsigned long long), h->stream));
 
+  if (h->hit_engine == AMBER_ENGINE_REFERENCE_BVH) {
+    HIP_TRY_H(hipMalloc(&h->d_ref_nodes, (ref_tree.nodes.size() + 1) * sizeof(DevRefNode)));
+    HIP_TRY_H(hipMalloc(&h->d_ref_leaves, (ref_tree.leaves.size() + 1) * sizeof(DevRefLeaf)));
+    if (!ref_tree.nodes.empty()) HIP_TRY_H(hipMemcpy(h->d_ref_nodes, ref_tree.nodes.data(), ref_tree.nodes.size() * sizeof(DevRefNode), hipMemcpyHostToDevice));
+    if (!ref_tree.leaves.empty()) HIP_TRY_H(hipMemcpy(h->d_ref_leaves, ref_tree.leaves.data(), ref_tree.leaves.size() * sizeof(DevRefLeaf), hipMemcpyHostToDevice));
+    // one stack column per thread of the largest grid a launch of this handle uses; a walk from the root pushes at most one entry per level
+    const uint64_t threads = static_cast<uint64_t>(h->n_cus) * ResidentBlocksPerCu(h->hit_engine, 0) * 256u;
+    const uint64_t bytes = threads * (static_cast<uint64_t>(ref_depth) + 1u) * sizeof(uint2);
+    if (bytes > (64ull << 30)) return cleanup(AMBER_ENOMEM, "the reference's BVH of this scene is " + std::to_string(ref_depth) + " levels deep: its traversal stacks would take " + std::to_string(bytes >> 30) + " GiB");
+    HIP_TRY_H(hipMalloc(&h->d_ref_stack, bytes));
+    h->scene.ref_stack_stride = static_cast<uint32_t>(threads);
+  }
   DevScene& sc = h->scene;
   sc.objects = h->d_objects; sc.materials = h->d_materials; sc.blades = h->d_blades;
   sc.planes = h->d_planes; sc.tri_filters = h->d_tri_filters; sc.sphere_filters = h->d_sphere_filters;
   sc.n_planes = static_cast<uint32_t>(fprog.planes.size()); sc.n_simple_planes = fprog.n_simple_planes; sc.n_sphere_filters = static_cast<uint32_t>(fprog.spheres.size());
-  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_nodes4 = h->d_bvh_nodes4; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_spheres = h->d_bvh_spheres; sc.bvh_tris = h->d_bvh_tris; sc.bvh_root = qbvh.root_ref;
+  sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_nodes4 = h->d_bvh_nodes4; sc.bvh_prims = h->d_bvh_prims; sc.bvh_objects = h->d_bvh_objects; sc.bvh_spheres = h->d_bvh_spheres; sc.bvh_tris = h->d_bvh_tris; sc.bvh_root = h->hit_engine == AMBER_ENGINE_REFERENCE_BVH ? ref_tree.root : qbvh.root_ref;
+  sc.ref_nodes = h->d_ref_nodes; sc.ref_leaves = h->d_ref_leaves; sc.ref_stack = h->d_ref_stack;
   for (int c = 0; c < 3; c++) { sc.bvh_gmin[c] = qbvh.gmin[c]; sc.bvh_step[c] = qbvh.step[c]; sc.bvh_reach[c] = qbvh.reach[c]; }
   {
     // per-ray box margin of engine BVH (BvhBegin): centre and half diagonal of the scene bounds, 1 / smallest sphere radius
@@ -801,6 +829,7 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
     else if (h->bvh_paths) hipLaunchKernelGGL((pt_megakernel<ENGINE_BVH, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (h->hit_engine == kHitTwoPhaseN) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE_N, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else if (h->hit_engine == AMBER_ENGINE_REFERENCE_BVH) hipLaunchKernelGGL((pt_megakernel<ENGINE_REF_BVH, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL((pt_megakernel<ENGINE_LIST, false, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
   } else if (bvh) {
     hipLaunchKernelGGL((pt_bvh_pool_kernel<false>), dim3(n_blocks), dim3(256), 0, h->stream, a);
@@ -810,6 +839,7 @@ int LaunchPaths(amber_hip_pt* h, uint32_t first, uint32_t n, uint32_t n_pixels, 
     if (h->bvh_paths) hipLaunchKernelGGL((pt_megakernel<ENGINE_BVH>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (h->hit_engine == kHitTwoPhaseN) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE_N>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+    else if (h->hit_engine == AMBER_ENGINE_REFERENCE_BVH) hipLaunchKernelGGL((pt_megakernel<ENGINE_REF_BVH>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL((pt_megakernel<ENGINE_LIST>), dim3(n_blocks), dim3(256), 0, h->stream, a);
   }
   HIP_TRY(hipGetLastError());
@@ -1025,6 +1055,7 @@ int amber_hip_lt_trace_range(amber_hip_pt* h, uint32_t first_sample, uint32_t n_
     if (by_work < n_blocks) n_blocks = by_work;
       if (h->hit_engine == AMBER_ENGINE_TWO_PHASE) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
       else if (h->hit_engine == kHitTwoPhaseN) hipLaunchKernelGGL((pt_megakernel<ENGINE_TWO_PHASE_N, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
+      else if (h->hit_engine == AMBER_ENGINE_REFERENCE_BVH) hipLaunchKernelGGL((pt_megakernel<ENGINE_REF_BVH, true>), dim3(n_blocks), dim3(256), 0, h->stream, a);
     else if (bvh) {
       if (h->bvh_depth <= 24) hipLaunchKernelGGL((pt_bvh_megakernel<true, 24>), dim3(n_blocks), dim3(256), 0, h->stream, a);
       else hipLaunchKernelGGL((pt_bvh_megakernel<true, AMBER_BVH_STACK>), dim3(n_blocks), dim3(256), 0, h->stream, a);
@@ -1167,6 +1198,9 @@ void amber_hip_pt_destroy(amber_hip_pt* h) {
   if (h->d_bvh_tris) (void)hipFree(h->d_bvh_tris);
   if (h->d_bvh_prims) (void)hipFree(h->d_bvh_prims);
   if (h->d_bvh_objects) (void)hipFree(h->d_bvh_objects);
+  if (h->d_ref_nodes) (void)hipFree(h->d_ref_nodes);
+  if (h->d_ref_leaves) (void)hipFree(h->d_ref_leaves);
+  if (h->d_ref_stack) (void)hipFree(h->d_ref_stack);
   if (h->d_wf) (void)hipFree(h->d_wf);
   if (h->d_fb) (void)hipFree(h->d_fb);
   if (h->d_rays) (void)hipFree(h->d_rays);

@@ -38,7 +38,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-ENGINES = {"auto": 0, "list": 1, "two_phase": 2, "bvh": 3, "wavefront": 4}     # AMBER_ENGINE_* (include/amber_hip.h)
+ENGINES = {"auto": 0, "list": 1, "two_phase": 2, "bvh": 3, "wavefront": 4, "reference_bvh": 6}     # AMBER_ENGINE_* (include/amber_hip.h)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 BYTES_PER_RAY = 96.0      # algorithmic ray-state bytes per bounce (DESIGN.md "Roofline")
 
@@ -518,7 +518,7 @@ def main():
     ap.add_argument("--dist-selftest", action="store_true",
                     help="CPU-only self-test of the multi-rank plumbing (gloo): rendezvous with its time-outs, first barrier, the row gather on stand-in rows, "
                          "the per-rank table; no GPU, no render (tests/test_distributed_cpu.py)")
-    ap.add_argument("--engine", default="auto", choices=["auto", "list", "two_phase", "bvh", "wavefront"],
+    ap.add_argument("--engine", default="auto", choices=["auto", "list", "two_phase", "bvh", "wavefront", "reference_bvh"],
                     help="closest-hit / scheduling engine (default: auto = the fastest valid one; others for comparison)")
     args = ap.parse_args()
 

@@ -146,15 +146,23 @@ enum {
 };
 
 /* All engines are the same persistent work-queue kernel; they differ in how a lane finds its closest hit.
- * Every engine returns the List-semantics answer (closest finite hit, ties to the lower object index). */
+ * Engines 1-4 return the List-semantics answer (closest finite hit, ties to the lower object index: acceleration_list.h:51-68).
+ * REFERENCE_BVH returns what the reference's command line computes: Cast through the reference's own BVH
+ * (acceleration_bvh.h:134-403), which differs from List on distance ties and on hits the reference's traversal loses
+ * (INTEGRATION.md section 3). */
 enum {
   AMBER_ENGINE_AUTO = 0,       /* TWO_PHASE when the scene has <= 80 objects, BVH otherwise */
   AMBER_ENGINE_LIST = 1,       /* exact test of every object, wave-uniform scan (object data in SGPRs) */
   AMBER_ENGINE_TWO_PHASE = 2,  /* conservative wave-uniform candidate filter, then exact tests of the candidates only; <= 128 objects
                                   (beyond 32 the objects are dealt into groups of 32, one filter program each) */
   AMBER_ENGINE_BVH = 3,        /* host-built flattened 2-wide BVH, per-lane traversal with an LDS stack, exact leaf tests */
-  AMBER_ENGINE_WAVEFRONT = 4   /* LAB BUILD ONLY (the product answers AMBER_EINVAL): streaming formulation -- SoA ray queues in HBM, one launch
+  AMBER_ENGINE_WAVEFRONT = 4,  /* LAB BUILD ONLY (the product answers AMBER_EINVAL): streaming formulation -- SoA ray queues in HBM, one launch
                                   per bounce, ballot/prefix-sum compaction; closest hit as AUTO.  Same results; kept to measure that design. */
+  AMBER_ENGINE_REFERENCE_BVH = 6  /* the reference's own tree, built at create as acceleration_bvh.h:134-312 builds it (same topology, boxes and
+                                  object order) and walked per lane in the order of BVH::Node::Cast (:340-403) with the reference's slab test
+                                  (aabb.cc:28-62): the image of the reference's command line, bit for bit.  Never chosen by AUTO: slower than
+                                  engine BVH (unquantised 64-byte nodes, large leaves, a stack in global memory), and the build sorts every node
+                                  four times like the reference does (1M spheres: seconds). */
 };
 
 #pragma GCC visibility push(hidden)            /* the handle is opaque: its members (and their constructors) are not part of the ABI */

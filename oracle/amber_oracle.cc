@@ -1444,6 +1444,32 @@ void oracle_scene_bvh_stats(const oracle_scene* s, uint32_t* n_nodes, uint32_t* 
   *n_nodes = s->bvh ? s->bvh->n_nodes.load() : 0u; *n_leaves = s->bvh ? s->bvh->n_leaves.load() : 0u; *max_depth = s->bvh ? s->bvh->max_depth.load() : 0u;
 }
 
+// The tree itself, for checks of a builder that claims to be the reference's (the engine's AMBER_ENGINE_REFERENCE_BVH): objects_ after the
+// build (position -> insertion index), and FNV-1a64 over a pre-order walk -- per node a tag (1 inner, 0 leaf), the six box floats, and for a
+// leaf its range [first, first + count) of objects_.
+void oracle_scene_bvh_order(const oracle_scene* s, uint32_t* out) {
+  if (!s->bvh) return;
+  for (size_t i = 0; i < s->bvh->objects.size(); i++) out[i] = s->bvh->objects[i].index;
+}
+uint64_t oracle_scene_bvh_digest(const oracle_scene* s) {
+  if (!s->bvh) return 0;
+  uint64_t h = 14695981039346656037ull;
+  auto mix = [&](const void* p, size_t n) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+  std::vector<const BVH::Node*> stack{s->bvh->root.get()};
+  while (!stack.empty()) {
+    const BVH::Node* n = stack.back(); stack.pop_back();
+    const bool leaf = n->first != n->last;
+    const uint32_t tag = leaf ? 0u : 1u;
+    const float bb[6] = {n->bb.mn.x, n->bb.mn.y, n->bb.mn.z, n->bb.mx.x, n->bb.mx.y, n->bb.mx.z};
+    mix(&tag, 4); mix(bb, 24);
+    if (leaf) {
+      const uint32_t range[2] = {static_cast<uint32_t>(n->first - s->bvh->objects.begin()), static_cast<uint32_t>(n->last - n->first)};
+      mix(range, 8);
+    } else { stack.push_back(n->right.get()); stack.push_back(n->left.get()); }
+  }
+  return h;
+}
+
 // PathTracing::Render (algorithm_pt.cc:82-95) through ParallelMean (rendering/parallel.h:57-68) with
 // ThreadCount()==1: passes are summed by the binary-counter Accumulator (accumulator.h:136-166) and
 // divided by the pass count (Mean, :88-95).  Pixel loop: y outer, x inner (algorithm_pt.cc:112-123).

@@ -102,6 +102,9 @@ void     oracle_scene_get_lens(const oracle_scene*, float origin[3], float globa
                                float* focus_distance, float* sensor_distance, float* p_area);
 /* BVH stats: nodes, leaves, max depth (reference BVH, acceleration_bvh.h:134-312) */
 void     oracle_scene_bvh_stats(const oracle_scene*, uint32_t* n_nodes, uint32_t* n_leaves, uint32_t* max_depth);
+/* objects_ after the build (position -> insertion index) ; FNV-1a64 over a pre-order walk of the tree (tag, box, leaf range) */
+void     oracle_scene_bvh_order(const oracle_scene*, uint32_t* order_out /* n_objects */);
+uint64_t oracle_scene_bvh_digest(const oracle_scene*);
 
 typedef struct {
   uint64_t casts;    /* Scene::Cast calls (= "rays", algorithm_pt.cc:139) */

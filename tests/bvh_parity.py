@@ -71,9 +71,23 @@ def check_band(amber, hs, osc, W, H, seed, spp, rows, max_ref_pixels, max_ref_ra
         for c in found:
             assert c["cause"] != "unexplained", (label, px, c)
     flat = [c for f in causes.values() for c in f]
-    out = dict(rays=int(rays), pixels=img.shape[0] * W, differ_from_reference_bvh=n_diff, ray_delta_to_reference_bvh=ray_delta, paths=len(flat),
+    out = dict(reference_image=ref.copy(), reference_casts=int(cnt_b.casts), rays=int(rays), pixels=img.shape[0] * W, differ_from_reference_bvh=n_diff, ray_delta_to_reference_bvh=ray_delta, paths=len(flat),
                lost_hits=sum(c["cause"].startswith("lost hit") for c in flat), ties=sum(c["cause"].startswith("exact") for c in flat),
                lit=float((img.sum(axis=2) > 0).mean()))
     print(f"\n{label}: rows {rows} @ {spp} spp: {rays} rays, GPU == oracle(List) on all {out['pixels']} pixels; against the reference's BVH {n_diff} pixels differ "
           f"({ray_delta:+d} rays), every one attributed ({out['paths']} paths: {out['lost_hits']} lost hits, {out['ties']} ties)")
     return out
+
+
+def check_reference_engine(amber, hs, W, H, seed, spp, rows, reference_image, reference_casts, max_depth=0, label=""):
+    """AMBER_ENGINE_REFERENCE_BVH (the reference's own tree, its own traversal order) on the same band: image bits and ray count
+    == oracle(ACCEL_BVH), i.e. what the reference's command line computes -- including the pixels on which the other engines differ."""
+    pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=seed, rows=rows, engine=amber.ENGINE_REFERENCE_BVH, max_depth=max_depth)
+    pt.render_pass(0, spp)
+    img, rays = pt.download()
+    ms = pt.kernel_time()[1]
+    pt.close()
+    differing = int((bits(img) != bits(reference_image)).any(axis=2).sum())
+    print(f"\n{label}: engine REFERENCE_BVH, rows {rows} @ {spp} spp: {rays} rays in {ms:.1f} ms, {differing} pixels differ from oracle(reference BVH)")
+    assert rays == reference_casts, (label, rays, reference_casts)
+    assert differing == 0, (label, differing)

@@ -87,6 +87,9 @@ def load():
     L.oracle_scene_get_material.argtypes = [vp, u32, C.POINTER(OMaterial), C.POINTER(f)]
     L.oracle_scene_get_lens.argtypes = [vp] + [C.POINTER(f)] * 6
     L.oracle_scene_bvh_stats.argtypes = [vp] + [C.POINTER(u32)] * 3
+    L.oracle_scene_bvh_order.argtypes = [vp, vp]
+    L.oracle_scene_bvh_digest.argtypes = [vp]
+    L.oracle_scene_bvh_digest.restype = u64
     L.oracle_render_mt.argtypes = [vp, C.POINTER(OSensor), u64, u32, C.c_int, vp, C.POINTER(OCounters)]
     L.oracle_render_xorshift.argtypes = [vp, C.POINTER(OSensor), u64, u32, u32, u32, u32, C.c_int, u32, u32, u32, vp, C.POINTER(OCounters)]
     L.oracle_render_lt_xorshift.restype = u64
@@ -287,6 +290,15 @@ class Scene:
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self.L.oracle_scene_bvh_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
+
+    def bvh_order(self):
+        """objects_ after the reference's build: position -> insertion index"""
+        out = np.zeros(self.L.oracle_scene_object_count(self.h), np.uint32)
+        self.L.oracle_scene_bvh_order(self.h, out.ctypes.data)
+        return out
+
+    def bvh_digest(self):
+        return int(self.L.oracle_scene_bvh_digest(self.h))
 
     def __del__(self):
         try:

@@ -24,7 +24,7 @@ from amber_amd import scenes
 pytestmark = pytest.mark.gpu
 W, H, SEED, SPP = 1920, 1080, 1, 256
 
-from bvh_parity import bits, check_band
+from bvh_parity import bits, check_band, check_reference_engine
 
 
 @pytest.fixture(scope="module")
@@ -33,11 +33,24 @@ def config3(amber):
     return amber.HostScene.create_arrays(**kw), O.Scene.create_arrays(**kw, accel=O.ACCEL_BVH_CONS)
 
 
-def test_config3_band_at_256spp_equals_the_list_oracle_and_every_difference_from_the_reference_bvh_is_attributed(amber, config3):
+BAND = (508, 572)
+
+
+@pytest.fixture(scope="module")
+def band(amber, config3):
     hs, osc = config3
     # hard bound against the reference's own BVH; the full frame has 117 such pixels of 2 073 600 (profiles/r04_config3_full_parity.txt)
-    st = check_band(amber, hs, osc, W, H, SEED, SPP, (508, 572), max_ref_pixels=32, max_ref_ray_delta=512, label="config 3")      # measured on this band: 15 pixels, -132 rays
-    assert st["differ_from_reference_bvh"] > 0                              # the band was chosen to contain some
+    return check_band(amber, hs, osc, W, H, SEED, SPP, BAND, max_ref_pixels=32, max_ref_ray_delta=512, label="config 3")      # measured on this band: 15 pixels, -132 rays
+
+
+def test_config3_band_at_256spp_equals_the_list_oracle_and_every_difference_from_the_reference_bvh_is_attributed(band):
+    assert band["differ_from_reference_bvh"] > 0                            # the band was chosen to contain some
+
+
+def test_config3_band_through_the_references_own_tree_equals_the_reference_bvh_oracle(amber, config3, band):
+    """AMBER_ENGINE_REFERENCE_BVH: the same band, now including the pixels of the test above -- what the reference's command line renders
+    (acceleration_bvh.h:134-403), bit for bit."""
+    check_reference_engine(amber, config3[0], W, H, SEED, SPP, BAND, band["reference_image"], band["reference_casts"], label="config 3")
 
 
 def test_config3_product_kernel_signatures_equal_the_list_oracle(amber, config3):

@@ -16,7 +16,7 @@ import pytest
 
 import oracle_binding as O
 from amber_amd import workloads as WL
-from bvh_parity import bits, check_band
+from bvh_parity import bits, check_band, check_reference_engine
 
 ROOT = Path(__file__).resolve().parent.parent
 
@@ -61,7 +61,8 @@ def test_cornell_through_engine_bvh_band_against_both_oracles(amber, oracle):
     """(i) the engine switch at 33 objects: config 2's frame through ENGINE_BVH, both of its schedulers."""
     hs, osc = amber.HostScene.cornell_box(), O.Scene.cornell(O.ACCEL_BVH_CONS)
     for flags, name in ((0, "Cornell, pt_megakernel<ENGINE_BVH>"), (amber.api.PT_FLAG_BVH_ITEMS, "Cornell, pt_bvh_megakernel")):
-        check_band(amber, hs, osc, 1024, 1024, 12345, 64, (600, 632), max_ref_pixels=8, max_ref_ray_delta=64, engine=amber.ENGINE_BVH, flags=flags, label=name)
+        st = check_band(amber, hs, osc, 1024, 1024, 12345, 64, (600, 632), max_ref_pixels=8, max_ref_ray_delta=64, engine=amber.ENGINE_BVH, flags=flags, label=name)
+    check_reference_engine(amber, hs, 1024, 1024, 12345, 64, (600, 632), st["reference_image"], st["reference_casts"], label="Cornell")
 
 
 @pytest.mark.gpu
@@ -72,6 +73,7 @@ def test_room_mesh_band_against_both_oracles(amber, oracle, tmp_path):
     for flags, name in ((0, "room mesh, engine auto"), (amber.api.PT_FLAG_BVH_ITEMS, "room mesh, pt_bvh_megakernel")):
         st = check_band(amber, hs, osc, 1024, 1024, 7, 64, (640, 672), max_ref_pixels=32, max_ref_ray_delta=256, flags=flags, label=name)
         assert st["lit"] > 0.25
+    check_reference_engine(amber, hs, 1024, 1024, 7, 64, (640, 672), st["reference_image"], st["reference_casts"], label="room mesh")
 
 
 @pytest.mark.gpu
@@ -83,6 +85,7 @@ def test_terrain_band_against_both_oracles(amber, oracle, tmp_path):
     for rows in ((200, 224), (800, 824)):
         st = check_band(amber, hs, osc, 1920, 1080, 3, 32, rows, max_ref_pixels=256, max_ref_ray_delta=2048, label="terrain")
         assert st["lit"] > 0.25
+        check_reference_engine(amber, hs, 1920, 1080, 3, 32, rows, st["reference_image"], st["reference_casts"], label="terrain")
     # the product kernel's paths one by one (hit-object sequence, hit distances): 4 rows at 8 spp
     osc.set_accel(O.ACCEL_BVH_CONS)
     so = osc.path_signatures(1920, 1080, 3, 0, 8, (700, 704), threads=16)
