@@ -3,7 +3,8 @@ the whole frame.
   (i)   GPU == oracle(List semantics through the conservative BVH, live libm): image bits and ray count;
   (ii)  the pixels on which the GPU differs from oracle(REFERENCE BVH) == the pixels on which the oracle's two accelerations differ;
   (iii) every such pixel attributed to a path whose first differing cast is either a hit the reference's BVH loses because the ray misses
-        the sphere's geometric box (its List, like the engine, keeps it) or an exact distance tie.
+        the sphere's geometric box (its List, like the engine, keeps it) or an exact distance tie;
+  (iv)  (round 5) the same frame through AMBER_ENGINE_REFERENCE_BVH == oracle(REFERENCE BVH): image bits and ray count, no pixel left over.
 python tools/config3_full_parity.py [spp] [threads] [config3 | terrain | room_mesh]     (config 3: about two minutes of oracle time on 16 host threads;
 terrain / room_mesh, round 5: the imported-mesh workloads of bench.py at their full frames, read back through cli::ImportScene)"""
 import os, sys, time
@@ -61,5 +62,11 @@ for px, found in list(causes.items())[:12]:
     for c in found:
         print("      pixel (y %4d, x %4d) sample %3d cast %d: List object %7d t %.9g | reference BVH object %7d t %.9g | %s"
               % (px[0], px[1], c["sample"], c["cast"], c["object_list"], c["t_list"], c["object_b"], c["t_b"], c["cause"]))
-ok = int((bits(img) != bits(cons)).any(axis=2).sum()) == 0 and rays == res[O.ACCEL_BVH_CONS][1] and np.array_equal(gpu_vs_ref, cons_vs_ref) and unattributed == 0 and "unexplained" not in tally
-print("RESULT:", "every difference from the reference's BVH is the reference's own List/BVH disagreement" if ok else "NOT fully attributed")
+# (iv) round 5: the same frame through AMBER_ENGINE_REFERENCE_BVH -- the reference's own tree and traversal order -- against oracle(reference BVH)
+t = time.time(); pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=seed, engine=A.ENGINE_REFERENCE_BVH); tc = time.time() - t
+pt.render_pass(0, spp); rimg, rrays = pt.download(); launches, ms = pt.kernel_time(); pt.close()
+rdiff = int((bits(rimg) != bits(refb)).any(axis=2).sum())
+print("(iv) engine REFERENCE_BVH: create %.1f s (the reference's build on the host), %d rays in %.1f ms (%d launches, %.2f Grays/s); pixels differing from oracle(reference BVH): %d of %d; ray count delta %+d"
+      % (tc, rrays, ms, launches, rrays / ms / 1e6, rdiff, W * H, int(rrays) - int(res[O.ACCEL_BVH][1])), flush=True)
+ok = rdiff == 0 and rrays == res[O.ACCEL_BVH][1] and int((bits(img) != bits(cons)).any(axis=2).sum()) == 0 and rays == res[O.ACCEL_BVH_CONS][1] and np.array_equal(gpu_vs_ref, cons_vs_ref) and unattributed == 0 and "unexplained" not in tally
+print("RESULT:", "every difference of the List engines from the reference's BVH is the reference's own List/BVH disagreement; engine REFERENCE_BVH equals the reference's BVH on every pixel" if ok else "NOT fully attributed")
