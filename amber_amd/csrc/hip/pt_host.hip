@@ -233,6 +233,8 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   if (params->engine == AMBER_ENGINE_WAVEFRONT) return Fail(AMBER_EINVAL, "engine WAVEFRONT (the streaming formulation, kept for measurement) is part of the lab build, libamber_hip_lab.so");
   if (params->reserved & AMBER_PT_FLAG_BVH_POOL) return Fail(AMBER_EINVAL, "AMBER_PT_FLAG_BVH_POOL (pt_bvh_pool_kernel, kept for measurement) is part of the lab build, libamber_hip_lab.so");
 #endif
+  if (params->engine == AMBER_ENGINE_REFERENCE_BVH && !amber_refbvh::CentresAreOrdered(s->objects, s->n_objects))
+    return Fail(AMBER_EINVAL, "AMBER_ENGINE_REFERENCE_BVH: an object's centre is NaN (the reference's build sorts objects by centre; std::sort is undefined on NaN keys)");
   if (params->engine == AMBER_ENGINE_TWO_PHASE && s->n_objects > AMBER_MAX_GROUP_OBJECTS)
     return Fail(AMBER_EINVAL, "AMBER_ENGINE_TWO_PHASE supports at most 128 objects");
 

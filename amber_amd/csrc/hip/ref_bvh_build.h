@@ -193,6 +193,16 @@ inline void Measure(const Node* n, uint32_t depth, Tree& t) {
 
 }  // namespace detail
 
+// The build orders objects by their centres with std::sort, whose behaviour is undefined when the comparison is not a strict weak order: a NaN
+// centre.  (The reference has no such check; amber_hip_pt_create refuses the scene for this engine instead of inheriting the undefined behaviour.)
+inline bool CentresAreOrdered(const AmberFlatObject* objects, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) {
+    const Key k = PrimitiveKey(objects[i], i);
+    for (int c = 0; c < 3; c++) if (std::isnan(k.c[c])) return false;
+  }
+  return true;
+}
+
 inline Tree Build(const AmberFlatObject* objects, uint32_t n) {                                         // BVH::BVH, BuildBVH :134-156
   std::vector<Box> boxes(n);
   std::vector<Key> keys(n);

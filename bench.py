@@ -191,6 +191,12 @@ def secondary_workloads(amber_amd, np, seed: int, device: int):
             "work-queue megakernel, engine BVH (16-bit quantised 2-wide tree, resumable LDS-stack traversal)")
     e["host_scene_s"] = round(t_scene, 3)
     out.append(e)
+    # the same frame through the reference's OWN tree and traversal order (AMBER_ENGINE_REFERENCE_BVH): what the reference's command line computes,
+    # bit for bit (the List engines differ from it on 117 of this frame's pixels; profiles/r05_reference_bvh_full_frame.txt); create_s = the reference's build
+    r = run("config 3 through AMBER_ENGINE_REFERENCE_BVH: the reference's own BVH (acceleration_bvh.h:134-403), 1920x1080 @ 256 spp", spheres, 1920, 1080, 256,
+            "path-granular megakernel, per-lane walk of the reference's tree in the reference's order (binary32 boxes, stack in global memory)", engine=amber_amd.ENGINE_REFERENCE_BVH)
+    r["kernel_ms_over_engine_bvh"] = round(r["kernel_ms"] / e["kernel_ms"], 3) if e["kernel_ms"] > 0 else None
+    out.append(r)
     spheres.close()
     cornell = amber_amd.HostScene.cornell_box()
     out.append(run("config 4: Cornell + glass/refractive 2048x2048 @ 4096 spp on 4 GPUs -- rank 0's stripes, one 1024-spp launch of its 4",
@@ -210,6 +216,10 @@ def secondary_workloads(amber_amd, np, seed: int, device: int):
     e = run("mesh (i'): the same through pt_bvh_megakernel (AMBER_PT_FLAG_BVH_ITEMS), the scheduler of deep trees",
             cornell, 1024, 1024, 1024, "item megakernel, resumable per-lane BVH traversal", engine=amber_amd.ENGINE_BVH, flags=amber_amd.api.PT_FLAG_BVH_ITEMS)
     e["kernel_ms_over_two_phase"] = round(e["kernel_ms"] / two["kernel_ms"], 3) if two["kernel_ms"] > 0 else None
+    out.append(e)
+    e = run("Cornell through AMBER_ENGINE_REFERENCE_BVH (the reference's tree of the box: a root and two leaves), config 2's frame at 256 spp",
+            cornell, 1024, 1024, 256, "path-granular megakernel, per-lane walk of the reference's tree in the reference's order", engine=amber_amd.ENGINE_REFERENCE_BVH)
+    e["kernel_ms_over_two_phase_at_equal_spp"] = round(e["kernel_ms"] * 4 / two["kernel_ms"], 3) if two["kernel_ms"] > 0 else None
     out.append(e)
     cornell.close()
     from amber_amd import scenes as _scenes

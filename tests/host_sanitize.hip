@@ -13,6 +13,7 @@
 #include "../amber_amd/csrc/amber/scene.h"
 #include "../amber_amd/csrc/hip/bvh_build.h"
 #include "../amber_amd/csrc/hip/filter_build.h"
+#include "../amber_amd/csrc/hip/ref_bvh_build.h"
 
 using amber_dev::DevObject;
 
@@ -56,6 +57,25 @@ static void CheckBvh(const std::vector<DevObject>& objs, const char* what) {
   std::printf("ok   bvh %-28s objects %zu nodes %zu leaves %zu depth %u\n", what, objs.size(), b.nodes.size(), leaves, b.depth);
 }
 
+// the builder of the reference's own tree (engine REFERENCE_BVH): every object in exactly one leaf, references in range, the flattened image
+// as large as the tree says; degenerate inputs must neither crash nor loop (a node whose candidates all leave one side empty becomes a leaf)
+static void CheckReferenceBvh(const std::vector<AmberFlatObject>& flat, const char* what) {
+  const amber_refbvh::Tree t = amber_refbvh::Build(flat.data(), static_cast<uint32_t>(flat.size()));
+  const amber_refbvh::FlatTree f = amber_refbvh::Flatten(t);
+  std::vector<int> seen(flat.size(), 0);
+  for (const auto& lf : f.leaves)
+    for (uint32_t k = lf.first; k < lf.first + lf.count; k++) {
+      if (k >= t.order.size() || t.order[k] >= flat.size()) { std::printf("FAIL %s: reference tree leaf range\n", what); std::exit(1); }
+      seen[t.order[k]]++;
+    }
+  for (int s : seen) if (s != 1) { std::printf("FAIL %s: reference tree references an object %d times\n", what, s); std::exit(1); }
+  for (const auto& nd : f.nodes)
+    for (int32_t r : {nd.left, nd.right})
+      if (r >= static_cast<int32_t>(f.nodes.size()) || -(r + 1) >= static_cast<int32_t>(f.leaves.size())) { std::printf("FAIL %s: reference tree child\n", what); std::exit(1); }
+  if (f.nodes.size() != t.n_inner || f.leaves.size() != t.n_leaves || t.n_leaves != t.n_inner + 1) { std::printf("FAIL %s: reference tree counts\n", what); std::exit(1); }
+  std::printf("ok   reference bvh %-22s objects %zu inner %u leaves %u (largest %u) depth %u\n", what, flat.size(), t.n_inner, t.n_leaves, t.largest_leaf, t.depth);
+}
+
 int main() {
   using namespace amber;
   // 1. Cornell box: flatten + filter program
@@ -87,6 +107,7 @@ int main() {
     if (!slabs_ok || fp.n_simple_planes != 8) { std::printf("FAIL filter program: slabs (%u leading planes)\n", fp.n_simple_planes); return 1; }
     std::printf("ok   filter program: 9 planes (4 slabs first), 22 triangles in 11 pair records, 3 spheres\n");
     CheckBvh(objs, "cornell");
+    CheckReferenceBvh(fs.objects, "cornell");
   }
   // 2. degenerate inputs: pinhole (zero-area triangle), one object, coincident centres, extreme coordinates
   {
@@ -106,6 +127,7 @@ int main() {
     if (fp.always_mask != 0x7u || !fp.planes.empty()) { std::printf("FAIL degenerate filter program always=%x\n", fp.always_mask); return 1; }
     std::printf("ok   degenerate scene: every object is an always-candidate\n");
     CheckBvh(objs, "pinhole+disk+cylinder");
+    CheckReferenceBvh(fs.objects, "pinhole+disk+cylinder");
   }
   {
     std::vector<DevObject> one(1); std::memset(&one[0], 0, sizeof(DevObject)); one[0].kind = 1; one[0].radius = 1;
@@ -122,6 +144,21 @@ int main() {
     std::vector<DevObject> objs(200000);
     for (auto& o : objs) { std::memset(&o, 0, sizeof o); o.kind = 1; o.a[0] = u(rng); o.a[1] = u(rng); o.a[2] = u(rng); o.radius = 0.004f; }
     CheckBvh(objs, "200k random spheres");
+    // the reference's tree of degenerate inputs: one object, a thousand coincident spheres (no plane separates them: one leaf), coordinates at the
+    // edge of binary32 (surface areas overflow to inf, costs to NaN: a leaf), NaN centres (refused: std::sort on them is undefined), and 200k random spheres
+    auto flat_sphere = [](float x, float y, float z, float r) { AmberFlatObject o{}; o.kind = AMBER_PRIM_SPHERE; o.p[0] = x; o.p[1] = y; o.p[2] = z; o.p[3] = r; return o; };
+    CheckReferenceBvh(std::vector<AmberFlatObject>(1, flat_sphere(0, 0, 0, 1)), "single sphere");
+    CheckReferenceBvh(std::vector<AmberFlatObject>(1000, flat_sphere(1, 2, 3, 0.5f)), "1000 coincident spheres");
+    std::vector<AmberFlatObject> fl;
+    fl.push_back(flat_sphere(-3e38f, 0, 0, 1e30f)); fl.push_back(flat_sphere(3e38f, 0, 0, 1e30f)); fl.push_back(flat_sphere(0, 0, 0, 1e-30f));
+    CheckReferenceBvh(fl, "extreme coordinates");
+    fl.clear();
+    for (int i = 0; i < 64; i++) fl.push_back(flat_sphere(i % 3 == 0 ? std::nanf("") : float(i), float(i % 7), i % 5 == 0 ? std::nanf("") : 1.0f, 0.25f));
+    if (amber_refbvh::CentresAreOrdered(fl.data(), static_cast<uint32_t>(fl.size())) || !amber_refbvh::CentresAreOrdered(fl.data() + 1, 1u)) { std::printf("FAIL NaN centres not detected\n"); return 1; }
+    std::printf("ok   reference bvh: NaN centres are refused (std::sort on them is undefined)\n");
+    fl.clear();
+    for (int i = 0; i < 200000; i++) fl.push_back(flat_sphere(u(rng), u(rng), u(rng), 0.005f));
+    CheckReferenceBvh(fl, "200k random spheres");
   }
   // 3b. round 5: filter programs of SUBSETS (the two-phase engine's groups of 32), triangle-leaf references, SAH figures
   {

@@ -99,3 +99,9 @@ def test_a_scene_the_reference_keeps_in_one_leaf_and_the_engine_id_gap(amber):
     assert rays == cnt.casts and np.array_equal(bits(img), bits(oimg)) and img.sum() > 0
     with pytest.raises(Exception):
         amber.PathTracer(hs, amber.Sensor.default(64, 64), seed=1, engine=5)
+    # a NaN centre: the reference's build would hand std::sort an order that is none (undefined behaviour); this engine refuses the scene, the others render it
+    sc["objects"] = sc["objects"] + [(1, 0, (float("nan"), 0.0, 0.0, 0.1))]
+    hs = amber.HostScene.create(**sc)
+    with pytest.raises(Exception, match="NaN"):
+        amber.PathTracer(hs, amber.Sensor.default(64, 64), seed=1, engine=amber.ENGINE_REFERENCE_BVH)
+    amber.PathTracer(hs, amber.Sensor.default(64, 64), seed=1).close()
