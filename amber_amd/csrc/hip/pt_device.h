@@ -1348,10 +1348,26 @@ __device__ __forceinline__ void ClosestHitReferenceBvh(const DevScene& sc, V3 o,
       if (lh) { cur = left; continue; }
       if (rh) { cur = right; continue; }
     } else {
+      // (best.idx holds the leaf-order slot until the end: strict < needs no index, and the scene index is one load for the winner)
       const DevRefLeaf lf = sc.ref_leaves[-(cur + 1)];
-      for (uint32_t k = lf.first; k < lf.first + lf.count; ++k) {
-        const DevObject& ob = sc.bvh_objects[k];
-        IntersectObject<false>(ob, ob.kind, static_cast<int>(sc.bvh_prims[k]), static_cast<int>(k), o, d, best);
+      const uint32_t last = lf.first + (lf.count & 0x3fffffffu);
+      if (lf.count & 0x80000000u) {                      // spheres only: the 16-byte records of engine BVH's sphere leaves, same operands
+        for (uint32_t k = lf.first; k < last; ++k) {
+          const float4 sp4 = sc.bvh_spheres[k];
+          IntersectSphere<false>(v3(sp4.x, sp4.y, sp4.z), sp4.w, static_cast<int>(k), static_cast<int>(k), o, d, best);
+        }
+      } else if (lf.count & 0x40000000u) {               // triangles only: {A.xyz E1.x} {E1.yz E2.xy} {E2.z ..}
+        for (uint32_t k = lf.first; k < last; ++k) {
+          // (a conservative rejection on v_rcp_f32 quotients in front of the divisions, as in engine BVH's leaves, was measured neutral here:
+          //  terrain 44.1 -> 44.8 ms, room 26.7 -> 27.8 -- this walk is bound by its node visits, EXPERIMENTS.md round 5)
+          const float4 t0 = sc.bvh_tris[3u * k], t1 = sc.bvh_tris[3u * k + 1u], t2 = sc.bvh_tris[3u * k + 2u];
+          IntersectTriangle<false>(v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y), v3(t1.z, t1.w, t2.x), static_cast<int>(k), static_cast<int>(k), o, d, best);
+        }
+      } else {
+        for (uint32_t k = lf.first; k < last; ++k) {
+          const DevObject& ob = sc.bvh_objects[k];
+          IntersectObject<false>(ob, ob.kind, static_cast<int>(k), static_cast<int>(k), o, d, best);
+        }
       }
     }
     bool more = false;
@@ -1360,8 +1376,9 @@ __device__ __forceinline__ void ClosestHitReferenceBvh(const DevScene& sc, V3 o,
       const uint2 e = stack[static_cast<size_t>(sp) * stride];
       if (!(best.t < __uint_as_float(e.y))) { cur = static_cast<int32_t>(e.x); more = true; break; }
     }
-    if (!more) return;
+    if (!more) break;
   }
+  if (best.slot >= 0) best.idx = static_cast<int>(sc.bvh_prims[best.slot]);
 }
 
 enum { ENGINE_LIST = 1, ENGINE_TWO_PHASE = 2, ENGINE_BVH = 3, ENGINE_TWO_PHASE_N = 5, ENGINE_REF_BVH = 6 };   // (4 is the public WAVEFRONT; 5 = two-phase over groups of 32 objects)

@@ -225,14 +225,23 @@ struct FlatTree {
   int32_t root = 0;                              // >= 0: nodes[root]; < 0: leaves[-(root + 1)] (a scene the reference keeps in one leaf)
 };
 
-inline int32_t Flatten(const Node* n, FlatTree& out) {
+// A leaf whose objects are all spheres (all triangles) says so in the two top bits of its count: the device then scans the 16-byte sphere
+// (48-byte triangle) records of engine BVH's leaf arrays instead of the 64-byte object records -- the same operands, the same order.
+constexpr uint32_t kLeafAllSpheres = 0x80000000u, kLeafAllTriangles = 0x40000000u, kLeafCountMask = 0x3fffffffu;
+
+inline int32_t Flatten(const Node* n, const Tree& t, const AmberFlatObject* objects, FlatTree& out) {
   if (!n->left) {
-    out.leaves.push_back(FlatLeaf{n->first, n->count});
+    bool spheres = true, triangles = true;
+    for (uint32_t k = n->first; k < n->first + n->count; k++) {
+      spheres = spheres && objects[t.order[k]].kind == AMBER_PRIM_SPHERE;
+      triangles = triangles && objects[t.order[k]].kind == AMBER_PRIM_TRIANGLE;
+    }
+    out.leaves.push_back(FlatLeaf{n->first, n->count | (spheres ? kLeafAllSpheres : 0u) | (triangles ? kLeafAllTriangles : 0u)});
     return -static_cast<int32_t>(out.leaves.size());
   }
   const size_t at = out.nodes.size();
   out.nodes.emplace_back();
-  const int32_t l = Flatten(n->left.get(), out), r = Flatten(n->right.get(), out);
+  const int32_t l = Flatten(n->left.get(), t, objects, out), r = Flatten(n->right.get(), t, objects, out);
   FlatNode& f = out.nodes[at];
   for (int c = 0; c < 3; c++) {
     f.lmin[c] = n->left->bb.mn[c]; f.lmax[c] = n->left->bb.mx[c];
@@ -241,10 +250,10 @@ inline int32_t Flatten(const Node* n, FlatTree& out) {
   f.left = l; f.right = r; f.pad[0] = f.pad[1] = 0;
   return static_cast<int32_t>(at);
 }
-inline FlatTree Flatten(const Tree& t) {
+inline FlatTree Flatten(const Tree& t, const AmberFlatObject* objects) {
   FlatTree out;
   out.nodes.reserve(t.n_inner); out.leaves.reserve(t.n_leaves);
-  out.root = Flatten(t.root.get(), out);
+  out.root = Flatten(t.root.get(), t, objects, out);
   return out;
 }
 

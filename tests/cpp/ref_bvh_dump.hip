@@ -34,10 +34,10 @@ int main(int argc, char** argv) {
     else { stack.push_back(n->right.get()); stack.push_back(n->left.get()); }
   }
   // the flattened image the device walks: every reference in range, every object in exactly one leaf
-  const amber_refbvh::FlatTree flat = amber_refbvh::Flatten(tree);
+  const amber_refbvh::FlatTree flat = amber_refbvh::Flatten(tree, objects.data());
   std::vector<int> seen(objects.size(), 0);
   for (const auto& lf : flat.leaves)
-    for (uint32_t k = lf.first; k < lf.first + lf.count; k++) { if (k >= objects.size()) { std::fprintf(stderr, "leaf range\n"); return 1; } seen[tree.order[k]]++; }
+    for (uint32_t k = lf.first; k < lf.first + (lf.count & amber_refbvh::kLeafCountMask); k++) { if (k >= objects.size()) { std::fprintf(stderr, "leaf range\n"); return 1; } seen[tree.order[k]]++; }
   for (int s : seen) if (s != 1) { std::fprintf(stderr, "an object sits in %d leaves\n", s); return 1; }
   for (const auto& nd : flat.nodes)
     for (int32_t r : {nd.left, nd.right})

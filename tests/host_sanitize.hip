@@ -61,10 +61,10 @@ static void CheckBvh(const std::vector<DevObject>& objs, const char* what) {
 // as large as the tree says; degenerate inputs must neither crash nor loop (a node whose candidates all leave one side empty becomes a leaf)
 static void CheckReferenceBvh(const std::vector<AmberFlatObject>& flat, const char* what) {
   const amber_refbvh::Tree t = amber_refbvh::Build(flat.data(), static_cast<uint32_t>(flat.size()));
-  const amber_refbvh::FlatTree f = amber_refbvh::Flatten(t);
+  const amber_refbvh::FlatTree f = amber_refbvh::Flatten(t, flat.data());
   std::vector<int> seen(flat.size(), 0);
   for (const auto& lf : f.leaves)
-    for (uint32_t k = lf.first; k < lf.first + lf.count; k++) {
+    for (uint32_t k = lf.first; k < lf.first + (lf.count & amber_refbvh::kLeafCountMask); k++) {
       if (k >= t.order.size() || t.order[k] >= flat.size()) { std::printf("FAIL %s: reference tree leaf range\n", what); std::exit(1); }
       seen[t.order[k]]++;
     }
