@@ -6,10 +6,11 @@ import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
 import amber_amd as A
-n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-n_obj = int(sys.argv[2]) if len(sys.argv) > 2 else 80000
-p_sphere = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0 / 6.0
-p_tri = float(sys.argv[4]) if len(sys.argv) > 4 else None
+_nums = [a for a in sys.argv[1:] if not a.startswith('--')]
+n_scenes = int(_nums[0]) if len(_nums) > 0 else 4
+n_obj = int(_nums[1]) if len(_nums) > 1 else 80000
+p_sphere = float(_nums[2]) if len(_nums) > 2 else 1.0 / 6.0
+p_tri = float(_nums[3]) if len(_nums) > 3 else None
 W, H, spp = 64, 48, 4
 for seed in range(n_scenes):
     rng = np.random.default_rng(1000 + seed)
@@ -42,6 +43,17 @@ for seed in range(n_scenes):
         t = time.time(); pt.render_pass(0, spp); img, rays = pt.download(); tr = time.time() - t; pt.close()
         res[e] = (img.view(np.uint32).copy(), rays)
         print("seed %d engine %d: create %.2f s, render %.2f s, rays %d" % (seed, e, tc, tr, rays), flush=True)
+    if "--reference-bvh" in sys.argv:              # engine REFERENCE_BVH against oracle(ACCEL_BVH): the reference's tree of the same soup on both sides
+        sys.path.insert(0, os.path.join(R, "tests"))
+        import oracle_binding as O
+        t = time.time(); pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=seed, engine=A.ENGINE_REFERENCE_BVH); tc = time.time() - t
+        pt.render_pass(0, spp); rimg, rrays = pt.download(); pt.close()
+        osc = O.Scene.create_arrays(kinds=kinds, material_index=material, params=params, materials=mats, transform=[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 4, 0, 0, 0, 1],
+                                    focal_length=0.05, focus_distance=4.0, radius=0.02, n_blades=6, accel=O.ACCEL_BVH)
+        oimg, cnt = osc.render_xorshift(W, H, seed, 0, spp)
+        print("seed %d engine REFERENCE_BVH: create %.2f s, rays %d (oracle(BVH) %d), tree %s, differs from List on %d values" % (seed, tc, rrays, cnt.casts, osc.bvh_stats(), int((rimg.view(np.uint32) != res[A.ENGINE_LIST][0]).sum())), flush=True)
+        if rrays != cnt.casts or not np.array_equal(rimg.view(np.uint32), oimg.view(np.uint32)):
+            print("REFERENCE-BVH MISMATCH seed", seed); sys.exit(1)
     if res[A.ENGINE_BVH][1] != res[A.ENGINE_LIST][1] or not np.array_equal(res[A.ENGINE_BVH][0], res[A.ENGINE_LIST][0]):
         print("MISMATCH seed", seed); sys.exit(1)
 print("big fuzz ok: %d scenes of %d objects" % (n_scenes, n_obj))

@@ -16,9 +16,11 @@ scaled = "--scaled" in sys.argv      # similarity transform: scale 10^U(-2,3), o
 use_stripes = "--stripes" in sys.argv # also render the image as three interleaved stripe sets (one process per GPU does this)
 extreme = "--extreme" in sys.argv    # disk normals scaled by 10^U(-2,2): direction lengths from 0.01 to 100
 use_lt = "--lt" in sys.argv           # also compare light tracing (splat records) between the work-queue engines
-if use_oracle:
+use_ref = "--reference-bvh" in sys.argv   # also render through AMBER_ENGINE_REFERENCE_BVH and compare with oracle(ACCEL_BVH): image bits, ray count (every scene)
+if use_oracle or use_ref:
     sys.path.insert(0, os.path.join(R, "tests"))
     import oracle_binding as O
+n_ref_differs = 0
 
 
 sys.path.insert(0, os.path.join(R, "tests"))
@@ -79,8 +81,27 @@ for seed in range(first_seed, first_seed + n_scenes):
         if cnt.casts != ref[1] or not np.array_equal(oimg.view(np.uint32), ref[0]):
             print("ORACLE MISMATCH seed %d: rays %d vs %d" % (seed, cnt.casts, ref[1]), flush=True)
             sys.exit(1)
+    if use_ref:
+        pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=seed, engine=A.ENGINE_REFERENCE_BVH)
+        pt.render_pass(0, spp)
+        rimg, rrays = pt.download(); pt.close()
+        obvh = O.Scene.create(**sc, accel=O.ACCEL_BVH)
+        oimg, cnt = obvh.render_xorshift(W, H, seed, 0, spp)
+        if cnt.casts != rrays or not np.array_equal(oimg.view(np.uint32), rimg.view(np.uint32)):
+            print("REFERENCE-BVH MISMATCH seed %d: rays %d vs oracle(BVH) %d, %d differing values" % (seed, rrays, cnt.casts, int((oimg.view(np.uint32) != rimg.view(np.uint32)).sum())), flush=True)
+            sys.exit(1)
+        n_ref_differs += int(not np.array_equal(rimg.view(np.uint32), ref[0]))
+        if use_lt:
+            pt = A.PathTracer(hs, A.Sensor.default(W, H), seed=seed, engine=A.ENGINE_REFERENCE_BVH, max_depth=lt_depth)
+            rec, lrays = pt.lt_trace(0, 3, capacity=1 << 14); pt.close()
+            _, lcnt, orec = obvh.render_lt(W, H, seed, 0, 3, max_depth=lt_depth)
+            got = np.stack([rec["path"], rec["sample"], rec["bounce"], rec["pixel"], *[rec["rgb"][:, c].view(np.uint32) for c in range(3)]], 1) if len(rec) else np.zeros((0, 7), np.uint32)
+            if lrays != lcnt.casts or not np.array_equal(got, orec):
+                print("REFERENCE-BVH LT MISMATCH seed %d: rays %d vs %d, %d vs %d records" % (seed, lrays, lcnt.casts, len(rec), len(orec)), flush=True)
+                sys.exit(1)
     if time.time() - t_scene > 5.0:
         print("seed %d slow: %.1f s (%d objects)" % (seed, time.time() - t_scene, n_obj), flush=True)
     if (seed - first_seed) % 25 == 24:
         print("seed %d ok (%d objects, %.2f rays/path) %.0f s" % (seed, n_obj, ref[1] / (W * H * spp), time.time() - t0), flush=True)
 print("fuzz ok: %d scenes, engines agree bit for bit%s" % (n_scenes, " (and with the oracle on every 8th small scene)" if use_oracle else ""))
+if use_ref: print("engine REFERENCE_BVH == oracle(reference BVH) on all %d scenes; the List engines differ from it on %d of them" % (n_scenes, n_ref_differs))
