@@ -340,6 +340,7 @@ int amber_hip_pt_create(const AmberFlatScene* s, const AmberSensor* sensor, cons
   uint32_t ref_depth = 0;
   if (h->hit_engine == AMBER_ENGINE_REFERENCE_BVH) {
     const amber_refbvh::Tree tree = amber_refbvh::Build(s->objects, s->n_objects);
+    if (tree.too_deep) { amber_hip_pt_destroy(h); return Fail(AMBER_EINVAL, "AMBER_ENGINE_REFERENCE_BVH: the reference's recursive build goes deeper than " + std::to_string(amber_refbvh::kMaxDepth) + " levels on this scene"); }
     ref_tree = amber_refbvh::Flatten(tree, s->objects);
     ref_depth = tree.depth;
     bvh.prim_index = tree.order;                               // the object arrays of engine BVH, in the reference's order

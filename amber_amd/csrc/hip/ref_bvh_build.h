@@ -28,6 +28,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -104,7 +105,10 @@ struct Node {                                    // BVH::Node, acceleration_bvh.
   Box bb;
 };
 
+constexpr uint32_t kMaxDepth = 2048;             // levels this build follows the reference's recursion (config 3: 21, the 1M-triangle terrain: 24)
+
 struct Tree {
+  bool too_deep = false;                         // the reference's recursion goes beyond kMaxDepth levels on this scene: no tree (root is not the reference's)
   std::unique_ptr<Node> root;
   std::vector<uint32_t> order;                   // objects_ after the build: position -> scene index
   uint32_t n_inner = 0, n_leaves = 0, depth = 0; // depth: edges on the longest root-to-leaf walk
@@ -161,12 +165,16 @@ inline Split FindSplit(const std::vector<Box>& boxes, It first, It last, const B
 struct Builder {
   const std::vector<Box>& boxes;
   It begin;
+  std::atomic<bool>* too_deep;
 
   std::unique_ptr<Node> Create(It first, It last, const Box& bb, uint32_t depth) const {                // :158-180
     const Split split = FindSplit(boxes, first, last, bb);
     auto node = std::make_unique<Node>();
     node->bb = bb;
-    if (split.cost > std::distance(first, last) * 1.0f) {
+    // The reference recurses as deep as its splits lead it (objects spaced geometrically along a line peel off a few per level) and would
+    // overflow its call stack; this build stops at kMaxDepth levels and reports the scene as refused (Tree::too_deep) rather than guess a tree.
+    if (depth >= kMaxDepth && !(split.cost > std::distance(first, last) * 1.0f)) too_deep->store(true);
+    if (split.cost > std::distance(first, last) * 1.0f || depth >= kMaxDepth) {
       node->first = static_cast<uint32_t>(first - begin);
       node->count = static_cast<uint32_t>(last - first);
     } else if (depth < 4 && std::distance(first, last) > 20000) {
@@ -207,12 +215,14 @@ inline Tree Build(const AmberFlatObject* objects, uint32_t n) {                 
   std::vector<Box> boxes(n);
   std::vector<Key> keys(n);
   for (uint32_t i = 0; i < n; i++) { boxes[i] = PrimitiveBox(objects[i]); keys[i] = PrimitiveKey(objects[i], i); }
-  const detail::Builder b{boxes, keys.begin()};
+  std::atomic<bool> too_deep{false};
+  const detail::Builder b{boxes, keys.begin(), &too_deep};
   Tree t;
   t.root = b.Create(keys.begin(), keys.end(), detail::RangeBox(boxes, keys.begin(), keys.end()), 0);
   t.order.resize(n);
   for (uint32_t i = 0; i < n; i++) t.order[i] = keys[i].index;
   detail::Measure(t.root.get(), 0, t);
+  t.too_deep = too_deep.load();
   return t;
 }
 

@@ -156,6 +156,15 @@ int main() {
     for (int i = 0; i < 64; i++) fl.push_back(flat_sphere(i % 3 == 0 ? std::nanf("") : float(i), float(i % 7), i % 5 == 0 ? std::nanf("") : 1.0f, 0.25f));
     if (amber_refbvh::CentresAreOrdered(fl.data(), static_cast<uint32_t>(fl.size())) || !amber_refbvh::CentresAreOrdered(fl.data() + 1, 1u)) { std::printf("FAIL NaN centres not detected\n"); return 1; }
     std::printf("ok   reference bvh: NaN centres are refused (std::sort on them is undefined)\n");
+    // centres spaced geometrically along a line (120 octaves): the candidate planes are spaced evenly over the box, so a split peels off the few
+    // objects of the top octaves.  The SAH stops it early here (depth 13); the guard behind it (kMaxDepth, Tree::too_deep) must stay silent
+    fl.clear();
+    for (int i = 0; i < 9000; i++) fl.push_back(flat_sphere(std::ldexp(1.0f, -(i % 120)) * (1.0f + 1e-3f * float(i / 120)), 0, 0, 1e-38f));
+    {
+      const amber_refbvh::Tree deep = amber_refbvh::Build(fl.data(), static_cast<uint32_t>(fl.size()));
+      std::printf("ok   reference bvh of 9000 geometrically spaced spheres: depth %u, too_deep %d\n", deep.depth, int(deep.too_deep));
+      if (deep.depth > amber_refbvh::kMaxDepth || deep.too_deep) { std::printf("FAIL depth guard\n"); return 1; }
+    }
     fl.clear();
     for (int i = 0; i < 200000; i++) fl.push_back(flat_sphere(u(rng), u(rng), u(rng), 0.005f));
     CheckReferenceBvh(fl, "200k random spheres");
