@@ -1326,6 +1326,10 @@ __device__ __forceinline__ void ClosestHitReferenceBvh(const DevScene& sc, V3 o,
   uint2* const stack = sc.ref_stack + (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x);
   const size_t stride = sc.ref_stack_stride;
   int sp = 0;
+  // The newest entry stays in registers (top_ref / top_in; top_ref == kNone: none): a pop right after a push -- the common case, a leaf or a miss
+  // below the node that pushed -- costs no memory round trip; an entry reaches the global stack only when a second one is pushed on top of it.
+  constexpr uint32_t kNone = 0x7fffffffu;
+  uint32_t top_ref = kNone; float top_in = 0.0f;
   int32_t cur = sc.bvh_root;                             // the root is cast without a test of its own box (:152-156)
   for (;;) {
     if (cur >= 0) {
@@ -1340,8 +1344,8 @@ __device__ __forceinline__ void ClosestHitReferenceBvh(const DevScene& sc, V3 o,
       if (lh && rh) {
         const bool left_near = lin < rin;
         const uint32_t far_ = static_cast<uint32_t>(left_near ? right : left);
-        stack[static_cast<size_t>(sp) * stride] = make_uint2(far_, __float_as_uint(left_near ? rin : lin));   // std::max(left_in, right_in)
-        ++sp;
+        if (top_ref != kNone) { stack[static_cast<size_t>(sp) * stride] = make_uint2(top_ref, __float_as_uint(top_in)); ++sp; }
+        top_ref = far_; top_in = left_near ? rin : lin;                                                        // std::max(left_in, right_in)
         cur = left_near ? left : right;
         continue;
       }
@@ -1371,10 +1375,12 @@ __device__ __forceinline__ void ClosestHitReferenceBvh(const DevScene& sc, V3 o,
       }
     }
     bool more = false;
-    while (sp > 0) {
-      --sp;
-      const uint2 e = stack[static_cast<size_t>(sp) * stride];
-      if (!(best.t < __uint_as_float(e.y))) { cur = static_cast<int32_t>(e.x); more = true; break; }
+    for (;;) {
+      uint32_t ref; float fin;
+      if (top_ref != kNone) { ref = top_ref; fin = top_in; top_ref = kNone; }
+      else if (sp > 0) { --sp; const uint2 e = stack[static_cast<size_t>(sp) * stride]; ref = e.x; fin = __uint_as_float(e.y); }
+      else break;
+      if (!(best.t < fin)) { cur = static_cast<int32_t>(ref); more = true; break; }
     }
     if (!more) break;
   }
