@@ -81,3 +81,30 @@ def test_mid_size_scenes(driver, tmp_path):
     mesh = workloads.room_mesh(3)
     kw = mesh.arrays()
     check(driver, tmp_path, A.HostScene.create_arrays(**kw), O.Scene.create_arrays(**kw, accel=O.ACCEL_BVH), "room mesh")
+
+
+def test_trees_equal_the_committed_records(driver, tmp_path):
+    """tests/golden/reference_bvh_trees.json (tools/make_reference_bvh_golden.py): the oracle today and the product's builder both reproduce the
+    recorded trees -- counts, depth, object order, digest -- so a different std::sort (order of equal centres) or a changed restatement is named."""
+    import json
+
+    def fnv(a):
+        h = 14695981039346656037
+        for b in np.ascontiguousarray(a).view(np.uint8).tolist():
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    golden = {t["scene"]: t for t in json.loads((ROOT / "tests" / "golden" / "reference_bvh_trees.json").read_text())["trees"]}
+    cases = [("cornell", A.HostScene.cornell_box(), O.Scene.cornell(O.ACCEL_BVH))]
+    for seed in (3, 7, 500, 501, 502, 503):
+        sc, _ = scene_for_seed(seed)
+        cases.append(("fuzz_scenes.scene_for_seed(%d)" % seed, A.HostScene.create(**sc), O.Scene.create(**sc, accel=O.ACCEL_BVH)))
+    kw = scenes.random_spheres(30000)
+    cases.append(("scenes.random_spheres(30000)", A.HostScene.create_arrays(**kw), O.Scene.create_arrays(**kw, accel=O.ACCEL_BVH)))
+    assert {c[0] for c in cases} == set(golden)
+    for name, hs, osc in cases:
+        g = golden[name]
+        nodes, leaves, depth = osc.bvh_stats()
+        assert (nodes, leaves, depth, str(fnv(osc.bvh_order())), str(osc.bvh_digest())) == (g["nodes"], g["leaves"], g["depth"], g["order_fnv1a64"], g["digest"]), name
+        stats, order = product_tree(driver, hs, tmp_path)
+        assert (stats["nodes"], stats["leaves"], stats["depth"], str(fnv(order)), str(stats["digest"])) == (g["nodes"], g["leaves"], g["depth"], g["order_fnv1a64"], g["digest"]), name
