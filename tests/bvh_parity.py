@@ -1,6 +1,7 @@
 """Shared by the GPU parity tests of engine BVH (config 3, the imported-mesh workloads, Cornell through ENGINE_BVH).
 
-Every engine implements the reference's List acceleration (/root/reference/include/amber/raytracer/acceleration_list.h:51-68).  The
+Every engine that AUTO can choose implements the reference's List acceleration (/root/reference/include/amber/raytracer/acceleration_list.h:51-68)
+(AMBER_ENGINE_REFERENCE_BVH implements the reference's BVH: check_reference_engine below).  The
 reference's BVH (acceleration_bvh.h:340-403) is a different function of the ray wherever a primitive test accepts a hit outside the
 primitive's geometric box (binary32 sphere discriminants, barycentrics of needle triangles) or two objects tie exactly.  So a band is
 checked in three steps:
