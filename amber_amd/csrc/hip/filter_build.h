@@ -1,5 +1,5 @@
 // filter_build.h -- host-side construction of the Phase-A filter program of the two-phase closest hit
-// (device side: ClosestHitTwoPhase in pt_device.h).
+// (device side: ClosestHitTwoPhase in dev_two_phase.h).
 #pragma once
 
 #include <algorithm>

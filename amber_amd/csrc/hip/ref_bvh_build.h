@@ -6,7 +6,7 @@
 // of the far child's box although an object of the far child reaches out of that box by a rounding error
 // (acceleration_bvh.h:386-391).  On the 1M-sphere scene that is 117 of 2 073 600 pixels.  A user who needs the command line's
 // image bit for bit asks for AMBER_ENGINE_REFERENCE_BVH: this file builds the tree acceleration_bvh.h:134-312 builds -- same
-// topology, same boxes, same object order inside the leaves -- and ClosestHitReferenceBvh (pt_device.h) walks it in the order
+// topology, same boxes, same object order inside the leaves -- and ClosestHitReferenceBvh (dev_closest_hit.h) walks it in the order
 // acceleration_bvh.h:340-403 does.
 //
 // What has to be reproduced, and how:

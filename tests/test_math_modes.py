@@ -1,5 +1,5 @@
 """The oracle's GLIBC mode -- the restatement of glibc 2.35's binary32 sincosf / powf that the gfx950 engine executes
-(oracle/amber_oracle.cc "GLIBC mode", amber_amd/csrc/hip/pt_device.h "sin / cos / pow") -- against the LIVE libm of this
+(oracle/amber_oracle.cc "GLIBC mode", amber_amd/csrc/hip/dev_math.h "sin / cos / pow") -- against the LIVE libm of this
 host, which is what the reference calls (sampling.h:249-250, 279, 283-284).
 
 libm is a third-party dependency of the reference (glibc 2.35, pinned by the image): its algorithm is restated, and

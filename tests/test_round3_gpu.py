@@ -367,7 +367,7 @@ def test_rays_almost_parallel_to_an_axis_stay_cheap_and_exact(amber):
     """Round 3 found engine BVH's slab slack shared by the three axes: a ray with |d.y| = 4e-7 (the middle rows of a frame) or a zero
     component switched off the culling of the other axes and walked every box of the sheet it lies in -- 40 000 nodes, 8 000 wave rounds on
     the 1M-sphere scene against a median of 10.  The slack is per axis now and a parallel axis stays in the test with a clamped 1/d
-    (pt_device.h BvhOperands).  Closest hits must equal the List scan's bit for bit, and no ray may be in flight for more than 100 rounds."""
+    (dev_bvh.h BvhOperands).  Closest hits must equal the List scan's bit for bit, and no ray may be in flight for more than 100 rounds."""
     from amber_amd import scenes
     kw = scenes.random_spheres(200_000, 7)
     hs = amber.HostScene.create_arrays(**kw)
