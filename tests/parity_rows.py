@@ -15,7 +15,9 @@ For every band of rows:
     distance identical but a different object index somewhere: an exact distance tie between two objects (a ray through
     the shared edge of two triangles), which the reference's BVH and its List acceleration resolve differently
     (acceleration_bvh.h:340-403 keeps the first-visited leaf's hit, acceleration_list.h:51-68 the lower index; the
-    engine implements List -- SURVEY.md Appendix C lists exact ties as a permitted difference).
+    engine implements List -- SURVEY.md Appendix C lists exact ties as a permitted difference);
+  * `engine_reference_bvh`: the same rows through AMBER_ENGINE_REFERENCE_BVH, which walks the reference's own tree in the reference's order:
+    differing pixels, ray-count difference and differing path signatures against the same oracle -- all zero, ties included.
 """
 from __future__ import annotations
 
@@ -48,6 +50,8 @@ def compare_rows(amber, width: int = 1024, spp: int = 1024, seed: int = 12345, b
                against=f"oracle(XorShift, {'BVH' if accel == O.ACCEL_BVH else 'List'}, "
                        f"{ {O.MATH_LIBM: 'live libm', O.MATH_GLIBC: 'glibc restatement', O.MATH_PORTABLE: 'portable'}[math] })",
                bands=[list(b) for b in bands], tolerance=tol)
+    # the same rows through AMBER_ENGINE_REFERENCE_BVH (the reference's own tree and traversal order): against the same oracle nothing may be left over
+    ref_engine = dict(pixels_differing=0, cast_delta=0, paths_differing=0 if signatures else None) if accel == O.ACCEL_BVH else None
     for y0, y1 in bands:
         pt = amber.PathTracer(hs, sensor, seed=seed, rows=(y0, y1))
         pt.render_pass(0, spp)
@@ -78,7 +82,18 @@ def compare_rows(amber, width: int = 1024, spp: int = 1024, seed: int = 12345, b
             out["inexact_paths"] += int(((lo_g == lo_o) & (hi_g != hi_o)).sum())
             out["tie_paths"] += int(((lo_g != lo_o) & (hi_g == hi_o)).sum())
         pt.close()
+        if ref_engine is not None:
+            pr = amber.PathTracer(hs, sensor, seed=seed, rows=(y0, y1), engine=amber.ENGINE_REFERENCE_BVH)
+            pr.render_pass(0, spp)
+            gr, rr = pr.download()
+            ref_engine["pixels_differing"] += int((gr.view(np.uint32) != o.view(np.uint32)).any(axis=2).sum())
+            ref_engine["cast_delta"] += int(rr) - int(cnt.casts)
+            if signatures:
+                ref_engine["paths_differing"] += int((pr.render_signatures(0, spp) != so).sum())
+            pr.close()
     out["cast_delta"] = out["rays_gpu"] - out["rays_oracle"]
+    if ref_engine is not None:
+        out["engine_reference_bvh"] = ref_engine
     return out
 
 

@@ -24,6 +24,8 @@ def test_config2_rows_all_samples_bit_exact_against_live_libm(amber):
     assert r["diverged_paths"] == 0 and r["inexact_paths"] == 0, r
     assert r["pixels_differing"] == 0 and r["pixels_over_tol"] == 0, r
     assert r["tie_paths"] <= 8, r          # exact distance ties, BVH vs List order (2 of 16.7 M paths measured)
+    # ... and through the reference's own tree in the reference's order the ties go the reference's way: no path differs
+    assert r["engine_reference_bvh"] == dict(pixels_differing=0, cast_delta=0, paths_differing=0), r
     # the same rows against the reference's List acceleration, whose tie rule the engine implements: nothing differs at all
     r = compare_rows(amber, 1024, 1024, 12345, DEFAULT_BANDS[:2], threads=16, math=O.MATH_LIBM, accel=O.ACCEL_LIST)
     assert (r["cast_delta"], r["diverged_paths"], r["inexact_paths"], r["tie_paths"], r["pixels_differing"]) == (0, 0, 0, 0, 0), r
@@ -37,6 +39,7 @@ def test_smaller_frame_whole_image_against_live_libm(amber):
     assert r["rays_oracle"] == 8783686                       # the cast count VERDICT.md quotes for libm mode
     assert r["cast_delta"] == 0 and r["diverged_paths"] == 0 and r["inexact_paths"] == 0 and r["pixels_differing"] == 0, r
     assert r["tie_paths"] <= 2, r
+    assert r["engine_reference_bvh"] == dict(pixels_differing=0, cast_delta=0, paths_differing=0), r
 
 
 def test_portable_build_distance_from_libm(amber):
