@@ -1,6 +1,6 @@
 """Runs the same renders many times (fresh handles) and checks that images and ray counts never change: config 2 at 256 spp,
 config 3 at 16 spp, a striped band, and (round 5) the 1M-triangle terrain, the room mesh through the path-granular BVH kernel, a 49-object scene through
-the two-phase engine's groups."""
+the two-phase engine's groups, config 3 and the terrain through engine REFERENCE_BVH."""
 import sys, os, hashlib; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np
 import amber_amd as A
@@ -18,6 +18,8 @@ for i in range(n):
                             ("terrain @8", lambda: A.PathTracer(terrain, A.Sensor.default(1920, 1080), seed=2), 8),
                             ("room mesh @64", lambda: A.PathTracer(room, A.Sensor.default(1024, 1024), seed=2), 64),
                             ("49 objects @64", lambda: A.PathTracer(plus, A.Sensor.default(1024, 1024), seed=2), 64),
+                            ("config 3 through engine REFERENCE_BVH @16 (the host build runs on threads: same tree every time)", lambda: A.PathTracer(sph, A.Sensor.default(1920, 1080), seed=1, engine=A.ENGINE_REFERENCE_BVH), 16),
+                            ("terrain through engine REFERENCE_BVH @8", lambda: A.PathTracer(terrain, A.Sensor.default(1920, 1080), seed=2, engine=A.ENGINE_REFERENCE_BVH), 8),
                             ("config 5 stripes @64", lambda: A.PathTracer(box, A.Sensor.default(3840, 2160), seed=3, max_depth=16, rows=(8, 2160), stripe=(8, 64)), 64)):
         pt = make(); pt.render_pass(0, spp); img, rays = pt.download(); pt.close()
         seen.setdefault(name, set()).add((rays, hashlib.sha1(img.tobytes()).hexdigest()))
