@@ -318,7 +318,8 @@ def cold_start(amber_amd, seed: int, device: int, width: int, spp: int, engine: 
     import numpy as np
     scene = amber_amd.HostScene.cornell_box()
     best = None
-    for _ in range(3):
+    runs = []
+    for _ in range(5):
         t0 = time.perf_counter()
         pt = amber_amd.PathTracer(scene, amber_amd.Sensor.default(width, width), seed=seed, device=device, engine=engine)
         t1 = time.perf_counter()
@@ -333,9 +334,12 @@ def cold_start(amber_amd, seed: int, device: int, width: int, spp: int, engine: 
         cur = {"cold_wall_ms": round((t3 - t0) * 1e3, 3), "create_ms": round((t1 - t0) * 1e3, 3), "create_to_end_of_first_launch_ms": round((t2 - t0) * 1e3, 3),
                "first_launch_incl_pixel_masks_ms": round((t2 - t1) * 1e3, 3), "rest_and_download_ms": round((t3 - t2) * 1e3, 3),
                "launches": n_launch, "kernel_ms_total": round(ms, 3), "rays": int(rays)}
-        if best is None or cur["cold_wall_ms"] < best["cold_wall_ms"]:
+        runs.append(cur["create_to_end_of_first_launch_ms"])
+        if best is None or cur["create_to_end_of_first_launch_ms"] < best["create_to_end_of_first_launch_ms"]:
             best = cur
-    best["what"] = f"new handle, Cornell {width}x{width} @ {spp} spp: create -> frame downloaded (best of 3; warm process)"
+    best["create_to_end_of_first_launch_ms_all_runs"] = runs
+    best["what"] = (f"new handle, Cornell {width}x{width} @ {spp} spp: create -> frame downloaded; five new handles in a warm process, the fields are those of the run "
+                    "with the shortest create -> end of first launch (all five listed)")
     return best
 
 
