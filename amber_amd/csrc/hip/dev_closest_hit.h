@@ -46,8 +46,26 @@ __device__ __forceinline__ void ClosestHitReferenceBvh(const DevScene& sc, V3 o,
   constexpr uint32_t kNone = 0x7fffffffu;
   uint32_t top_ref = kNone; float top_in = 0.0f;
   int32_t cur = sc.bvh_root;                             // the root is cast without a test of its own box (:152-156)
+  constexpr int32_t kDone = 0x7fffffff;
+  // next subtree: the newest pending entry whose box the closest hit so far does not lie in front of (the recursion's return path, see above)
+  auto next_subtree = [&]() {
+    for (;;) {
+      uint32_t ref; float fin;
+      if (top_ref != kNone) { ref = top_ref; fin = top_in; top_ref = kNone; }
+      else if (sp > 0) { --sp; const uint2 e = stack[static_cast<size_t>(sp) * stride]; ref = e.x; fin = __uint_as_float(e.y); }
+      else { cur = kDone; return; }
+      if (!(best.t < fin)) { cur = static_cast<int32_t>(ref); return; }
+    }
+  };
+  // A lane's own sequence of visits is the recursion's; only how the lanes of a wave INTERLEAVE is a choice: up to AMBER_REF_BVH_BUDGET inner nodes,
+  // then (all lanes that have reached one) a leaf -- so that the long leaf scans run with many lanes instead of holding up lanes that only step
+  // through a node (one node or one leaf per trip: config 3 at 64 spp 59.7 ms; this form: see EXPERIMENTS.md round 5).
+#ifndef AMBER_REF_BVH_BUDGET
+#define AMBER_REF_BVH_BUDGET 4
+#endif
   for (;;) {
-    if (cur >= 0) {
+    int budget = AMBER_REF_BVH_BUDGET;
+    while (cur >= 0 && cur != kDone && budget-- > 0) {
       const uint4* nd = reinterpret_cast<const uint4*>(sc.ref_nodes + cur);
       const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
       const float lmin[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)}, lmax[3] = {__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y)};
@@ -62,11 +80,15 @@ __device__ __forceinline__ void ClosestHitReferenceBvh(const DevScene& sc, V3 o,
         if (top_ref != kNone) { stack[static_cast<size_t>(sp) * stride] = make_uint2(top_ref, __float_as_uint(top_in)); ++sp; }
         top_ref = far_; top_in = left_near ? rin : lin;                                                        // std::max(left_in, right_in)
         cur = left_near ? left : right;
-        continue;
+      } else if (lh) {
+        cur = left;
+      } else if (rh) {
+        cur = right;
+      } else {
+        next_subtree();
       }
-      if (lh) { cur = left; continue; }
-      if (rh) { cur = right; continue; }
-    } else {
+    }
+    if (cur < 0) {
       // (best.idx holds the leaf-order slot until the end: strict < needs no index, and the scene index is one load for the winner)
       const DevRefLeaf lf = sc.ref_leaves[-(cur + 1)];
       const uint32_t last = lf.first + (lf.count & 0x3fffffffu);
@@ -88,16 +110,9 @@ __device__ __forceinline__ void ClosestHitReferenceBvh(const DevScene& sc, V3 o,
           IntersectObject<false>(ob, ob.kind, static_cast<int>(k), static_cast<int>(k), o, d, best);
         }
       }
+      next_subtree();
     }
-    bool more = false;
-    for (;;) {
-      uint32_t ref; float fin;
-      if (top_ref != kNone) { ref = top_ref; fin = top_in; top_ref = kNone; }
-      else if (sp > 0) { --sp; const uint2 e = stack[static_cast<size_t>(sp) * stride]; ref = e.x; fin = __uint_as_float(e.y); }
-      else break;
-      if (!(best.t < fin)) { cur = static_cast<int32_t>(ref); more = true; break; }
-    }
-    if (!more) break;
+    if (cur == kDone) break;
   }
   if (best.slot >= 0) best.idx = static_cast<int>(sc.bvh_prims[best.slot]);
 }
