@@ -160,9 +160,9 @@ enum {
                                   per bounce, ballot/prefix-sum compaction; closest hit as AUTO.  Same results; kept to measure that design. */
   AMBER_ENGINE_REFERENCE_BVH = 6  /* the reference's own tree, built at create as acceleration_bvh.h:134-312 builds it (same topology, boxes and
                                   object order) and walked per lane in the order of BVH::Node::Cast (:340-403) with the reference's slab test
-                                  (aabb.cc:28-62): the image of the reference's command line, bit for bit.  Never chosen by AUTO: slower than
-                                  engine BVH (unquantised 64-byte nodes, large leaves, a stack in global memory), and the build sorts every node
-                                  four times like the reference does (1M spheres: seconds). */
+                                  (aabb.cc:28-62): the image of the reference's command line, bit for bit.  Never chosen by AUTO: 1.1x (1M spheres) to 2x
+                                  (the Cornell box) the time of the engine AUTO picks (unquantised 64-byte nodes, large leaves, a stack in global
+                                  memory), and the build sorts every node four times like the reference does (1M objects: under 2 s). */
 };
 
 #pragma GCC visibility push(hidden)            /* the handle is opaque: its members (and their constructors) are not part of the ABI */
