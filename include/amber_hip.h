@@ -158,6 +158,7 @@ enum {
   AMBER_ENGINE_BVH = 3,        /* host-built flattened 2-wide BVH, per-lane traversal with an LDS stack, exact leaf tests */
   AMBER_ENGINE_WAVEFRONT = 4,  /* LAB BUILD ONLY (the product answers AMBER_EINVAL): streaming formulation -- SoA ray queues in HBM, one launch
                                   per bounce, ballot/prefix-sum compaction; closest hit as AUTO.  Same results; kept to measure that design. */
+  /* 5 is reserved (the library's own id of the two-phase engine over groups of 32 objects; create answers AMBER_EINVAL) */
   AMBER_ENGINE_REFERENCE_BVH = 6  /* the reference's own tree, built at create as acceleration_bvh.h:134-312 builds it (same topology, boxes and
                                   object order) and walked per lane in the order of BVH::Node::Cast (:340-403) with the reference's slab test
                                   (aabb.cc:28-62): the image of the reference's command line, bit for bit.  Never chosen by AUTO: 1.1x (1M spheres) to 2x
