@@ -123,3 +123,25 @@ def test_command_line_with_engine_6_writes_the_reference_bvh_image(amber, tmp_pa
     osc = O.Scene.create_arrays(**wl.arrays(), accel=O.ACCEL_BVH | O.BLADES_LAST)
     oimg, _ = osc.render_xorshift(96, 64, 5, 0, 16, math=O.MATH_LIBM)
     assert np.array_equal(bits(parse_exr(out + ".exr")), bits((oimg / np.float32(16))[:, ::-1]))
+
+
+def test_stripes_of_three_ranks_through_the_references_tree_equal_the_whole_frame(amber):
+    """the sharding of bench.py --gpus N (interleaved 8-row stripes, one handle per rank) with this engine: every rank's rows are the whole frame's rows,
+    the ray counts add up -- a 300-object soup at 96 x 64"""
+    from amber_amd.distributed import stripe_partition
+    sc, _ = scene_for_seed(11)
+    hs = amber.HostScene.create(**sc)
+    W, H, spp = 96, 64, 16
+    pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=4, engine=amber.ENGINE_REFERENCE_BVH)
+    pt.render_pass(0, spp)
+    full, rays = pt.download()
+    pt.close()
+    total = 0
+    for part in stripe_partition(H, 3):
+        pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=4, rows=part["rows"], stripe=part["stripe"], engine=amber.ENGINE_REFERENCE_BVH)
+        pt.render_pass(0, spp)
+        img, r = pt.download()
+        pt.close()
+        total += r
+        assert np.array_equal(bits(img), bits(full[part["index"]]))
+    assert total == rays
