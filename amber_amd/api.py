@@ -72,7 +72,7 @@ class HostStats(C.Structure):
 PRIM_TRIANGLE, PRIM_SPHERE, PRIM_DISK, PRIM_CYLINDER = 0, 1, 2, 3
 MAT_LAMBERTIAN, MAT_PHONG, MAT_SPECULAR, MAT_REFRACTION, MAT_DIFFUSE_LIGHT, MAT_EYE = 0, 1, 2, 3, 4, 5
 ENGINE_AUTO, ENGINE_LIST, ENGINE_TWO_PHASE, ENGINE_BVH, ENGINE_WAVEFRONT = 0, 1, 2, 3, 4
-ENGINE_REFERENCE_BVH = 6     # the reference's own tree and traversal order: the image of the reference's command line bit for bit (include/amber_hip.h)
+ENGINE_REFERENCE_BVH = 6     # the reference's own tree and traversal order: every ray gets the hit the reference's BVH gives it (include/amber_hip.h)
 PT_FLAG_NULL_STREAM, PT_FLAG_BVH_POOL, PT_FLAG_BVH_ITEMS = 1, 2, 4
 
 # every symbol include/amber_hip.h and include/amber_host.h declare: what libamber_hip.so (the product) exports

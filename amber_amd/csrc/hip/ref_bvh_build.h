@@ -4,8 +4,8 @@
 // command line casts through its BVH (cornel_box.cc:198, application.cc:74-87), which is a slightly different function of the
 // ray: a distance tie goes to the object the traversal meets first, and a hit is lost when the near child's hit lies in front
 // of the far child's box although an object of the far child reaches out of that box by a rounding error
-// (acceleration_bvh.h:386-391).  On the 1M-sphere scene that is 117 of 2 073 600 pixels.  A user who needs the command line's
-// image bit for bit asks for AMBER_ENGINE_REFERENCE_BVH: this file builds the tree acceleration_bvh.h:134-312 builds -- same
+// (acceleration_bvh.h:386-391).  On the 1M-sphere scene that is 117 of 2 073 600 pixels.  A user who needs every ray to get the hit the
+// command line's BVH gives it asks for AMBER_ENGINE_REFERENCE_BVH: this file builds the tree acceleration_bvh.h:134-312 builds -- same
 // topology, same boxes, same object order inside the leaves -- and ClosestHitReferenceBvh (dev_closest_hit.h) walks it in the order
 // acceleration_bvh.h:340-403 does.
 //

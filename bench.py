@@ -191,7 +191,7 @@ def secondary_workloads(amber_amd, np, seed: int, device: int):
             "work-queue megakernel, engine BVH (16-bit quantised 2-wide tree, resumable LDS-stack traversal)")
     e["host_scene_s"] = round(t_scene, 3)
     out.append(e)
-    # the same frame through the reference's OWN tree and traversal order (AMBER_ENGINE_REFERENCE_BVH): what the reference's command line computes,
+    # the same frame through the reference's OWN tree and traversal order (AMBER_ENGINE_REFERENCE_BVH): the hits the reference's command line finds (oracle in its reference-BVH mode),
     # bit for bit (the List engines differ from it on 117 of this frame's pixels; profiles/r05_reference_bvh_full_frame.txt); create_s = the reference's build
     r = run("config 3 through AMBER_ENGINE_REFERENCE_BVH: the reference's own BVH (acceleration_bvh.h:134-403), 1920x1080 @ 256 spp", spheres, 1920, 1080, 256,
             "path-granular megakernel, per-lane walk of the reference's tree in the reference's order (binary32 boxes, stack in global memory)", engine=amber_amd.ENGINE_REFERENCE_BVH)

@@ -147,7 +147,7 @@ enum {
 
 /* All engines are the same persistent work-queue kernel; they differ in how a lane finds its closest hit.
  * Engines 1-4 return the List-semantics answer (closest finite hit, ties to the lower object index: acceleration_list.h:51-68).
- * REFERENCE_BVH returns what the reference's command line computes: Cast through the reference's own BVH
+ * REFERENCE_BVH returns the hit the reference's command line finds: Cast through the reference's own BVH
  * (acceleration_bvh.h:134-403), which differs from List on distance ties and on hits the reference's traversal loses
  * (INTEGRATION.md section 3). */
 enum {
@@ -161,7 +161,7 @@ enum {
   /* 5 is reserved (the library's own id of the two-phase engine over groups of 32 objects; create answers AMBER_EINVAL) */
   AMBER_ENGINE_REFERENCE_BVH = 6  /* the reference's own tree, built at create as acceleration_bvh.h:134-312 builds it (same topology, boxes and
                                   object order) and walked per lane in the order of BVH::Node::Cast (:340-403) with the reference's slab test
-                                  (aabb.cc:28-62): the image of the reference's command line, bit for bit.  Never chosen by AUTO: 1.1x (1M spheres) to 2x
+                                  (aabb.cc:28-62): ties and lost hits exactly as the reference's command line resolves them.  Never chosen by AUTO: 1.1x (1M spheres) to 2x
                                   (the Cornell box) the time of the engine AUTO picks (unquantised 64-byte nodes, large leaves, a stack in global
                                   memory), and the build sorts every node four times like the reference does (1M objects: under 2 s). */
 };

@@ -82,7 +82,7 @@ def check_band(amber, hs, osc, W, H, seed, spp, rows, max_ref_pixels, max_ref_ra
 
 def check_reference_engine(amber, hs, W, H, seed, spp, rows, reference_image, reference_casts, max_depth=0, label=""):
     """AMBER_ENGINE_REFERENCE_BVH (the reference's own tree, its own traversal order) on the same band: image bits and ray count
-    == oracle(ACCEL_BVH), i.e. what the reference's command line computes -- including the pixels on which the other engines differ."""
+    == oracle(ACCEL_BVH), i.e. what the reference's code computes through its BVH from the same random numbers -- including the pixels on which the other engines differ."""
     pt = amber.PathTracer(hs, amber.Sensor.default(W, H), seed=seed, rows=rows, engine=amber.ENGINE_REFERENCE_BVH, max_depth=max_depth)
     pt.render_pass(0, spp)
     img, rays = pt.download()

@@ -48,7 +48,7 @@ def test_config3_band_at_256spp_equals_the_list_oracle_and_every_difference_from
 
 
 def test_config3_band_through_the_references_own_tree_equals_the_reference_bvh_oracle(amber, config3, band):
-    """AMBER_ENGINE_REFERENCE_BVH: the same band, now including the pixels of the test above -- what the reference's command line renders
+    """AMBER_ENGINE_REFERENCE_BVH: the same band, now including the pixels of the test above -- what the reference's code renders through its BVH
     (acceleration_bvh.h:134-403), bit for bit."""
     check_reference_engine(amber, config3[0], W, H, SEED, SPP, BAND, band["reference_image"], band["reference_casts"], label="config 3")
 

@@ -1,6 +1,6 @@
 """AMBER_ENGINE_REFERENCE_BVH on the GPU: the reference's own tree (ref_bvh_build.h, proved equal to the oracle's restatement of
 acceleration_bvh.h:134-312 on the CPU in tests/test_reference_bvh_build.py) walked in the order of BVH::Node::Cast (:340-403).
-The bar is the reference's command line: image bits, ray counts and every path's hit sequence == oracle(ACCEL_BVH) -- no tie or
+The bar is the reference's own closest hit: image bits, ray counts and every path's hit sequence == oracle(ACCEL_BVH) -- no tie or
 lost-hit pixel left over.  (The bands of config 3 and of the mesh workloads: tests/test_config3_parity_gpu.py, test_mesh_workloads.py.)"""
 import numpy as np
 import pytest
